@@ -1,0 +1,91 @@
+"""ctypes binding of libbohip.so (include/bohip.h).  No CPU fallback: importing works without a
+GPU (so the ABI can be inspected), but every compute entry point raises when the library or the
+device is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbohip.so")
+
+OK, E_ARG, E_NOTPD, E_HIP, E_NODEVICE, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+KERN = {"SEArd": 0, "SEIso": 1, "Mat52Ard": 2}
+ACQ = {"EI": 0, "PI": 1, "UCB": 2, "MI": 3, "MaxMean": 4}
+INFO_PIVOT, INFO_CAPACITY, INFO_REFITS, INFO_APPENDS = 0, 1, 2, 3
+
+
+class Best(C.Structure):
+    _fields_ = [("val", C.c_double), ("idx", C.c_int64)]
+
+
+class BohipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbohip error {code}: {msg}")
+        self.code = code
+
+
+class NotPositiveDefinite(BohipError):
+    pass
+
+
+_dp = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_gp = C.c_void_p
+
+# every symbol include/bohip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "bohip_gp_create": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.POINTER(_gp)]),
+    "bohip_gp_destroy": (None, [_gp]),
+    "bohip_gp_set_hyper": (C.c_int, [_gp, _dp, C.c_double, C.c_double, C.c_double]),
+    "bohip_gp_append": (C.c_int, [_gp, _dp, _dp, C.c_int64]),
+    "bohip_gp_refit": (C.c_int, [_gp]),
+    "bohip_gp_dims": (C.c_int, [_gp, _i64p, _i64p]),
+    "bohip_gp_maxy": (C.c_int, [_gp, _dp]),
+    "bohip_gp_get_xy": (C.c_int, [_gp, _dp, _dp]),
+    "bohip_gp_mll": (C.c_int, [_gp, _dp]),
+    "bohip_gp_predict": (C.c_int, [_gp, _dp, C.c_int64, _dp, _dp]),
+    "bohip_gp_score": (C.c_int, [_gp, C.c_int, _dp, _dp, C.c_int64, _dp, C.POINTER(Best)]),
+    "bohip_gp_score_grad": (C.c_int, [_gp, C.c_int, _dp, _dp, C.c_int64, _dp, _dp]),
+    "bohip_gp_thompson": (C.c_int, [_gp, _dp, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.POINTER(Best)]),
+    "bohip_thompson_normal": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64]),
+    "bohip_gp_score_dev": (C.c_int, [_gp, C.c_int, _dp, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bohip_gp_predict_dev": (C.c_int, [_gp, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "bohip_gp_set_stream": (C.c_int, [_gp, C.c_void_p]),
+    "bohip_gp_synchronize": (C.c_int, [_gp]),
+    "bohip_gp_get_factor": (C.c_int, [_gp, _dp]),
+    "bohip_gp_get_alpha": (C.c_int, [_gp, _dp]),
+    "bohip_gp_info": (C.c_int, [_gp, C.c_int, _i64p]),
+    "bohip_gp_enable_timing": (C.c_int, [_gp, C.c_int]),
+    "bohip_gp_get_timing": (C.c_int, [_gp, C.POINTER(C.c_char_p), _dp, C.c_int]),
+    "bohip_last_error": (C.c_char_p, []),
+    "bohip_version": (C.c_char_p, []),
+    "bohip_device_count": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libbohip.so and bind every declared symbol.  Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BohipError(E_NODEVICE, f"{LIB_PATH} not built (run __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == OK:
+        return
+    msg = load().bohip_last_error().decode()
+    if rc == E_NOTPD:
+        raise NotPositiveDefinite(rc, msg)
+    raise BohipError(rc, msg)

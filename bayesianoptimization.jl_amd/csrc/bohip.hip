@@ -1,0 +1,679 @@
+// bohip.hip -- libbohip.so: C ABI (include/bohip.h) + host orchestration of the gfx950 kernels.
+// Single translation unit (the kernel files are included) so one hipcc invocation builds the library.
+//
+// HBM layout per handle (capacity C observations, ld = round_up(C + 1, 128)):
+//   dX  [C][d]      observations, row = one observation (= Julia's d x N column-major)
+//   dy  [C]
+//   dL  [ld][ld]    row-major; lower 128-tiles hold cK then its Cholesky factor L (= Julia's upper U
+//                   read column-major); strict-upper tiles stay zero; rows/cols >= N identity padding
+//   dW  [ld][ld]    W = L^-1 (lower).  Row N (first padding row) carries alpha' so the scoring
+//                   contraction V = W K* also produces mu - beta.
+//   dS  [ld][ld]    scratch for the recursive triangular inverse
+//   dKsT [Rc][ld]   cross-covariance chunk, candidate-major
+// There is NO CPU fallback: every entry point that computes fails with BOHIP_E_NODEVICE / BOHIP_E_HIP
+// when the GPU is unavailable.
+#include "../../include/bohip.h"
+#include "kernels_linalg.hip"
+#include "kernels_score.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+using namespace bohip;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(BOHIP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ \
+                                         ":" + std::to_string(__LINE__) + ")");                        \
+    } while (0)
+#define CHK(expr)              \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+static_assert(sizeof(bohip_best) == sizeof(Best), "record layout");
+
+struct StageTimer {
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
+    std::vector<std::pair<std::string, double>> result;
+};
+
+struct bohip_gp {
+    int device = 0, d = 0, kern = 0;
+    int64_t n = 0, cap = 0, ld = 0;
+    double *dX = nullptr, *dy = nullptr, *dL = nullptr, *dW = nullptr, *dS = nullptr;
+    double *dalpha = nullptr, *dr = nullptr, *dt = nullptr, *dmll = nullptr;
+    int* dinfo = nullptr;
+    std::vector<double> hX, hy;
+    double loglen[DMAX], logsig = 0.0, lognoise = -2.0, beta = 0.0;
+    bool stale = true;
+    int64_t n_factored = 0;  // observations covered by the current factor
+    hipStream_t stream = nullptr, own_stream = nullptr;
+    // scoring scratch
+    double* dKsT = nullptr;
+    int64_t kst_rows = 0;
+    double *dq = nullptr, *dmu_raw = nullptr, *dXs = nullptr, *dmu = nullptr, *dvar = nullptr, *dscore = nullptr;
+    int64_t q_cap = 0, r_cap = 0, xs_cap = 0;
+    Best *dblock_best = nullptr, *dbest = nullptr;
+    int64_t bb_cap = 0;
+    // bookkeeping
+    int64_t pivot = 0, refits = 0, appends = 0;
+    bool timing = false;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> tev;
+    std::vector<std::string> tnames;
+    std::vector<double> tms;
+};
+
+static KernelHyper make_hyper(const bohip_gp* g) {
+    KernelHyper h;
+    h.kern = g->kern;
+    h.d = g->d;
+    h.sigma2 = std::exp(2.0 * g->logsig);
+    for (int k = 0; k < DMAX; ++k) h.il2[k] = 0.0;
+    for (int k = 0; k < g->d; ++k) h.il2[k] = std::exp(-2.0 * g->loglen[g->kern == KERN_SEISO ? 0 : k]);
+    return h;
+}
+
+// ---- stage timing (HIP events on the handle's stream) ---------------------------------------------
+static void t_begin(bohip_gp* g, const char* name) {
+    if (!g->timing) return;
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipEventRecord(a, g->stream);
+    g->tev.push_back({name, {a, b}});
+}
+static void t_end(bohip_gp* g) {
+    if (!g->timing || g->tev.empty()) return;
+    hipEventRecord(g->tev.back().second.second, g->stream);
+}
+static void t_reset(bohip_gp* g) {
+    for (auto& e : g->tev) {
+        hipEventDestroy(e.second.first);
+        hipEventDestroy(e.second.second);
+    }
+    g->tev.clear();
+}
+static void t_collect(bohip_gp* g) {
+    if (!g->timing) return;
+    g->tnames.clear();
+    g->tms.clear();
+    for (auto& e : g->tev) {
+        hipEventSynchronize(e.second.second);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e.second.first, e.second.second);
+        g->tnames.push_back(e.first);
+        g->tms.push_back(ms);
+    }
+    t_reset(g);
+}
+
+// ---- allocation -----------------------------------------------------------------------------------
+static int free_model(bohip_gp* g) {
+    for (double** p : {&g->dX, &g->dy, &g->dL, &g->dW, &g->dS, &g->dalpha, &g->dr, &g->dt})
+        if (*p) { hipFree(*p); *p = nullptr; }
+    return 0;
+}
+static int alloc_model(bohip_gp* g, int64_t cap) {
+    free_model(g);
+    g->cap = cap;
+    g->ld = round_up(cap + 1, TILE);
+    const size_t mat = (size_t)g->ld * g->ld * sizeof(double);
+    HIPCHK(hipMalloc(&g->dX, std::max<size_t>(8, (size_t)cap * g->d * 8)));
+    HIPCHK(hipMalloc(&g->dy, std::max<size_t>(8, (size_t)cap * 8)));
+    HIPCHK(hipMalloc(&g->dL, mat));
+    HIPCHK(hipMalloc(&g->dW, mat));
+    HIPCHK(hipMalloc(&g->dS, mat));
+    HIPCHK(hipMalloc(&g->dalpha, g->ld * 8));
+    HIPCHK(hipMalloc(&g->dr, g->ld * 8));
+    HIPCHK(hipMalloc(&g->dt, g->ld * 8));
+    HIPCHK(hipMemsetAsync(g->dL, 0, mat, g->stream));
+    HIPCHK(hipMemsetAsync(g->dW, 0, mat, g->stream));
+    HIPCHK(hipMemsetAsync(g->dS, 0, mat, g->stream));
+    if (g->n > 0) {
+        HIPCHK(hipMemcpyAsync(g->dX, g->hX.data(), (size_t)g->n * g->d * 8, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(g->dy, g->hy.data(), (size_t)g->n * 8, hipMemcpyHostToDevice, g->stream));
+    }
+    g->stale = true;
+    return 0;
+}
+
+// ---- GEMM launcher --------------------------------------------------------------------------------
+static int launch_gemm(bohip_gp* g, bool b_nmajor, const GemmParams& p, int batch) {
+    const int tiles = p.lower_tiles ? p.mt * (p.mt + 1) / 2 : p.mt * p.nt;
+    if (tiles <= 0 || batch <= 0 || p.kc <= 0) return 0;
+    dim3 grid(tiles, batch);
+    if (b_nmajor)
+        hipLaunchKernelGGL(k_gemm<true>, grid, dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, p);
+    else
+        hipLaunchKernelGGL(k_gemm<false>, grid, dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int one_time_kernel_setup() {
+    static bool done = false;
+    if (done) return 0;
+    HIPCHK(hipFuncSetAttribute((const void*)k_potf2_inv, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    done = true;
+    return 0;
+}
+
+// ---- A1-A3: full rebuild --------------------------------------------------------------------------
+static int compute_alpha(bohip_gp* g) {
+    const int64_t N = g->n;
+    hipLaunchKernelGGL(k_sub_mean, dim3((N + 255) / 256), dim3(256), 0, g->stream, g->dy, g->beta, N, g->dr);
+    hipLaunchKernelGGL(k_trimv, dim3((N + 3) / 4), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dr, g->dt);
+    hipLaunchKernelGGL(k_trimv_t, dim3((N + 63) / 64), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dt, g->dalpha);
+    HIPCHK(hipGetLastError());
+    // alpha' into the first padding row of W (cols < N); W[N][N] = 1 meets K*[N] = 0.
+    HIPCHK(hipMemcpyAsync(g->dW + N * g->ld, g->dalpha, (size_t)N * 8, hipMemcpyDeviceToDevice, g->stream));
+    return 0;
+}
+
+static int check_info(bohip_gp* g) {
+    int info = 0;
+    HIPCHK(hipMemcpyAsync(&info, g->dinfo, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (info != 0) {
+        g->pivot = info;
+        g->stale = true;
+        return fail(BOHIP_E_NOTPD, "kernel matrix not positive definite at pivot " + std::to_string(info));
+    }
+    g->pivot = 0;
+    return 0;
+}
+
+static int refit(bohip_gp* g) {
+    CHK(one_time_kernel_setup());
+    const int64_t N = g->n;
+    if (N == 0) {
+        g->stale = false;
+        g->n_factored = 0;
+        return 0;
+    }
+    const int64_t Npad = round_up(N + 1, TILE), ld = g->ld;
+    const int T = (int)(Npad / TILE);
+    const KernelHyper hp = make_hyper(g);
+    const double noise = std::exp(2.0 * g->lognoise) + std::numeric_limits<double>::epsilon();
+    HIPCHK(hipMemsetAsync(g->dinfo, 0, sizeof(int), g->stream));
+    t_begin(g, "build_cov");
+    hipLaunchKernelGGL(k_build_cov, dim3(Npad / 64, Npad / 64), dim3(256), 2 * 64 * g->d * 8, g->stream, g->dX, N, Npad,
+                       hp, noise, g->dL, ld, (int64_t)0);
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    t_begin(g, "cholesky");
+    for (int kb = 0; kb < T; ++kb) {
+        double* Lkk = g->dL + (int64_t)kb * TILE * (ld + 1);
+        double* Wkk = g->dW + (int64_t)kb * TILE * (ld + 1);
+        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(256), POTF2_LDS_BYTES, g->stream, Lkk, ld, Wkk, ld, g->dinfo,
+                           kb * TILE);
+        HIPCHK(hipGetLastError());
+        const int rem = T - kb - 1;
+        if (rem == 0) break;
+        GemmParams p{};
+        double* panel = g->dL + (int64_t)(kb + 1) * TILE * ld + (int64_t)kb * TILE;
+        // panel solve  L[i,kb] = A[i,kb] * inv(L_kk)'   (in place: each tile reads only its own rows)
+        p.A = panel; p.lda = ld; p.B = Wkk; p.ldb = ld; p.C = panel; p.ldc = ld;
+        p.mt = rem; p.nt = 1; p.kc = TILE / KC; p.alpha = 1.0; p.beta = 0.0;
+        CHK(launch_gemm(g, false, p, 1));
+        // trailing update  A[i,j] -= L[i,kb] L[j,kb]'  on lower tiles
+        GemmParams s{};
+        s.A = panel; s.lda = ld; s.B = panel; s.ldb = ld;
+        s.C = g->dL + (int64_t)(kb + 1) * TILE * (ld + 1); s.ldc = ld;
+        s.mt = rem; s.nt = rem; s.kc = TILE / KC; s.alpha = -1.0; s.beta = 1.0; s.lower_tiles = 1;
+        CHK(launch_gemm(g, false, s, 1));
+    }
+    t_end(g);
+    // W = L^-1 by recursive doubling over diagonal blocks:
+    //   [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22]
+    t_begin(g, "tri_inverse");
+    for (int h = 1; h < T; h *= 2) {  // h = half-block size in tiles
+        const int pairs = (T + 2 * h - 1) / (2 * h);
+        const int64_t zstride = (int64_t)2 * h * TILE * (ld + 1);
+        // S21 = L21 * W11   (B = W11 in N-major form, lower-triangular -> k starts at the column tile)
+        GemmParams a{};
+        a.A = g->dL + (int64_t)h * TILE * ld; a.lda = ld;
+        a.B = g->dW; a.ldb = ld;
+        a.C = g->dS + (int64_t)h * TILE * ld; a.ldc = ld;
+        a.zA = a.zB = a.zC = zstride;
+        a.mt = h; a.nt = h; a.kc = h * (TILE / KC); a.alpha = 1.0; a.beta = 0.0; a.klo_from_n = 1;
+        a.z_row0 = h; a.z_rstride = 2 * h; a.total_rows = T;
+        CHK(launch_gemm(g, true, a, pairs));
+        // W21 = -W22 * S21  (A = W22 lower-triangular -> k stops at the row tile)
+        GemmParams b{};
+        b.A = g->dW + (int64_t)h * TILE * (ld + 1); b.lda = ld;
+        b.B = g->dS + (int64_t)h * TILE * ld; b.ldb = ld;
+        b.C = g->dW + (int64_t)h * TILE * ld; b.ldc = ld;
+        b.zA = b.zB = b.zC = zstride;
+        b.mt = h; b.nt = h; b.kc = h * (TILE / KC); b.alpha = -1.0; b.beta = 0.0; b.khi_from_m = 1;
+        b.z_row0 = h; b.z_rstride = 2 * h; b.total_rows = T;
+        CHK(launch_gemm(g, true, b, pairs));
+    }
+    t_end(g);
+    t_begin(g, "alpha");
+    CHK(compute_alpha(g));
+    t_end(g);
+    CHK(check_info(g));
+    g->stale = false;
+    g->n_factored = N;
+    g->refits++;
+    return 0;
+}
+
+static int ensure_fresh(bohip_gp* g) {
+    if (g->stale || g->n_factored != g->n) return refit(g);
+    return 0;
+}
+
+// ---- scoring --------------------------------------------------------------------------------------
+static int64_t chunk_rows(const bohip_gp* g) {
+    // keep the K*' chunk around 128 MB so it stays in the 256 MB Infinity Cache next to W
+    int64_t rows = (int64_t)(128.0 * 1024 * 1024 / (8.0 * g->ld));
+    rows = std::max<int64_t>(1024, std::min<int64_t>(8192, rows / TILE * TILE));
+    return rows;
+}
+static int ensure_score_scratch(bohip_gp* g, int64_t R) {
+    const int64_t Rpad = round_up(std::max<int64_t>(R, 1), TILE);
+    const int64_t T = g->ld / TILE;
+    const int64_t rc = std::min(chunk_rows(g), Rpad);
+    if (g->kst_rows < rc || g->dKsT == nullptr) {
+        if (g->dKsT) hipFree(g->dKsT);
+        g->dKsT = nullptr;
+        HIPCHK(hipMalloc(&g->dKsT, (size_t)rc * g->ld * 8));
+        g->kst_rows = rc;
+    }
+    if (g->q_cap < T * Rpad) {
+        if (g->dq) hipFree(g->dq);
+        g->dq = nullptr;
+        HIPCHK(hipMalloc(&g->dq, (size_t)T * Rpad * 8));
+        g->q_cap = T * Rpad;
+    }
+    if (g->r_cap < Rpad) {
+        for (double** p : {&g->dmu_raw, &g->dmu, &g->dvar, &g->dscore})
+            if (*p) { hipFree(*p); *p = nullptr; }
+        HIPCHK(hipMalloc(&g->dmu_raw, Rpad * 8));
+        HIPCHK(hipMalloc(&g->dmu, Rpad * 8));
+        HIPCHK(hipMalloc(&g->dvar, Rpad * 8));
+        HIPCHK(hipMalloc(&g->dscore, Rpad * 8));
+        g->r_cap = Rpad;
+    }
+    const int64_t nb = (R + 255) / 256 + 1;
+    if (g->bb_cap < nb) {
+        if (g->dblock_best) hipFree(g->dblock_best);
+        g->dblock_best = nullptr;
+        HIPCHK(hipMalloc(&g->dblock_best, nb * sizeof(Best)));
+        g->bb_cap = nb;
+    }
+    return 0;
+}
+static int ensure_xs(bohip_gp* g, int64_t R) {
+    if (g->xs_cap < R * g->d) {
+        if (g->dXs) hipFree(g->dXs);
+        g->dXs = nullptr;
+        HIPCHK(hipMalloc(&g->dXs, std::max<size_t>(8, (size_t)R * g->d * 8)));
+        g->xs_cap = R * g->d;
+    }
+    return 0;
+}
+
+template <int DT>
+static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, int64_t Npad, const KernelHyper& hp) {
+    const int rb = 64;
+    dim3 grid((Npad + 255) / 256, (r1 - r0 + rb - 1) / rb);
+    hipLaunchKernelGGL(k_kstar<DT>, grid, dim3(256), 0, g->stream, g->dX, g->n, Npad, dXs, r0, r1, hp, g->dKsT, g->ld, rb);
+}
+
+// posterior pass over all R candidates: fills dq (partials) and dmu_raw.  VT optional (chunk-local).
+static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
+    CHK(one_time_kernel_setup());
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE);
+    const int T = (int)(Npad / TILE);
+    const KernelHyper hp = make_hyper(g);
+    const int64_t rc = g->kst_rows;
+    for (int64_t r0 = 0; r0 < R; r0 += rc) {
+        const int64_t r1 = std::min(R, r0 + rc);
+        t_begin(g, "kstar");
+        if (g->d <= 2) launch_kstar<2>(g, dXs, r0, r1, Npad, hp);
+        else if (g->d <= 4) launch_kstar<4>(g, dXs, r0, r1, Npad, hp);
+        else if (g->d <= 8) launch_kstar<8>(g, dXs, r0, r1, Npad, hp);
+        else if (g->d <= 16) launch_kstar<16>(g, dXs, r0, r1, Npad, hp);
+        else if (g->d <= 32) launch_kstar<32>(g, dXs, r0, r1, Npad, hp);
+        else launch_kstar<64>(g, dXs, r0, r1, Npad, hp);
+        HIPCHK(hipGetLastError());
+        t_end(g);
+        const int CT = (int)((r1 - r0 + TILE - 1) / TILE);
+        const int n_local = (CT + 7) / 8;
+        t_begin(g, "trigemm_sq");
+        hipLaunchKernelGGL(k_trigemm_sq, dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, (double*)nullptr, (int64_t)0);
+        HIPCHK(hipGetLastError());
+        t_end(g);
+    }
+    return 0;
+}
+
+static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const double* dXs, int64_t R, double* d_mu,
+                      double* d_var, double* d_score, Best* d_best) {
+    if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
+    CHK(ensure_fresh(g));
+    CHK(ensure_score_scratch(g, R));
+    CHK(posterior_pass(g, dXs, R));
+    AcqParams ap{acq_id, 0.0, 0.0};
+    if (acq_params) {
+        if (acq_id != BOHIP_ACQ_MAXMEAN) ap.p0 = acq_params[0];
+        if (acq_id == BOHIP_ACQ_MI) ap.p1 = acq_params[1];
+    } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
+        return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
+    }
+    const int64_t Npad = round_up(g->n + 1, TILE), Rpad = round_up(R, TILE);
+    const int T = (int)(Npad / TILE);
+    const int nb = (int)((R + 255) / 256);
+    t_begin(g, "score");
+    hipLaunchKernelGGL(k_score, dim3(nb), dim3(256), 0, g->stream, g->dq, Rpad, T, g->dmu_raw, R,
+                       std::exp(2.0 * g->logsig), g->beta, ap, d_mu, d_var, d_score, d_best ? g->dblock_best : nullptr);
+    if (d_best) hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, g->stream, g->dblock_best, nb, d_best);
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    return 0;
+}
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* bohip_last_error(void) { return g_err.c_str(); }
+const char* bohip_version(void) { return "bohip 0.1 (gfx950, fp64 mfma 4x4x4)"; }
+int bohip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohip_gp** out) {
+    if (!out) return fail(BOHIP_E_ARG, "out is null");
+    *out = nullptr;
+    if (d < 1 || d > DMAX) return fail(BOHIP_E_ARG, "d must be in [1, 64]");
+    if (capacity < 1) capacity = 1;
+    if (kernel_id < 0 || kernel_id > 2) return fail(BOHIP_E_ARG, "unknown kernel_id");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(BOHIP_E_NODEVICE, "no HIP device visible; libbohip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(BOHIP_E_ARG, "device ordinal out of range");
+    HIPCHK(hipSetDevice(device));
+    bohip_gp* g = new bohip_gp();
+    g->device = device;
+    g->d = (int)d;
+    g->kern = kernel_id;
+    for (int k = 0; k < DMAX; ++k) g->loglen[k] = 0.0;
+    hipError_t e = hipStreamCreateWithFlags(&g->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete g; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
+    g->stream = g->own_stream;
+    if (hipMalloc(&g->dinfo, sizeof(int)) != hipSuccess || hipMalloc(&g->dmll, 8) != hipSuccess ||
+        hipMalloc(&g->dbest, 4096 * sizeof(Best)) != hipSuccess) {
+        delete g;
+        return fail(BOHIP_E_HIP, "hipMalloc failed");
+    }
+    int rc = alloc_model(g, capacity);
+    if (rc != 0) { bohip_gp_destroy(g); return rc; }
+    *out = g;
+    return 0;
+}
+
+void bohip_gp_destroy(bohip_gp* g) {
+    if (!g) return;
+    hipSetDevice(g->device);
+    if (g->own_stream) hipStreamSynchronize(g->own_stream);
+    free_model(g);
+    for (double** p : {&g->dKsT, &g->dq, &g->dmu_raw, &g->dXs, &g->dmu, &g->dvar, &g->dscore, &g->dmll})
+        if (*p) hipFree(*p);
+    if (g->dblock_best) hipFree(g->dblock_best);
+    if (g->dbest) hipFree(g->dbest);
+    if (g->dinfo) hipFree(g->dinfo);
+    t_reset(g);
+    if (g->own_stream) hipStreamDestroy(g->own_stream);
+    delete g;
+}
+
+int bohip_gp_set_hyper(bohip_gp* g, const double* loglen, double logsig, double lognoise, double mean_const) {
+    if (!g || !loglen) return fail(BOHIP_E_ARG, "null argument");
+    const int nl = g->kern == KERN_SEISO ? 1 : g->d;
+    for (int k = 0; k < nl; ++k) g->loglen[k] = loglen[k];
+    if (g->kern == KERN_SEISO)
+        for (int k = 1; k < g->d; ++k) g->loglen[k] = loglen[0];
+    g->logsig = logsig;
+    g->lognoise = lognoise;
+    g->beta = mean_const;
+    g->stale = true;
+    return 0;
+}
+
+int bohip_gp_append(bohip_gp* g, const double* X, const double* y, int64_t p) {
+    if (!g || p < 0 || (p > 0 && (!X || !y))) return fail(BOHIP_E_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    if (p > 0) {
+        g->hX.insert(g->hX.end(), X, X + p * g->d);
+        g->hy.insert(g->hy.end(), y, y + p);
+        const int64_t n_new = g->n + p;
+        if (n_new > g->cap) {
+            g->n = n_new;
+            CHK(alloc_model(g, std::max<int64_t>(2 * g->cap, n_new)));
+        } else {
+            HIPCHK(hipMemcpyAsync(g->dX + g->n * g->d, X, (size_t)p * g->d * 8, hipMemcpyHostToDevice, g->stream));
+            HIPCHK(hipMemcpyAsync(g->dy + g->n, y, (size_t)p * 8, hipMemcpyHostToDevice, g->stream));
+            HIPCHK(hipStreamSynchronize(g->stream));  // caller's buffers are only valid during the call
+            g->n = n_new;
+        }
+    }
+    int rc = ensure_fresh(g);
+    HIPCHK(hipStreamSynchronize(g->stream));
+    t_collect(g);
+    return rc;
+}
+
+int bohip_gp_refit(bohip_gp* g) {
+    if (!g) return fail(BOHIP_E_ARG, "null handle");
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    int rc = refit(g);
+    HIPCHK(hipStreamSynchronize(g->stream));
+    t_collect(g);
+    return rc;
+}
+
+int bohip_gp_dims(const bohip_gp* g, int64_t* d, int64_t* n) {
+    if (!g) return fail(BOHIP_E_ARG, "null handle");
+    if (d) *d = g->d;
+    if (n) *n = g->n;
+    return 0;
+}
+int bohip_gp_maxy(const bohip_gp* g, double* maxy) {
+    if (!g || !maxy) return fail(BOHIP_E_ARG, "null argument");
+    double m = -INFINITY;
+    for (double v : g->hy) if (v > m) m = v;
+    *maxy = m;
+    return 0;
+}
+int bohip_gp_get_xy(const bohip_gp* g, double* X, double* y) {
+    if (!g) return fail(BOHIP_E_ARG, "null handle");
+    if (X && g->n) std::memcpy(X, g->hX.data(), (size_t)g->n * g->d * 8);
+    if (y && g->n) std::memcpy(y, g->hy.data(), (size_t)g->n * 8);
+    return 0;
+}
+
+int bohip_gp_mll(bohip_gp* g, double* mll) {
+    if (!g || !mll) return fail(BOHIP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(g->device));
+    if (g->n == 0) { *mll = 0.0; return 0; }
+    CHK(ensure_fresh(g));
+    hipLaunchKernelGGL(k_mll, dim3(1), dim3(256), 0, g->stream, g->dL, g->ld, g->n, g->dr, g->dalpha, g->dmll);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(mll, g->dmll, 8, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int bohip_gp_predict_dev(bohip_gp* g, const double* dXs, int64_t R, double* d_mu, double* d_var) {
+    if (!g || !dXs || R < 0) return fail(BOHIP_E_ARG, "bad arguments");
+    if (R == 0) return 0;
+    HIPCHK(hipSetDevice(g->device));
+    return score_core(g, BOHIP_ACQ_MAXMEAN, nullptr, dXs, R, d_mu, d_var, nullptr, nullptr);
+}
+
+int bohip_gp_score_dev(bohip_gp* g, int acq_id, const double* acq_params, const double* dXs, int64_t R,
+                       double* d_score, bohip_best* d_best) {
+    if (!g || !dXs || R < 0) return fail(BOHIP_E_ARG, "bad arguments");
+    if (acq_id < 0 || acq_id > BOHIP_ACQ_MAXMEAN) return fail(BOHIP_E_ARG, "unknown acq_id");
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    if (R == 0) {
+        if (d_best) {
+            Best b{-INFINITY, -1};
+            HIPCHK(hipMemcpyAsync(d_best, &b, sizeof(b), hipMemcpyHostToDevice, g->stream));
+            HIPCHK(hipStreamSynchronize(g->stream));
+        }
+        return 0;
+    }
+    return score_core(g, acq_id, acq_params, dXs, R, nullptr, nullptr, d_score, reinterpret_cast<Best*>(d_best));
+}
+
+int bohip_gp_predict(bohip_gp* g, const double* Xs, int64_t R, double* mu, double* var) {
+    if (!g || R < 0 || (R > 0 && (!Xs || !mu || !var))) return fail(BOHIP_E_ARG, "bad arguments");
+    if (R == 0) return 0;
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    CHK(ensure_xs(g, R));
+    CHK(ensure_score_scratch(g, R));
+    HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
+    CHK(score_core(g, BOHIP_ACQ_MAXMEAN, nullptr, g->dXs, R, g->dmu, g->dvar, nullptr, nullptr));
+    HIPCHK(hipMemcpyAsync(mu, g->dmu, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipMemcpyAsync(var, g->dvar, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    t_collect(g);
+    return 0;
+}
+
+int bohip_gp_score(bohip_gp* g, int acq_id, const double* acq_params, const double* Xs, int64_t R, double* score,
+                   bohip_best* best) {
+    if (!g || R < 0 || (R > 0 && !Xs)) return fail(BOHIP_E_ARG, "bad arguments");
+    if (acq_id < 0 || acq_id > BOHIP_ACQ_MAXMEAN) return fail(BOHIP_E_ARG, "unknown acq_id");
+    if (R == 0) {
+        if (best) { best->val = -INFINITY; best->idx = -1; }
+        return 0;
+    }
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    CHK(ensure_xs(g, R));
+    CHK(ensure_score_scratch(g, R));
+    HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
+    CHK(score_core(g, acq_id, acq_params, g->dXs, R, nullptr, nullptr, score ? g->dscore : nullptr,
+                   best ? g->dbest : nullptr));
+    if (score) HIPCHK(hipMemcpyAsync(score, g->dscore, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
+    if (best) HIPCHK(hipMemcpyAsync(best, g->dbest, sizeof(Best), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    t_collect(g);
+    return 0;
+}
+
+int bohip_gp_score_grad(bohip_gp*, int, const double*, const double*, int64_t, double*, double*) {
+    return fail(BOHIP_E_UNSUPPORTED, "score_grad: not built yet");
+}
+
+double bohip_thompson_normal(uint64_t seed, int64_t s, int64_t j) { return thompson_normal(seed, s, j); }
+
+int bohip_gp_thompson(bohip_gp* g, const double* Xs, int64_t R, int64_t S, uint64_t seed, int64_t j0, bohip_best* best) {
+    if (!g || R <= 0 || S <= 0 || !Xs || !best) return fail(BOHIP_E_ARG, "bad arguments");
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    CHK(ensure_xs(g, R));
+    CHK(ensure_score_scratch(g, R));
+    HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
+    CHK(score_core(g, BOHIP_ACQ_MAXMEAN, nullptr, g->dXs, R, g->dmu, g->dvar, nullptr, nullptr));
+    Best* dout = nullptr;
+    HIPCHK(hipMalloc(&dout, S * sizeof(Best)));
+    t_begin(g, "thompson");
+    hipLaunchKernelGGL(k_thompson, dim3(S), dim3(256), 0, g->stream, g->dmu, g->dvar, R, seed, j0, dout);
+    t_end(g);
+    hipError_t e = hipMemcpyAsync(best, dout, S * sizeof(Best), hipMemcpyDeviceToHost, g->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    hipFree(dout);
+    if (e != hipSuccess) return fail(BOHIP_E_HIP, hipGetErrorString(e));
+    t_collect(g);
+    return 0;
+}
+
+int bohip_gp_set_stream(bohip_gp* g, void* stream) {
+    if (!g) return fail(BOHIP_E_ARG, "null handle");
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->stream = stream ? (hipStream_t)stream : g->own_stream;
+    return 0;
+}
+int bohip_gp_synchronize(bohip_gp* g) {
+    if (!g) return fail(BOHIP_E_ARG, "null handle");
+    HIPCHK(hipStreamSynchronize(g->stream));
+    t_collect(g);
+    return 0;
+}
+
+int bohip_gp_get_factor(bohip_gp* g, double* L) {
+    if (!g || !L) return fail(BOHIP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(g->device));
+    CHK(ensure_fresh(g));
+    if (g->n == 0) return 0;
+    HIPCHK(hipMemcpy2DAsync(L, g->n * 8, g->dL, g->ld * 8, g->n * 8, g->n, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+int bohip_gp_get_alpha(bohip_gp* g, double* alpha) {
+    if (!g || !alpha) return fail(BOHIP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(g->device));
+    CHK(ensure_fresh(g));
+    if (g->n == 0) return 0;
+    HIPCHK(hipMemcpyAsync(alpha, g->dalpha, g->n * 8, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
+    if (!g || !value) return fail(BOHIP_E_ARG, "null argument");
+    switch (what) {
+        case BOHIP_INFO_PIVOT: *value = g->pivot; return 0;
+        case BOHIP_INFO_CAPACITY: *value = g->cap; return 0;
+        case BOHIP_INFO_REFITS: *value = g->refits; return 0;
+        case BOHIP_INFO_APPENDS: *value = g->appends; return 0;
+        default: return fail(BOHIP_E_ARG, "unknown info id");
+    }
+}
+int bohip_gp_enable_timing(bohip_gp* g, int on) {
+    if (!g) return fail(BOHIP_E_ARG, "null handle");
+    g->timing = on != 0;
+    return 0;
+}
+int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {
+    if (!g) return 0;
+    const int n = (int)std::min<size_t>(g->tnames.size(), cap > 0 ? cap : 0);
+    for (int i = 0; i < n; ++i) {
+        if (names) names[i] = g->tnames[i].c_str();
+        if (ms) ms[i] = g->tms[i];
+    }
+    return (int)g->tnames.size();
+}
+
+}  // extern "C"

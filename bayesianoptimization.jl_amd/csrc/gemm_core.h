@@ -1,0 +1,132 @@
+// gemm_core.h -- the FP64 contraction engine every dense kernel of libbohip shares.
+//
+// Why v_mfma_f64_4x4x4_4b_f64 and not v_mfma_f64_16x16x4_f64: measured on MI355X
+// (tools/ubench_fp64b.hip, profiles/r01_ubench_fp64.txt) the 16x16x4 form sustains 36 TF/s
+// (1 wave/SIMD) to 48 TF/s (>=2 waves/SIMD) while the 4x4x4 four-block form sustains
+// 68-73 TF/s, i.e. ~93 % of the 78.6 TF/s FP64 peak.  Lane layout (probed on hardware,
+// tools/probe_mfma444.hip):  A[b][i][k] in lane 16k+4b+i,  B[b][k][j] in lane 16k+4b+j,
+// D[b][i][j] in lane 16i+4b+j, with 4 independent blocks b.  We arrange the four blocks as a
+// 2 x 2 grid (bi = b>>1, bj = b&1) so ONE instruction computes an 8 x 8 x 4 product:
+//     rows 4*bi + i, cols 4*bj + j, A replicated over bj, B replicated over bi
+// which balances the operand footprint (32 + 32 distinct doubles per instruction).
+//
+// Workgroup tile 128 x 128, 256 threads = 4 waves in 2 x 2, wave tile 64 x 64 = 8 x 8 groups
+// -> 64 accumulator doubles per lane.  Both operand tiles are staged K-major in LDS as
+// [128 rows][KC=16 (+2 pad)]; lane-group k' = lane>>4 supplies contraction index 4s + k' of k-step s.
+#pragma once
+#include "common.h"
+
+namespace bohip {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double mfma444(double a, double b, double c) {
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
+// ---- global -> register staging (issued early, consumed after the MFMA block) ----------------
+// K-major operand: tile = 128 rows x 16 doubles at src (row stride ld).  8 lanes cover one
+// 128-B row segment, a wave covers 8 full cache lines per instruction.
+__device__ __forceinline__ void stage_load_kmajor(const double* __restrict__ src, int64_t ld, int tid, d2 (&r)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 32 + (tid >> 3), seg = tid & 7;
+        r[q] = *reinterpret_cast<const d2*>(src + (int64_t)row * ld + seg * 2);
+    }
+}
+__device__ __forceinline__ void stage_store_kmajor(double* dst, int tid, const d2 (&r)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = q * 32 + (tid >> 3), seg = tid & 7;
+        *reinterpret_cast<d2*>(dst + row * LDSROW + seg * 2) = r[q];
+    }
+}
+// N-major operand (B[k][n], n contiguous): tile = 16 k-rows x 128 n; transposed while storing.
+__device__ __forceinline__ void stage_load_nmajor(const double* __restrict__ src, int64_t ld, int tid, d2 (&r)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = q * 4 + (tid >> 6), n = (tid & 63) * 2;
+        r[q] = *reinterpret_cast<const d2*>(src + (int64_t)k * ld + n);
+    }
+}
+__device__ __forceinline__ void stage_store_nmajor(double* dst, int tid, const d2 (&r)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = q * 4 + (tid >> 6), n = (tid & 63) * 2;
+        dst[n * LDSROW + k] = r[q].x;
+        dst[(n + 1) * LDSROW + k] = r[q].y;
+    }
+}
+
+// ---- one K-chunk (16) of MFMA work for this wave: 256 x v_mfma_f64_4x4x4 ---------------------
+// Four k-steps of 4; lane-group k' = lane>>4 reads column 4s + k' with ds_read_b64 (conflict-free:
+// bank pair = (36*row + 2*col) mod 64 is distinct over the 8 rows x 2 columns of a 32-lane half).
+// One double per fragment keeps the live set at 128 (acc) + 16 + 16 VGPRs, so the kernel fits the
+// 256-VGPR budget of 2 waves/SIMD without spilling.
+__device__ __forceinline__ void mma_chunk(const double* As, const double* Bs, int lane, int wr, int wc,
+                                          double (&acc)[8][8]) {
+    const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
+    const double* ap = As + (wr * 64 + 4 * (b >> 1) + t) * LDSROW + k;
+    const double* bp = Bs + (wc * 64 + 4 * (b & 1) + t) * LDSROW + k;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            av[i] = ap[i * 8 * LDSROW + 4 * s];
+            bv[i] = bp[i * 8 * LDSROW + 4 * s];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = mfma444(av[i], bv[j], acc[i][j]);
+    }
+}
+
+// ---- K loop: acc += A[128 x K] * op(B) over chunks [kc_begin, kc_end) -------------------------
+// A points at (row0, 0) of a K-major matrix.  B points at (n0, 0) when K-major, (0, n0) when N-major.
+// Register-staged double buffering: loads of chunk c+1 are in flight during the MFMAs of chunk c;
+// one barrier per chunk.
+template <bool B_NMAJOR>
+__device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ A, int64_t lda,
+                                               const double* __restrict__ B, int64_t ldb, int kc_begin,
+                                               int kc_end, double* smem, double (&acc)[8][8]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    double* As = smem;
+    double* Bs = smem + 2 * TILE_LDS_DOUBLES;
+    d2 ra[4], rb[4];
+    if (kc_begin >= kc_end) return;
+    stage_load_kmajor(A + (int64_t)kc_begin * KC, lda, tid, ra);
+    if (B_NMAJOR) stage_load_nmajor(B + (int64_t)kc_begin * KC * ldb, ldb, tid, rb);
+    else stage_load_kmajor(B + (int64_t)kc_begin * KC, ldb, tid, rb);
+    stage_store_kmajor(As, tid, ra);
+    if (B_NMAJOR) stage_store_nmajor(Bs, tid, rb);
+    else stage_store_kmajor(Bs, tid, rb);
+    __syncthreads();
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int cur = (kc - kc_begin) & 1;
+        const bool more = kc + 1 < kc_end;
+        if (more) {
+            stage_load_kmajor(A + (int64_t)(kc + 1) * KC, lda, tid, ra);
+            if (B_NMAJOR) stage_load_nmajor(B + (int64_t)(kc + 1) * KC * ldb, ldb, tid, rb);
+            else stage_load_kmajor(B + (int64_t)(kc + 1) * KC, ldb, tid, rb);
+        }
+        mma_chunk(As + cur * TILE_LDS_DOUBLES, Bs + cur * TILE_LDS_DOUBLES, lane, wr, wc, acc);
+        if (more) {
+            stage_store_kmajor(As + (cur ^ 1) * TILE_LDS_DOUBLES, tid, ra);
+            if (B_NMAJOR) stage_store_nmajor(Bs + (cur ^ 1) * TILE_LDS_DOUBLES, tid, rb);
+            else stage_store_kmajor(Bs + (cur ^ 1) * TILE_LDS_DOUBLES, tid, rb);
+        }
+        __syncthreads();
+    }
+}
+
+// Where this lane's accumulator acc[mi][nj] lives inside the 128 x 128 workgroup tile.
+__device__ __forceinline__ int acc_row(int lane, int wr, int mi) {
+    return wr * 64 + 8 * mi + 4 * (((lane >> 2) & 3) >> 1) + (lane >> 4);
+}
+__device__ __forceinline__ int acc_col(int lane, int wc, int nj) {
+    return wc * 64 + 8 * nj + 4 * (((lane >> 2) & 3) & 1) + (lane & 3);
+}
+
+}  // namespace bohip

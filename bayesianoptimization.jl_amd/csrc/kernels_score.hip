@@ -1,0 +1,237 @@
+// kernels_score.hip -- the acquisition hot path (rows A4-A7, A9 of SURVEY.md section 8):
+//   k_kstar        cross-covariance K*' chunk [Rc][Npad] (candidate-major, contraction index contiguous)
+//   k_trigemm_sq   V = W K* on FP64 MFMA with the sum-of-squares epilogue fused: V is never stored.
+//                  Row N of W carries alpha', so the same contraction also yields mu - beta.
+//   k_score        sigma^2 = max(s_f^2 - sum v^2, 0), the reference's acquisition formulas verbatim,
+//                  per-block arg-max;  k_argmax_final reduces to ONE 16-byte record.
+//   k_thompson     S x R independent posterior draws with a counter-based normal generator.
+// Reference call sites replaced: mean_var / predict_f (src/models/gp.jl:2-8), the functors of
+// src/acquisitionfunctions.jl:24-27,47-50,96,111,141 with src/utils.jl:48-49, and the arg-max of
+// acquire_max (src/acquisition.jl:54-68).
+#include "gemm_core.h"
+
+namespace bohip {
+
+__device__ __forceinline__ double cov_from_r_fast(int kern, double sigma2, double r) {
+    if (kern == KERN_MAT52ARD) {
+        const double R = sqrt(r), s = sqrt(5.0) * R;
+        return sigma2 * (1.0 + s + 5.0 / 3.0 * r) * exp(-s);
+    }
+    return sigma2 * exp(-0.5 * r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K*': thread = observation j (its coordinates live in registers), loop over the block's
+// candidates whose coordinates are wave-uniform (scalar loads).  Stores are coalesced along j.
+// KsT[r][j] = k(x_j, x*_r) for j < N, 0 for N <= j < Npad.  Xs is [R][d] (d contiguous).
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ X, int64_t N, int64_t Npad,
+                                               const double* __restrict__ Xs, int64_t r_begin, int64_t r_end,
+                                               KernelHyper hp, double* __restrict__ KsT, int64_t ldk, int rb) {
+    const int d = hp.d;
+    const int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Npad) return;
+    double xj[DT];
+#pragma unroll
+    for (int k = 0; k < DT; ++k) xj[k] = (k < d && j < N) ? X[j * d + k] : 0.0;
+    const int64_t r0 = r_begin + (int64_t)blockIdx.y * rb;
+    const int64_t r1 = min(r0 + rb, r_end);
+    for (int64_t r = r0; r < r1; ++r) {
+        const double* xs = Xs + r * d;
+        double rr = 0.0;
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+            if (k < d) {
+                const double t = xj[k] - xs[k];
+                rr += hp.il2[k] * (t * t);
+            }
+        const double v = (j < N) ? cov_from_r_fast(hp.kern, hp.sigma2, rr) : 0.0;
+        KsT[(r - r_begin) * ldk + j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// V = W K*, fused epilogue.  Tile (rt, ct): rows [128 rt, 128 rt + 128) of W against candidates
+// [128 ct, ...) of the chunk; W is lower-triangular so the contraction stops at k = 128 (rt + 1).
+// Work per tile grows with rt, so tiles are issued heaviest-first; blocks are dealt to XCDs
+// (block b runs on XCD b % 8) so that each XCD owns a fixed subset of candidate tiles and walks the
+// row tiles together: the W row-tile stream is then shared through that XCD's L2.
+// Output: q_part[rt][r] = sum over the tile's rows of v^2 (fixed summation order -> deterministic),
+//         mu_raw[r] = alpha' k*_r taken from the row of W that stores alpha (alpha_row).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
+                                                                const double* __restrict__ KsT, int64_t ldk,
+                                                                int T, int CT, int64_t alpha_row,
+                                                                double* __restrict__ q_part, int64_t ldq,
+                                                                double* __restrict__ mu_raw, int64_t r_off,
+                                                                double* __restrict__ VT, int64_t ldv) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int n_local = (CT + 7) >> 3;
+    const int rt = T - 1 - slot / n_local;
+    const int ct = xcd + 8 * (slot % n_local);
+    if (ct >= CT || rt < 0) return;
+    double acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+    gemm_tile_loop<false>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * TILE * ldk, ldk, 0,
+                          (rt + 1) * (TILE / KC), smem, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    double* red = smem;  // [2][128]; safe: gemm_tile_loop ends with a barrier
+    const int64_t row_base = (int64_t)rt * TILE;
+#pragma unroll
+    for (int nj = 0; nj < 8; ++nj) {
+        double s = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int64_t grow = row_base + acc_row(lane, wr, mi);
+            const double v = acc[mi][nj];
+            if (grow == alpha_row) {
+                mu_raw[r_off + (int64_t)ct * TILE + acc_col(lane, wc, nj)] = v;
+            } else {
+                s += v * v;
+            }
+            if (VT != nullptr && grow < alpha_row)
+                VT[((int64_t)ct * TILE + acc_col(lane, wc, nj)) * ldv + grow] = v;
+        }
+        s += __shfl_xor(s, 8);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        if (lane < 8) red[wr * TILE + wc * 64 + 8 * nj + lane] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < TILE)
+        q_part[(int64_t)rt * ldq + r_off + (int64_t)ct * TILE + threadIdx.x] = red[threadIdx.x] + red[TILE + threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Acquisition functors -- verbatim operation order of the reference, contraction OFF (Julia never
+// fuses a*b+c).  normal_pdf / normal_cdf: src/utils.jl:48-49.
+// ------------------------------------------------------------------------------------------------
+struct AcqParams {
+    int acq;
+    double p0, p1;
+};
+
+__device__ __forceinline__ double acq_eval(const AcqParams& a, double mu, double s2) {
+#pragma clang fp contract(off)
+    switch (a.acq) {
+        case ACQ_EI: {  // src/acquisitionfunctions.jl:47-50  (D*Phi + sqrt(s2)*pdf  ==  D*Phi(z) + phi(z))
+            const double tau = a.p0;
+            if (s2 == 0.0) return mu > tau ? mu - tau : 0.0;
+            const double D = mu - tau;
+            const double cdf = 1.0 / 2.0 * (1.0 + erf(D / sqrt(2.0 * s2)));
+            const double pdf = 1.0 / sqrt(2.0 * M_PI * s2) * exp(-(D * D) / (2.0 * s2));
+            return D * cdf + sqrt(s2) * pdf;
+        }
+        case ACQ_PI: {  // :24-27
+            const double tau = a.p0;
+            if (s2 == 0.0) return mu > tau ? 1.0 : 0.0;
+            return 1.0 / 2.0 * (1.0 + erf((mu - tau) / sqrt(2.0 * s2)));
+        }
+        case ACQ_UCB:  // :96
+            return mu + a.p0 * sqrt(s2);
+        case ACQ_MI:  // :141
+            return mu + a.p0 * (sqrt(s2 + a.p1) - sqrt(a.p1));
+        default:  // MaxMean :111
+            return mu;
+    }
+}
+
+// (value desc, index asc); NaN never wins (reference: `f > maxf` is false for NaN).
+__device__ __forceinline__ bool better(double v, long long i, double bv, long long bi) {
+    if (i < 0) return false;
+    if (bi < 0) return v > -INFINITY;
+    return v > bv || (v == bv && i < bi);
+}
+__device__ __forceinline__ void block_argmax(double& v, long long& i, Best* sh) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const long long oi = __shfl_xor(i, o);
+        if (better(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[wave].val = v; sh[wave].idx = i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (better(sh[w].val, sh[w].idx, v, i)) { v = sh[w].val; i = sh[w].idx; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_score(const double* __restrict__ q_part, int64_t ldq, int T,
+                                               const double* __restrict__ mu_raw, int64_t R, double sigma2,
+                                               double beta, AcqParams ap, double* __restrict__ mu_out,
+                                               double* __restrict__ var_out, double* __restrict__ score_out,
+                                               Best* __restrict__ block_best) {
+#pragma clang fp contract(off)
+    __shared__ Best sh[4];
+    const int64_t r = blockIdx.x * 256 + threadIdx.x;
+    double v = -INFINITY;
+    long long idx = -1;
+    if (r < R) {
+        double q = 0.0;
+        for (int t = 0; t < T; ++t) q += q_part[(int64_t)t * ldq + r];
+        double s2 = sigma2 - q;
+        if (s2 < 0.0) s2 = 0.0;  // predict_f: max(sigma2, 0)
+        const double mu = beta + mu_raw[r];
+        if (mu_out) mu_out[r] = mu;
+        if (var_out) var_out[r] = s2;
+        const double f = acq_eval(ap, mu, s2);
+        if (score_out) score_out[r] = f;
+        if (f > -INFINITY) { v = f; idx = r; }  // false for NaN and -Inf
+    }
+    if (block_best) {
+        block_argmax(v, idx, sh);
+        if (threadIdx.x == 0) { block_best[blockIdx.x].val = idx >= 0 ? v : -INFINITY; block_best[blockIdx.x].idx = idx; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_argmax_final(const Best* __restrict__ in, int n, Best* __restrict__ out) {
+    __shared__ Best sh[4];
+    double v = -INFINITY;
+    long long idx = -1;
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (better(in[i].val, in[i].idx, v, idx)) { v = in[i].val; idx = in[i].idx; }
+    block_argmax(v, idx, sh);
+    if (threadIdx.x == 0) { out->val = idx >= 0 ? v : -INFINITY; out->idx = idx; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A9: counter-based standard normals.  z(seed, s, j) = Box-Muller of two splitmix64-derived
+// uniforms keyed on (seed, s, j); identical on host and device, independent of sharding.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline double thompson_normal(uint64_t seed, int64_t s, int64_t j) {
+    const uint64_t h = splitmix64(seed ^ splitmix64((uint64_t)s * 0xD1B54A32D192ED03ull + (uint64_t)j));
+    const uint64_t h2 = splitmix64(h);
+    const double u1 = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740993.0);  // (0,1)
+    const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);         // [0,1)
+    return sqrt(-2.0 * log(u1)) * cos(2.0 * M_PI * u2);
+}
+
+// one workgroup per draw s; threads stride the candidates; never materialises S x R.
+__global__ __launch_bounds__(256) void k_thompson(const double* __restrict__ mu, const double* __restrict__ var,
+                                                  int64_t R, uint64_t seed, int64_t j0, Best* __restrict__ out) {
+#pragma clang fp contract(off)
+    __shared__ Best sh[4];
+    const int64_t s = blockIdx.x;
+    double v = -INFINITY;
+    long long idx = -1;
+    for (int64_t r = threadIdx.x; r < R; r += 256) {
+        const double f = mu[r] + sqrt(var[r]) * thompson_normal(seed, s, j0 + r);
+        if (better(f, r, v, idx)) { v = f; idx = r; }
+    }
+    block_argmax(v, idx, sh);
+    if (threadIdx.x == 0) { out[s].val = idx >= 0 ? v : -INFINITY; out[s].idx = idx; }
+}
+
+}  // namespace bohip

@@ -1,0 +1,264 @@
+"""Model adapter: the six generic functions through which the reference's BO loop touches the GP
+(reference src/models/gp.jl:2-18), backed by the device-resident factor in libbohip.
+
+Arrays keep the reference's Julia shapes: a batch of points is ``d x R`` (one point per COLUMN).
+``np.asfortranarray`` of such an array has exactly the memory layout the C ABI wants
+(every point = d contiguous doubles).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import Best, check
+
+_dp = C.POINTER(C.c_double)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _cols(x, d):
+    """d x R (or length-d vector) -> Fortran-contiguous float64 d x R."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1)
+    if x.shape[0] != d:
+        raise ValueError(f"expected {d} rows (one point per column), got shape {x.shape}")
+    return np.asfortranarray(x)
+
+
+# ---- GaussianProcesses.jl constructor vocabulary used by the reference --------------------------
+class MeanZero:
+    beta = 0.0
+
+
+class MeanConst:
+    def __init__(self, beta):
+        self.beta = float(beta)
+
+
+class _Kernel:
+    kern = "SEArd"
+
+    def __init__(self, ll, lsigma):
+        self.ll = np.atleast_1d(np.asarray(ll, dtype=np.float64)).copy()
+        self.lsigma = float(lsigma)
+
+
+class SEArd(_Kernel):
+    """SEArd(ll::Vector, lσ): k = exp(2lσ) exp(-½ Σ (x-y)²/exp(2 ll_k))  (README.md:24)."""
+    kern = "SEArd"
+
+
+class SEIso(_Kernel):
+    """SEIso(ll, lσ)  (test/acquisition.jl:2)."""
+    kern = "SEIso"
+
+
+class Mat52Ard(_Kernel):
+    """Mat52Ard(ll::Vector, lσ)  (default model, src/BayesianOptimization.jl:259-262)."""
+    kern = "Mat52Ard"
+
+
+class ElasticGPE:
+    """Drop-in for ``ElasticGPE(d; mean, kernel, logNoise, capacity)`` (README.md:22-27).
+
+    Owns a ``bohip_gp`` handle: x, y, the Cholesky factor, its inverse and alpha live in HBM and
+    survive across ``boptimize_`` calls; ``append_`` extends the factor (reference ``append!``).
+    ``model.x`` (d x n) and ``model.y`` are host mirrors, as the reference reads those fields
+    directly (src/BayesianOptimization.jl:117-119, src/acquisitionfunctions.jl:136).
+    """
+
+    def __init__(self, d, mean=None, kernel=None, logNoise=-2.0, capacity=1024, device=0):
+        self.dim = int(d)
+        self.mean = mean if mean is not None else MeanZero()
+        self.kernel = kernel if kernel is not None else SEArd(np.zeros(d), 0.0)
+        self.logNoise = float(logNoise)
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.bohip_gp_create(self.dim, int(capacity), _lib.KERN[self.kernel.kern], int(device), C.byref(h)))
+        self._h = h
+        self._x = np.zeros((self.dim, 0), order="F")
+        self._y = np.zeros(0)
+        self._push_hyper()
+
+    @classmethod
+    def from_data(cls, x, y, mean=None, kernel=None, logNoise=-2.0, **kw):
+        """GPE(x, y, mean, kernel[, logNoise]) (test/acquisitionfunctions.jl:4, test/acquisition.jl:2)."""
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(1, -1)
+        m = cls(x.shape[0], mean=mean, kernel=kernel, logNoise=logNoise, capacity=max(x.shape[1], 1), **kw)
+        m.append_(x, y)
+        return m
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.bohip_gp_destroy(h)
+            except Exception:
+                pass
+
+    # -- hyper-parameters (GP.set_params!) ---------------------------------------------------------
+    def _push_hyper(self):
+        ll = self.kernel.ll
+        if self.kernel.kern != "SEIso" and ll.size != self.dim:
+            raise ValueError("kernel length-scale vector must have d entries")
+        ll = np.ascontiguousarray(np.broadcast_to(ll, (self.dim,)) if ll.size == 1 else ll)
+        check(self._lib.bohip_gp_set_hyper(self._h, _ptr(ll), self.kernel.lsigma, self.logNoise, self.mean.beta))
+
+    def set_params_(self, ll=None, lsigma=None, logNoise=None, beta=None):
+        if ll is not None:
+            self.kernel.ll = np.atleast_1d(np.asarray(ll, dtype=np.float64)).copy()
+        if lsigma is not None:
+            self.kernel.lsigma = float(lsigma)
+        if logNoise is not None:
+            self.logNoise = float(logNoise)
+        if beta is not None:
+            self.mean = MeanConst(beta)
+        self._push_hyper()
+
+    # -- fields the reference reads directly -------------------------------------------------------
+    @property
+    def x(self):
+        return self._x
+
+    @property
+    def y(self):
+        return self._y
+
+    @property
+    def nobs(self):
+        return self._y.size
+
+    # -- append! / fit! ----------------------------------------------------------------------------
+    def append_(self, x, y):
+        x = _cols(x, self.dim)
+        y = np.ascontiguousarray(np.atleast_1d(np.asarray(y, dtype=np.float64)))
+        if x.shape[1] != y.size:
+            raise ValueError("x and y disagree on the number of observations")
+        check(self._lib.bohip_gp_append(self._h, _ptr(x), _ptr(y), y.size))
+        self._x = np.asfortranarray(np.concatenate([self._x, x], axis=1))
+        self._y = np.concatenate([self._y, y])
+        return self
+
+    def fit_(self):
+        check(self._lib.bohip_gp_refit(self._h))
+        return self
+
+    def mll(self):
+        out = C.c_double()
+        check(self._lib.bohip_gp_mll(self._h, C.byref(out)))
+        return out.value
+
+    # -- predict_f / scoring ------------------------------------------------------------------------
+    def predict_f(self, xs):
+        xs = _cols(xs, self.dim)
+        R = xs.shape[1]
+        mu = np.empty(R)
+        var = np.empty(R)
+        check(self._lib.bohip_gp_predict(self._h, _ptr(xs), R, _ptr(mu), _ptr(var)))
+        return mu, var
+
+    def score(self, acq, params, xs, want_scores=True):
+        """Fused predict + acquisition + arg-max.  Returns (scores or None, best_val, best_idx)."""
+        xs = _cols(xs, self.dim)
+        R = xs.shape[1]
+        p = np.ascontiguousarray(np.atleast_1d(np.asarray(params, dtype=np.float64)))
+        if p.size < 2:
+            p = np.concatenate([p, np.zeros(2 - p.size)])
+        sc = np.empty(R) if want_scores else None
+        best = Best()
+        check(self._lib.bohip_gp_score(self._h, _lib.ACQ[acq], _ptr(p), _ptr(xs), R,
+                                       _ptr(sc) if want_scores else None, C.byref(best)))
+        return sc, best.val, best.idx
+
+    def score_grad(self, acq, params, xs):
+        xs = _cols(xs, self.dim)
+        R = xs.shape[1]
+        p = np.ascontiguousarray(np.atleast_1d(np.asarray(params, dtype=np.float64)))
+        if p.size < 2:
+            p = np.concatenate([p, np.zeros(2 - p.size)])
+        sc = np.empty(R)
+        grad = np.empty((self.dim, R), order="F")
+        check(self._lib.bohip_gp_score_grad(self._h, _lib.ACQ[acq], _ptr(p), _ptr(xs), R, _ptr(sc), _ptr(grad)))
+        return sc, grad
+
+    def thompson(self, xs, S, seed=0, j0=0):
+        xs = _cols(xs, self.dim)
+        out = (Best * S)()
+        check(self._lib.bohip_gp_thompson(self._h, _ptr(xs), xs.shape[1], S, seed, j0, out))
+        return np.array([b.val for b in out]), np.array([b.idx for b in out], dtype=np.int64)
+
+    # -- introspection ------------------------------------------------------------------------------
+    def factor(self):
+        n = self.nobs
+        L = np.zeros((n, n))
+        check(self._lib.bohip_gp_get_factor(self._h, _ptr(L)))
+        return L
+
+    def alpha(self):
+        a = np.zeros(self.nobs)
+        check(self._lib.bohip_gp_get_alpha(self._h, _ptr(a)))
+        return a
+
+    def info(self, what):
+        v = C.c_int64()
+        check(self._lib.bohip_gp_info(self._h, what, C.byref(v)))
+        return v.value
+
+    def enable_timing(self, on=True):
+        check(self._lib.bohip_gp_enable_timing(self._h, int(on)))
+
+    def timing(self):
+        names = (C.c_char_p * 64)()
+        ms = (C.c_double * 64)()
+        n = self._lib.bohip_gp_get_timing(self._h, names, ms, 64)
+        return [(names[i].decode(), ms[i]) for i in range(min(n, 64))]
+
+    def __repr__(self):
+        return (f"ElasticGPE(dim={self.dim}, nobs={self.nobs}, kernel={self.kernel.kern}"
+                f"(ll={self.kernel.ll.tolist()}, lσ={self.kernel.lsigma}), mean β={self.mean.beta}, "
+                f"logNoise={self.logNoise}) [device-resident, libbohip]")
+
+
+# ---- the generic functions of reference src/models/gp.jl ----------------------------------------
+def mean_var(model, x):
+    """gp.jl:2-5 (vector -> scalars) and :8 (d x R matrix -> vectors)."""
+    x = np.asarray(x, dtype=np.float64)
+    mu, var = model.predict_f(x)
+    if x.ndim == 1:
+        return float(mu[0]), float(var[0])
+    return mu, var
+
+
+def myrand(model, x, rng=None):
+    """gp.jl:6-7.  Vector: one draw from N(mu, sigma^2).  Matrix: independent draws per column
+    (the reference draws jointly for matrices; only its length is pinned, test/acquisitionfunctions.jl:8)."""
+    rng = rng if rng is not None else np.random.default_rng()
+    x = np.asarray(x, dtype=np.float64)
+    mu, var = model.predict_f(x)
+    z = rng.standard_normal(mu.shape)
+    out = mu + np.sqrt(var) * z
+    return float(out[0]) if x.ndim == 1 else out
+
+
+def dims(model):
+    """gp.jl:9 -> (D, nobs)."""
+    return model.dim, model.nobs
+
+
+def maxy(model):
+    """gp.jl:10."""
+    return -math.inf if model.nobs == 0 else float(np.max(model.y))
+
+
+def update_(model, x, y):
+    """gp.jl:11  update!(model::GPE{<:ElasticArray}, x, y) = append!(model, x, y)."""
+    return model.append_(x, y)

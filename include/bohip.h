@@ -1,0 +1,148 @@
+/*
+ * bohip.h -- C ABI of libbohip.so: the MI355X (gfx950) implementation of the GP-posterior +
+ * acquisition-scoring hot path of jbrea/BayesianOptimization.jl.
+ *
+ * The reference has no FFI of its own; its seam is Julia dispatch on the model type
+ * (reference src/models/gp.jl:2-18).  Each entry point below names the reference generic
+ * function / call site it replaces.  A Julia model type `BOHipGPE` (julia/BOHip.jl) forwards
+ * those generic functions here with `ccall`; bayesianoptimization.jl_amd/ does the same with ctypes.
+ *
+ * Conventions
+ *   - Float64 / Int64 only.  Matrices are Julia-shaped: d x n COLUMN-major, i.e. every
+ *     observation / candidate is d contiguous doubles.
+ *   - The library owns all device memory and a host mirror of x, y (Julia reads model.x/.y).
+ *     Caller owns every pointer it passes; none is retained after the call returns.
+ *   - Every call is blocking (internal stream synchronised before return) unless it is a
+ *     *_dev entry point, which enqueues on the handle's stream and returns.
+ *   - Return value: 0 = OK, negative = error (see BOHIP_E_*); bohip_last_error() gives text.
+ *     Nothing throws or aborts across the ABI.  A handle is not re-entrant; distinct
+ *     handles are independent.  One handle = one device.
+ */
+#ifndef BOHIP_H
+#define BOHIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bohip_gp bohip_gp;
+
+/* error codes */
+#define BOHIP_OK 0
+#define BOHIP_E_ARG (-1)      /* bad argument (null pointer, d mismatch, negative size)          */
+#define BOHIP_E_NOTPD (-2)    /* Cholesky met a non-positive pivot; bohip_gp_info(...,PIVOT)      */
+#define BOHIP_E_HIP (-3)      /* HIP runtime error (text in bohip_last_error)                    */
+#define BOHIP_E_NODEVICE (-4) /* no gfx950 device visible -- there is NO CPU fallback             */
+#define BOHIP_E_STATE (-5)    /* call not valid in this state (e.g. predict with 0 observations) */
+#define BOHIP_E_UNSUPPORTED (-6)
+
+/* kernel_id: GaussianProcesses.jl kernels the reference's tests/defaults construct
+ * (README.md:24, test/acquisition.jl:2, src/BayesianOptimization.jl:259-262) */
+#define BOHIP_KERN_SEARD 0
+#define BOHIP_KERN_SEISO 1
+#define BOHIP_KERN_MAT52ARD 2
+
+/* acq_id + acq_params: the functors of reference src/acquisitionfunctions.jl
+ *   EI  :47-50  params {tau}          PI :24-27 params {tau}
+ *   UCB :96     params {beta_t}       MI :141   params {sqrt_alpha, gamma_hat}
+ *   MAXMEAN :110-111 params {}  (nullable)                                             */
+#define BOHIP_ACQ_EI 0
+#define BOHIP_ACQ_PI 1
+#define BOHIP_ACQ_UCB 2
+#define BOHIP_ACQ_MI 3
+#define BOHIP_ACQ_MAXMEAN 4
+
+/* 16-byte arg-max record, the unit exchanged between GPUs (one per rank) */
+typedef struct bohip_best {
+    double val;  /* best score; -Inf if nothing beat -Inf (reference src/acquisition.jl:55) */
+    int64_t idx; /* 0-based column of the winner, -1 if none; ties -> smallest index (:62)  */
+} bohip_best;
+
+/* ---- lifetime ---------------------------------------------------------------------------
+ * Replaces ElasticGPE(d; mean, kernel, logNoise, capacity) (README.md:22-27).  `capacity` is
+ * the initial observation capacity; storage grows geometrically beyond it.  device = HIP
+ * ordinal.  Fails with BOHIP_E_NODEVICE when no GPU is visible.                           */
+int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohip_gp **out);
+void bohip_gp_destroy(bohip_gp *gp);
+
+/* ---- hyper-parameters (GP.set_params! at reference src/models/gp.jl:60) ------------------
+ * loglen: d log length-scales (SEIso: loglen[0] only), logsig: log signal std, lognoise:
+ * logNoise, mean_const: MeanConst beta (0 for MeanZero).  Marks the factor stale; the next
+ * append/refit/predict rebuilds K, its Cholesky factor and alpha from the stored x, y.     */
+int bohip_gp_set_hyper(bohip_gp *gp, const double *loglen, double logsig, double lognoise, double mean_const);
+
+/* ---- update!(model, x, y) (reference src/models/gp.jl:11; called at
+ * src/BayesianOptimization.jl:169,194-196).  X: d x p column-major, y: p.  Incremental:
+ * new covariance rows, Cholesky extension (ElasticPDMats append!), alpha.  p == 0 is a no-op
+ * that only brings a stale factor up to date.                                             */
+int bohip_gp_append(bohip_gp *gp, const double *X, const double *y, int64_t p);
+
+/* ---- GP.fit! / update_target! role (reference src/models/gp.jl:14-16,61): full rebuild of
+ * K (SEArd assembly), its Cholesky factor and alpha from the stored observations.          */
+int bohip_gp_refit(bohip_gp *gp);
+
+/* ---- dims(model) :9, maxy(model) :10, model.x / model.y field reads ---------------------- */
+int bohip_gp_dims(const bohip_gp *gp, int64_t *d, int64_t *n);
+int bohip_gp_maxy(const bohip_gp *gp, double *maxy); /* -Inf when n == 0 */
+int bohip_gp_get_xy(const bohip_gp *gp, double *X /* d x n, nullable */, double *y /* n, nullable */);
+/* log marginal likelihood of the current factor: -0.5 (y-b)'alpha - sum log L_ii - n/2 log 2pi
+ * (gp.mll, read by MAP fitting at reference src/models/gp.jl:61-63)                         */
+int bohip_gp_mll(bohip_gp *gp, double *mll);
+
+/* ---- mean_var(model, X::Matrix) (reference src/models/gp.jl:8 -> GP.predict_f):
+ * Xs d x R column-major; mu, var length R (latent f variance, clamped at 0).                */
+int bohip_gp_predict(bohip_gp *gp, const double *Xs, int64_t R, double *mu, double *var);
+
+/* ---- acquisitionfunction(a, model)(X) + the arg-max of acquire_max (reference
+ * src/acquisitionfunctions.jl:4-9, src/acquisition.jl:54-68) fused: score all R columns, return
+ * per-column scores (nullable) and the best (value, index) under strict '>' from -Inf.       */
+int bohip_gp_score(bohip_gp *gp, int acq_id, const double *acq_params, const double *Xs, int64_t R,
+                   double *score /* R, nullable */, bohip_best *best);
+
+/* ---- wrap_gradient role (reference src/acquisition.jl:11-17): score and d(score)/dx, the
+ * latter d x R column-major.  SEArd / SEIso kernels.                                        */
+int bohip_gp_score_grad(bohip_gp *gp, int acq_id, const double *acq_params, const double *Xs, int64_t R,
+                        double *score, double *grad);
+
+/* ---- ThompsonSamplingSimple (reference src/acquisitionfunctions.jl:107-108, myrand
+ * src/models/gp.jl:6-7) in its batched form: S independent draws mu_j + sigma_j z_sj over the R
+ * candidates, arg-max per draw.  z comes from a counter-based generator keyed (seed, s, j + j0)
+ * so any shard of the candidate set reproduces the same stream (j0 = global column offset). */
+int bohip_gp_thompson(bohip_gp *gp, const double *Xs, int64_t R, int64_t S, uint64_t seed, int64_t j0,
+                      bohip_best *best /* S records, idx local to this shard */);
+/* the generator itself, exposed so tests and other shards can reproduce z (host side) */
+double bohip_thompson_normal(uint64_t seed, int64_t s, int64_t j);
+
+/* ---- device-resident variants (inputs already in HBM; results stay in HBM) ----------------
+ * dXs: device pointer, d x R column-major.  d_score (nullable), d_best: device pointers.
+ * Enqueued on the handle's stream; no host synchronisation.                                */
+int bohip_gp_score_dev(bohip_gp *gp, int acq_id, const double *acq_params, const double *dXs, int64_t R,
+                       double *d_score, bohip_best *d_best);
+int bohip_gp_predict_dev(bohip_gp *gp, const double *dXs, int64_t R, double *d_mu, double *d_var);
+/* stream = hipStream_t (NULL -> the handle's own stream).  Lets a host framework order our
+ * kernels with its own work.                                                               */
+int bohip_gp_set_stream(bohip_gp *gp, void *stream);
+int bohip_gp_synchronize(bohip_gp *gp);
+
+/* ---- introspection for tests / benchmarks ------------------------------------------------ */
+/* copies the n x n lower Cholesky factor L (row-major; == Julia's column-major upper U) */
+int bohip_gp_get_factor(bohip_gp *gp, double *L);
+int bohip_gp_get_alpha(bohip_gp *gp, double *alpha);
+#define BOHIP_INFO_PIVOT 0        /* 1-based failing pivot of the last BOHIP_E_NOTPD, else 0     */
+#define BOHIP_INFO_CAPACITY 1     /* current observation capacity                                */
+#define BOHIP_INFO_REFITS 2       /* number of full refits so far                                */
+#define BOHIP_INFO_APPENDS 3      /* number of incremental factor extensions so far              */
+int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
+/* per-stage device times (ms, HIP events on the handle's stream) of the LAST call when timing
+ * is enabled: names/values for up to `cap` stages; returns the number of stages.            */
+int bohip_gp_enable_timing(bohip_gp *gp, int on);
+int bohip_gp_get_timing(bohip_gp *gp, const char **names, double *ms, int cap);
+
+const char *bohip_last_error(void); /* thread-local */
+const char *bohip_version(void);
+int bohip_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOHIP_H */
