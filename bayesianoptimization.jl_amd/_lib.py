@@ -4,7 +4,9 @@ device is missing."""
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbohip.so")
@@ -66,6 +68,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+    /opt/rocm's); whichever is dlopen'ed first wins for both, and torch cannot see the GPU when the
+    system copy got there first.  So when PyTorch is installed (it is the plumbing for device memory,
+    streams and RCCL in bench.py / dist.py) and not yet imported, load its copy first.
+    BOHIP_SYSTEM_HIP=1 skips this."""
+    if "torch" in sys.modules or os.environ.get("BOHIP_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """dlopen libbohip.so and bind every declared symbol.  Raises if the library was not built."""
     global _lib
@@ -73,6 +97,7 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise BohipError(E_NODEVICE, f"{LIB_PATH} not built (run __graft_entry__.build()); there is no CPU fallback")
+    _one_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -222,7 +222,7 @@ static int refit(bohip_gp* g) {
     for (int kb = 0; kb < T; ++kb) {
         double* Lkk = g->dL + (int64_t)kb * TILE * (ld + 1);
         double* Wkk = g->dW + (int64_t)kb * TILE * (ld + 1);
-        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(256), POTF2_LDS_BYTES, g->stream, Lkk, ld, Wkk, ld, g->dinfo,
+        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, Lkk, ld, Wkk, ld, g->dinfo,
                            kb * TILE);
         HIPCHK(hipGetLastError());
         const int rem = T - kb - 1;

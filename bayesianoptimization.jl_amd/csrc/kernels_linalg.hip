@@ -63,67 +63,263 @@ __global__ __launch_bounds__(256) void k_build_cov(const double* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------
-// A2 (diagonal block): in-LDS Cholesky of one 128 x 128 block followed by its triangular inverse.
-// Right-looking, ONE barrier per column: the scaled column j is written to the mirror position
-// (row j of the strict upper triangle, never read by the trailing update) and the diagonal to dl[],
-// so the unscaled column stays readable by every thread during the rank-1 update.
-// Then thread c solves L w = e_c by forward substitution; w overwrites column c of the (now free)
-// lower triangle.  Output: L block (in place, strict upper zeroed) and W block = L^-1.
+// A2 (diagonal block): in-LDS Cholesky of one 128 x 128 block followed by its triangular inverse,
+// one workgroup.  This kernel sits on the critical path of the blocked factorisation (it cannot
+// overlap the trailing update that feeds it), so it is organised to minimise barriers:
+//
+//  Cholesky, 8 panels of 16 columns (3 barriers per panel):
+//    A1  wave 0 factors the 16 x 16 diagonal block wave-synchronously (no workgroup barrier);
+//        finished columns go to the MIRROR position (strict upper triangle, a[c][r]) and the
+//        diagonal to dl[], so the lower triangle keeps serving as workspace.
+//    A2  one thread per row below solves x L16' = a_row (16 steps in registers) -> mirror.
+//    A3  rank-16 trailing update with 7 x 7 cyclic register tiles per thread.
+//  Inverse by recursive doubling over 16-blocks (4 barriers per level):
+//    B0  thread c inverts its column of a 16 x 16 diagonal block in registers.
+//    B1  for h = 16, 32, 64:  S = L21 W11,  W21 = -W22 S  with (h/16) x 4 register tiles.
+//  W (lower, incl. diagonal) is built in the lower triangle while L stays in the mirror.
+// LDS row stride 129 doubles: column walks (stride 129 doubles = 258 dwords = 2 mod 64 banks) are
+// conflict-free for 16 consecutive rows.
 // info: first failing pivot (1-based global index) if the block is not positive definite.
 // ------------------------------------------------------------------------------------------------
 constexpr int PF_LD = TILE + 1;
-constexpr int POTF2_LDS_BYTES = (TILE * PF_LD + TILE) * 8;
+constexpr int POTF2_LDS_BYTES = (TILE * PF_LD + 2 * TILE) * 8;
 
-__global__ __launch_bounds__(256) void k_potf2_inv(double* __restrict__ Lblk, int64_t ld, double* __restrict__ Wblk,
+constexpr int PF_THREADS = 256;  // measured: 512 threads is slower (254k vs 228k cycles per block)
+
+template <int H>
+__device__ __forceinline__ void inv_level(double* a, int tid) {
+    // pairs of H-blocks: [W11 0; W21 W22], W21 = -W22 (L21 W11).  4H threads per pair;
+    // thread tile ROWS x 4 with rows cyclic (stride 16) so column walks of W22 stay conflict-free.
+    constexpr int ROWS = H / 16;
+    const int pair = tid / (4 * H), t = tid % (4 * H);
+    const int c0 = 4 * (t % (H / 4)), ti = t / (H / 4);
+    const int q0 = 2 * H * pair, q1 = q0 + H;
+    double acc[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    // S[i][c] = sum_{k>=c} L21[i][k] W11[k][c];  L21[i][k] = mirror a[q0+k][q1+i]
+#pragma unroll 4
+    for (int k = c0; k < H; ++k) {
+        double wv[4], lv[ROWS];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const double tv = a[(q0 + k) * PF_LD + q0 + c0 + c];
+            wv[c] = (k >= c0 + c) ? tv : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) lv[r] = a[(q0 + k) * PF_LD + q1 + ti + 16 * r];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] += lv[r] * wv[c];
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[(q1 + ti + 16 * r) * PF_LD + q0 + c0 + c] = acc[r][c];  // S into the (free) W21 slot
+    __syncthreads();
+    // W21[i][c] = -sum_{k<=i} W22[i][k] S[k][c]
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+#pragma unroll 4
+    for (int k = 0; k <= ti + 16 * (ROWS - 1); ++k) {
+        double sv[4], wv[ROWS];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sv[c] = a[(q1 + k) * PF_LD + q0 + c0 + c];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const double tv = a[(q1 + ti + 16 * r) * PF_LD + q1 + k];
+            wv[r] = (k <= ti + 16 * r) ? tv : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] -= wv[r] * sv[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[(q1 + ti + 16 * r) * PF_LD + q0 + c0 + c] = acc[r][c];
+    __syncthreads();
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, l);
+    hi = __builtin_amdgcn_readlane(hi, l);
+    return __hiloint2double(hi, lo);
+}
+// 1/sqrt(x) to ~1 ulp: hardware v_rsq_f64 seed + two Newton steps (the libm sqrt + divide pair is a
+// ~150-cycle dependent chain, and this sits on the critical path of every column).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * (1.5 - h * y * y);
+    y = y * (1.5 - h * y * y);
+    return y;
+}
+
+// A3 for a trailing size of NB 16-blocks: cyclic NB x NB register tile per thread (lower half only).
+template <int NB>
+__device__ __forceinline__ void trailing_update(double* a, int P, int tid) {
+    const int base = P + 16, ty = tid >> 4, tx = tid & 15;
+    double acc[NB][NB];
+#pragma unroll
+    for (int ai = 0; ai < NB; ++ai)
+#pragma unroll
+        for (int ki = 0; ki < NB; ++ki) acc[ai][ki] = 0.0;
+#pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+        const double* col = a + (P + c) * PF_LD + base;
+        double li[NB], lk[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            li[q] = col[ty + 16 * q];
+            lk[q] = col[tx + 16 * q];
+        }
+#pragma unroll
+        for (int ai = 0; ai < NB; ++ai)
+#pragma unroll
+            for (int ki = 0; ki <= ai; ++ki) acc[ai][ki] += li[ai] * lk[ki];
+    }
+#pragma unroll
+    for (int ai = 0; ai < NB; ++ai)
+#pragma unroll
+        for (int ki = 0; ki <= ai; ++ki) {
+            const int i = base + ty + 16 * ai, k = base + tx + 16 * ki;
+            if (k <= i) a[i * PF_LD + k] -= acc[ai][ki];
+        }
+}
+
+#ifdef BOHIP_POTF2_CLOCKS
+#define PF_CLK(slot) do { if (threadIdx.x == 0) pf_clocks[slot] += clock64() - pf_t0; pf_t0 = clock64(); } while (0)
+__device__ long long pf_clocks[16];
+#else
+#define PF_CLK(slot) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ Lblk, int64_t ld, double* __restrict__ Wblk,
                                                    int64_t ldw, int* __restrict__ info, int row0) {
-#pragma clang fp contract(off)
     extern __shared__ double sm[];
+#ifdef BOHIP_POTF2_CLOCKS
+    long long pf_t0 = clock64();
+#endif
     double* a = sm;
     double* dl = sm + TILE * PF_LD;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < TILE * TILE; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        a[i * PF_LD + j] = (j <= i) ? Lblk[(int64_t)i * ld + j] : 0.0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* idl = sm + TILE * PF_LD + TILE;  // 1/L_ii (the hot loops multiply, never divide)
+    {   // 16 independent loads in flight per thread; each half-wave reads one full 128-B... row segment
+        const int j = tid & 127, ih = tid >> 7;  // 2 row phases
+#pragma unroll 1
+        for (int i0 = 0; i0 < TILE; i0 += 32) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = Lblk[(int64_t)(i0 + 2 * u + ih) * ld + j];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[(i0 + 2 * u + ih) * PF_LD + j] = (j <= i0 + 2 * u + ih) ? v[u] : 0.0;
+        }
     }
     __syncthreads();
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int j = 0; j < TILE; ++j) {
-        double ajj = a[j * PF_LD + j];
-        if (!(ajj > 0.0)) {
-            if (tid == 0) atomicCAS(info, 0, row0 + j + 1);
-            ajj = 1.0;
+    PF_CLK(0);
+    for (int jb = 0; jb < 8; ++jb) {
+        const int P = 16 * jb;
+        if (wave == 0) {  // A1: 16 x 16 diagonal block in registers, lane r (< 16) holds row r
+            const int r = lane & 15;
+            double row[16], dkeep[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) row[k] = a[(P + r) * PF_LD + P + k];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double ajj = readlane_f64(row[j], j);
+                if (!(ajj > 0.0)) {
+                    if (lane == 0) atomicCAS(info, 0, row0 + P + j + 1);
+                    ajj = 1.0;
+                }
+                const double inv = fast_rsqrt(ajj);
+                const double lj = row[j] * inv;  // lane j: the pivot L_jj = ajj * inv
+                dkeep[j] = ajj * inv;
+                row[j] = (r == j) ? inv : lj;    // keep 1/L_jj on the diagonal
+#pragma unroll
+                for (int k = j + 1; k < 16; ++k) row[k] -= lj * readlane_f64(lj, k);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    if (r > j) a[(P + j) * PF_LD + P + r] = row[j];  // mirror
+                    if (r == j) { idl[P + j] = row[j]; dl[P + j] = dkeep[j]; }
+                }
+            }
         }
-        const double dd = sqrt(ajj), inv = 1.0 / dd;
-        if (tid == 0) dl[j] = dd;
-        for (int i = j + 1 + ty; i < TILE; i += 16) {
-            const double lij = a[i * PF_LD + j] * inv;
-            for (int k = j + 1 + tx; k <= i; k += 16) a[i * PF_LD + k] -= lij * (a[k * PF_LD + j] * inv);
-        }
-        for (int i = j + 1 + tid; i < TILE; i += 256) a[j * PF_LD + i] = a[i * PF_LD + j] * inv;
         __syncthreads();
-    }
-    // write L (coalesced along j)
-    for (int e = tid; e < TILE * TILE; e += 256) {
-        const int i = e >> 7, j = e & 127;
-        const double v = (j < i) ? a[j * PF_LD + i] : (j == i ? dl[i] : 0.0);
-        Lblk[(int64_t)i * ld + j] = v;
-    }
-    __syncthreads();
-    // inverse: thread c owns column c of W, stored at a[i][c], i >= c.  L[i][k] (i>k) is a[k][i].
-    if (tid < TILE) {
-        const int c = tid;
-        a[c * PF_LD + c] = 1.0 / dl[c];
-        for (int i = c + 1; i < TILE; ++i) {
-            double s = 0.0;
-            for (int k = c; k < i; ++k) s += a[k * PF_LD + i] * a[k * PF_LD + c];
-            a[i * PF_LD + c] = -s / dl[i];
+        PF_CLK(1);
+        const int base = P + 16, m = TILE - base;
+        if (tid < m) {  // A2: rows below the diagonal block
+            const int i = base + tid;
+            double x[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                double sacc = a[i * PF_LD + P + c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) sacc -= x[k] * a[(P + k) * PF_LD + P + c];
+                x[c] = sacc * idl[P + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a[(P + c) * PF_LD + i] = x[c];
         }
+        __syncthreads();
+        PF_CLK(2);
+        switch (m >> 4) {  // A3: rank-16 trailing update, tile size known at compile time per panel
+            case 7: trailing_update<7>(a, P, tid); break;
+            case 6: trailing_update<6>(a, P, tid); break;
+            case 5: trailing_update<5>(a, P, tid); break;
+            case 4: trailing_update<4>(a, P, tid); break;
+            case 3: trailing_update<3>(a, P, tid); break;
+            case 2: trailing_update<2>(a, P, tid); break;
+            case 1: trailing_update<1>(a, P, tid); break;
+            default: break;
+        }
+        __syncthreads();
+        PF_CLK(3);
+    }
+    // L out (coalesced along j): strict lower from the mirror, diagonal from dl, zeros above
+    for (int e = tid; e < TILE * TILE; e += PF_THREADS) {
+        const int i = e >> 7, j = e & 127;
+        Lblk[(int64_t)i * ld + j] = (j < i) ? a[j * PF_LD + i] : (j == i ? dl[i] : 0.0);
+    }
+    PF_CLK(4);
+    // B0: 16 x 16 diagonal inverses, thread = column
+    if (tid < TILE) {
+        const int q = tid & ~15, cc = tid & 15;
+        double w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc += a[(q + k) * PF_LD + q + i] * w[k];  // w[k] = 0 for k < cc
+            w[i] = (i < cc) ? 0.0 : (i == cc ? idl[q + i] : -sacc * idl[q + i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i >= cc) a[(q + i) * PF_LD + q + cc] = w[i];
     }
     __syncthreads();
-    for (int e = tid; e < TILE * TILE; e += 256) {
+    PF_CLK(5);
+    inv_level<16>(a, tid);
+    PF_CLK(6);
+    inv_level<32>(a, tid);
+    PF_CLK(7);
+    inv_level<64>(a, tid);
+    PF_CLK(8);
+    for (int e = tid; e < TILE * TILE; e += PF_THREADS) {
         const int i = e >> 7, c = e & 127;
         Wblk[(int64_t)i * ldw + c] = (c <= i) ? a[i * PF_LD + c] : 0.0;
     }
+    PF_CLK(9);
 }
 
 // ------------------------------------------------------------------------------------------------

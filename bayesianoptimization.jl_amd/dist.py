@@ -1,0 +1,53 @@
+"""Multi-GPU sharding of the multi-restart candidate set.
+
+Candidates are independent, so rank g scores columns [g*R/G, (g+1)*R/G) with no data-path
+collective.  The ONE exchange step is the arg-max: RCCL has no MAXLOC, so every rank contributes its
+16-byte record (float64 value bits, int64 GLOBAL column index) to a single all_gather
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests) and every rank applies the same
+(value desc, index asc) reduction -> bit-identical winner everywhere, identical to the 1-GPU result
+(reference tie rule: strict '>' keeps the first maximum, src/acquisition.jl:62).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def shard_bounds(R, world, rank):
+    """Contiguous column range of `rank` (last ranks get the remainder-free floor split + spill)."""
+    base, rem = divmod(R, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def reduce_best(vals, idxs):
+    """(value desc, index asc); NaN / -Inf / idx<0 never win.  Returns (-inf, -1) if nothing qualifies."""
+    best_v, best_i = -math.inf, -1
+    for v, i in zip(vals, idxs):
+        i = int(i)
+        if i < 0 or not (v > -math.inf):
+            continue
+        if best_i < 0 or v > best_v or (v == best_v and i < best_i):
+            best_v, best_i = float(v), i
+    return best_v, best_i
+
+
+def allgather_best(rec, offset, world):
+    """rec: int64[2] tensor holding (value bits, local index) on this rank's device.
+    Returns the global (value, index) on every rank."""
+    import torch
+
+    if world == 1:
+        h = rec.cpu().numpy()
+        v = float(h[:1].view(np.float64)[0])
+        return (v, int(h[1])) if h[1] >= 0 else (-math.inf, -1)
+    import torch.distributed as dist
+
+    g = rec.clone()
+    g[1] = torch.where(g[1] >= 0, g[1] + offset, g[1])
+    out = torch.empty(world * 2, dtype=torch.int64, device=rec.device)
+    dist.all_gather_into_tensor(out, g)
+    h = out.cpu().numpy().reshape(world, 2)
+    vals = h[:, 0].copy().view(np.float64)
+    return reduce_best(vals, h[:, 1])

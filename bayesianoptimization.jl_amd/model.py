@@ -143,9 +143,11 @@ class ElasticGPE:
         y = np.ascontiguousarray(np.atleast_1d(np.asarray(y, dtype=np.float64)))
         if x.shape[1] != y.size:
             raise ValueError("x and y disagree on the number of observations")
-        check(self._lib.bohip_gp_append(self._h, _ptr(x), _ptr(y), y.size))
-        self._x = np.asfortranarray(np.concatenate([self._x, x], axis=1))
-        self._y = np.concatenate([self._y, y])
+        rc = self._lib.bohip_gp_append(self._h, _ptr(x), _ptr(y), y.size)
+        if rc in (_lib.OK, _lib.E_NOTPD):  # observations are stored even when the factorisation fails
+            self._x = np.asfortranarray(np.concatenate([self._x, x], axis=1))
+            self._y = np.concatenate([self._y, y])
+        check(rc)
         return self
 
     def fit_(self):

@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- acquisition-candidates/sec of the fused GP-posterior + ExpectedImprovement + arg-max
+hot path on MI355X (BASELINE.json configs[1]: N=3000 observations, d=8, SEArd, EI, R=4096 restarts
+per GPU; at --gpus G the candidate set is R*G sharded over G ranks = configs[2] at G=8).
+
+One "step" = one pass of the hot path over one batch of candidates already resident in HBM:
+k_kstar (cross-covariances) -> k_trigemm_sq (V = L^-1 K*, sum v^2, mu) -> k_score (sigma^2, EI,
+block arg-max) -> k_argmax_final, then (G > 1) ONE RCCL all_gather of the 16-byte (value, index)
+record per rank and an identical local reduce, then the 16-byte result is read back by the host.
+
+Launch:  python bench.py [--gpus N --steps K --warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_OBS, DIM, R_PER_GPU = 3000, 8, 4096
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = vector peak (256 CU x 4 SIMD x 2.4 GHz x 32 FLOP/clk); the
+#                          MICROARCH guide lists no FP64 row; tools/ubench_fp64b.hip measures 73 TF/s sustained.
+
+
+def synth(seed=0):
+    """BASELINE.md synthetic inputs: X~U[0,1]^{N x d}, y = sum sin(3x) + 0.1 N(0,1), ll=log .5, ls=0, logNoise=-2."""
+    rng = np.random.default_rng(seed)
+    X = rng.random((N_OBS, DIM))
+    y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N_OBS)
+    return X, y
+
+
+def lhs(R, seed):
+    """Latin-hypercube candidates on [0,1]^d (reference src/utils.jl:101-120 semantics)."""
+    rng = np.random.default_rng(seed)
+    out = np.empty((R, DIM))
+    for k in range(DIM):
+        col = (np.arange(R) + rng.random(R)) / R
+        rng.shuffle(col)
+        out[:, k] = col
+    return out
+
+
+def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
+    """The CPU port (oracle/gp_oracle.c) of the reference's path: one candidate at a time, k* column,
+    mu dot, forward substitution on L, clamp, EI, strict-'>' arg-max.  Single thread (the reference is
+    single-threaded) on a bounded sample; an all-cores figure is reported beside it."""
+    from oracle.oracle import COracle
+
+    orc = COracle()
+    ll = np.full(DIM, np.log(0.5))
+    L, alpha = orc.fit(X, y, ll, 0.0, -2.0, 0.0)
+    sample = Xs[:budget_candidates]
+    t0 = time.perf_counter()
+    orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], sample, nthreads=1)
+    t1 = time.perf_counter() - t0
+    ncores = min(orc.max_threads(), os.cpu_count() or 1)
+    big = Xs[: min(len(Xs), max(budget_candidates, 16 * ncores))]
+    t0 = time.perf_counter()
+    orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], big, nthreads=ncores)
+    tn = time.perf_counter() - t0
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": len(sample) / t1, "unit": "candidates/s", "cores": 1, "kind": "port",
+        "sample": f"first {len(sample)} of the {len(Xs)} candidates of this workload, oracle/gp_oracle.c "
+                  f"(restatement of the reference path; the Julia package cannot run here), {t1:.1f} s",
+        "allcores": {"value": len(big) / tn, "cores": ncores, "sample": f"{len(big)} candidates, {tn:.1f} s"},
+        "cpu_model": cpu_model, "host_cores": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libbohip has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import bohip
+    from bohip import _lib
+    from bohip.dist import allgather_best
+
+    lib = _lib.load()
+    X, y = synth(0)
+    tau = float(y.max())
+    R_total = R_PER_GPU * world
+    Xs_all = lhs(R_total, seed=1)
+    lo = rank * R_PER_GPU
+    Xs_local = Xs_all[lo:lo + R_PER_GPU]
+
+    ll = np.full(DIM, np.log(0.5))
+    model = bohip.ElasticGPE(DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0,
+                             capacity=N_OBS, device=local_rank)
+    model.enable_timing(True)
+    model.append_(X.T, y)  # every rank factors the same model redundantly (192 KB broadcast beats 36 MB of L)
+    fit_ms = dict(model.timing())
+    model.fit_()
+    fit_ms = dict(model.timing())
+
+    dev = torch.device("cuda", local_rank)
+    dXs = torch.from_numpy(np.ascontiguousarray(Xs_local)).to(dev)  # [R][d] = d x R column-major
+    d_best = torch.zeros(2, dtype=torch.int64, device=dev)          # 16-byte (f64 value bits, i64 index) record
+    stream = torch.cuda.current_stream()
+    _lib.check(lib.bohip_gp_set_stream(model._h, C.c_void_p(stream.cuda_stream)))
+    params = (C.c_double * 2)(tau, 0.0)
+
+    def step():
+        _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()),
+                                          R_PER_GPU, None, C.c_void_p(d_best.data_ptr())))
+        val, idx = allgather_best(d_best, lo, world)  # RCCL all_gather of 16 B/rank + identical local reduce
+        _lib.check(lib.bohip_gp_synchronize(model._h))
+        return val, idx
+
+    for _ in range(args.warmup):
+        step()
+    stage_sum = {}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        val, idx = step()
+        for name, ms in model.timing():
+            stage_sum[name] = stage_sum.get(name, 0.0) + ms
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = R_total * args.steps / elapsed
+        stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
+        tg_ms = stage_ms.get("trigemm_sq", float("nan"))
+        flops_per_launch = R_PER_GPU * (N_OBS * N_OBS + 2.0 * N_OBS)  # triangular contraction + mu row
+        achieved = flops_per_launch / (tg_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_trigemm_sq.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "acquisition-candidates/sec (N=3000,d=8)", "value": value, "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: N=3000 obs, d=8, SEArd, ExpectedImprovement, R=4096 "
+                                   "restarts per GPU (LHS candidates resident in HBM)",
+                       "N": N_OBS, "d": DIM, "R_per_gpu": R_PER_GPU, "R_total": R_total, "acquisition": "EI",
+                       "parallelism": f"candidates sharded x{world}, one 16-byte all_gather"},
+            "roofline": {"bound": "mfma", "kernel": "k_trigemm_sq", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                         "avg_launch_ms": tg_ms, "flops_per_launch": flops_per_launch},
+            "stage_ms": stage_ms,
+            "model_update_ms": fit_ms,
+            "cholesky": {"N": N_OBS, "gflops": (N_OBS ** 3 / 3.0) / (fit_ms.get("cholesky", float("nan")) * 1e-3) / 1e9},
+            "best": {"value": val, "index": idx},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X, y, Xs_all, tau)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path (through the C ABI in libbohip.so) against the CPU oracle.
+
+Tolerances (north_star: mu / sigma^2 / EI within 1e-6 relative, arg-max indices bit-exact):
+  mu, scores : |d| <= 1e-6 |ref| + floor, floor = eps-level multiple of the cancelling terms
+  sigma^2    : |d| <= 1e-6 |ref| + 64 N eps s_f^2   (see conftest.var_tol)
+  arg-max    : exact index equality with the oracle's strict-'>' first-maximum rule
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, synth, var_tol
+
+pytestmark = pytest.mark.gpu
+EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope="module")
+def bohip():
+    import bohip as b
+    from bohip import _lib
+
+    assert _lib.load().bohip_device_count() > 0, "GPU tests need an MI355X; libbohip has no CPU fallback"
+    return b
+
+
+def make_model(bohip, X, y, ll, lsig, lnoise, beta, kern="SEArd", capacity=None):
+    K = {"SEArd": bohip.SEArd, "SEIso": bohip.SEIso, "Mat52Ard": bohip.Mat52Ard}[kern]
+    m = bohip.ElasticGPE(X.shape[1], mean=bohip.MeanConst(beta), kernel=K(ll, lsig), logNoise=lnoise,
+                         capacity=capacity or max(len(y), 1))
+    m.append_(X.T, y)
+    return m
+
+
+def mu_floor(alpha, s2f):
+    return 64 * EPS * s2f * np.abs(alpha).sum()
+
+
+def check_scores(sc, ref, floor):
+    assert np.all(np.abs(sc - ref) <= 1e-6 * np.abs(ref) + floor), np.abs(sc - ref).max()
+
+
+# ---- committed golden vectors ---------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["n1_seiso_maxmean", "n2_seard", "readme_d2_rep5", "branin_shaped", "n256_d8_r512", "ties_n256"])
+def test_golden(bohip, name):
+    g = load_golden(name)
+    X, y, Xs = g["X"], g["y"], g["Xs"]
+    N = len(y)
+    s2f = math.exp(2 * float(g["logsig"]))
+    m = make_model(bohip, X, y, g["loglen"], float(g["logsig"]), float(g["lognoise"]), float(g["beta"]))
+    mu, var = m.predict_f(Xs.T)
+    fl = mu_floor(g["alpha"], s2f)
+    assert np.all(np.abs(mu - g["mu"]) <= 1e-6 * np.abs(g["mu"]) + fl)
+    assert np.all(np.abs(var - g["var"]) <= var_tol(g["var"], N, s2f))
+    np.testing.assert_allclose(np.diag(m.factor()), g["Ldiag"], rtol=1e-10)
+    np.testing.assert_allclose(m.factor()[-1], g["Lrow_last"], rtol=1e-8, atol=1e-10 * math.sqrt(s2f))
+    for acq in ("EI", "PI", "UCB", "MI", "MaxMean"):
+        if f"{acq}_score" not in g:
+            continue
+        sc, bv, bi = m.score(acq, g[f"{acq}_params"], Xs.T)
+        ref = g[f"{acq}_score"]
+        sfloor = fl + 64 * N * EPS * s2f * (1 + (abs(g[f"{acq}_params"][0]) if acq in ("UCB",) else 0)) + 1e-15
+        if acq == "UCB" or acq == "MI":  # sqrt(sigma^2) amplifies the sigma^2 floor near observations
+            sfloor = sfloor + np.sqrt(var_tol(g["var"], N, s2f, rel=0)) * max(1.0, abs(g[f"{acq}_params"][0]))
+        check_scores(sc, ref, sfloor)
+        assert bi == g[f"{acq}_best_idx"][0], (acq, bi, g[f"{acq}_best_idx"][0])
+        assert sc[bi] == bv
+
+
+def test_ties_smallest_index_wins_on_device(bohip):
+    g = load_golden("ties_n256")
+    m = make_model(bohip, g["X"], g["y"], g["loglen"], float(g["logsig"]), float(g["lognoise"]), float(g["beta"]))
+    sc, bv, bi = m.score("EI", g["EI_params"], g["Xs"].T)
+    # duplicated columns are scored by identical instruction sequences -> bit-identical values
+    np.testing.assert_array_equal(sc[:100], sc[101:201])
+    assert bi == g["EI_best_idx"][0] and bi == int(np.flatnonzero(sc == sc.max()).min())
+
+
+# ---- reference test/acquisitionfunctions.jl:8-11: batched == single, BIT-exact, on the device ------
+@pytest.mark.parametrize("acq,params", [("PI", [0.4]), ("EI", [0.4]), ("UCB", [2.0]), ("MI", [1.0, 0.0]), ("MaxMean", [])])
+def test_batch_equals_single_bitexact_on_device(bohip, acq, params):
+    rng = np.random.default_rng(1)
+    X = rng.random((4, 3)); y = rng.random(4)
+    m = make_model(bohip, X, y, [0.0], 0.0, -2.0, 0.0, kern="SEIso")
+    x = rng.random((3, 2))
+    batch, _, _ = m.score(acq, params, x)
+    single, _, _ = m.score(acq, params, x[:, :1])
+    assert len(batch) == 2 and batch[0] == single[0]
+    big = rng.random((3, 700)); big[:, 333] = x[:, 0]
+    assert m.score(acq, params, big)[0][333] == single[0]          # independent of position / batch size
+
+
+# ---- seeded synthetic cases against the oracle, every acquisition ------------------------------------
+@pytest.mark.parametrize("N,d,R,lsig,lnoise,beta", [
+    (1, 1, 5, 0.0, -2.0, 0.0), (7, 2, 3, 0.5, -1.0, 0.3), (127, 3, 129, 0.0, -2.0, 0.0), (128, 4, 128, 0.0, -2.0, -1.0),
+    (129, 5, 257, 0.3, -1.5, 0.0), (500, 2, 1000, 5.0, 0.0, 0.0), (1000, 8, 1500, 0.0, -2.0, 0.0), (700, 16, 300, 0.0, -2.0, 0.2)])
+def test_seeded_vs_oracle(bohip, orc, N, d, R, lsig, lnoise, beta):
+    X, y, Xs = synth(N, d, R, seed=N + d)
+    ll = np.linspace(-0.9, -0.3, d)
+    L, alpha = orc.fit(X, y, ll, lsig, lnoise, beta)
+    m = make_model(bohip, X, y, ll, lsig, lnoise, beta)
+    s2f = math.exp(2 * lsig)
+    np.testing.assert_allclose(m.factor(), L, rtol=1e-9, atol=1e-11 * math.sqrt(s2f))
+    np.testing.assert_allclose(m.alpha(), alpha, rtol=1e-6, atol=1e-9 * np.abs(alpha).max())
+    mu_o, var_o = orc.predict(X, ll, lsig, beta, L, alpha, Xs, nthreads=8)
+    mu, var = m.predict_f(Xs.T)
+    fl = mu_floor(alpha, s2f)
+    assert np.all(np.abs(mu - mu_o) <= 1e-6 * np.abs(mu_o) + fl)
+    assert np.all(np.abs(var - var_o) <= var_tol(var_o, N, s2f))
+    tau = float(y.max())
+    for acq, p in [("EI", [tau]), ("PI", [tau]), ("UCB", [orc.brochu_beta(d, N)]), ("MI", [1.0, 0.3]), ("MaxMean", [])]:
+        sc_o, bv_o, bi_o = orc.score(X, ll, lsig, beta, L, alpha, acq, p, Xs, nthreads=8)
+        sc, bv, bi = m.score(acq, p, Xs.T)
+        amp = max(1.0, abs(p[0])) if acq in ("UCB", "MI") else 1.0
+        floor = fl + amp * np.sqrt(var_tol(var_o, N, s2f, rel=0)) if acq in ("UCB", "MI") else fl + var_tol(var_o, N, s2f, rel=0) + 1e-15
+        check_scores(sc, sc_o, floor)
+        # arg-max: exact unless the oracle's own top two are closer than the documented floor
+        top2 = np.sort(sc_o)[-2:] if R > 1 else np.array([-np.inf, sc_o[0]])
+        if top2[1] - top2[0] > 4 * np.max(floor):
+            assert bi == bi_o, (acq, bi, bi_o)
+        assert sc[bi] == bv
+
+
+def test_mat52ard_and_seiso_kernels(bohip, orc):
+    X, y, Xs = synth(300, 6, 400, seed=21)
+    for kern, ll in (("Mat52Ard", np.linspace(-0.5, 0.2, 6)), ("SEIso", np.array([-0.4]))):
+        L, alpha = orc.fit(X, y, ll, 0.1, -2.0, 0.0, kern=kern)
+        m = make_model(bohip, X, y, ll, 0.1, -2.0, 0.0, kern=kern)
+        sc_o, _, bi_o = orc.score(X, ll, 0.1, 0.0, L, alpha, "EI", [y.max()], Xs, kern=kern, nthreads=8)
+        sc, _, bi = m.score("EI", [y.max()], Xs.T)
+        check_scores(sc, sc_o, mu_floor(alpha, math.exp(0.2)) + 1e-12)
+        assert bi == bi_o
+
+
+# ---- edge cases -------------------------------------------------------------------------------------
+def test_empty_and_ragged_inputs(bohip):
+    m = bohip.ElasticGPE(3)
+    assert bohip.dims(m) == (3, 0) and bohip.maxy(m) == -math.inf
+    with pytest.raises(bohip.BohipError):                    # predict with no observations is a state error, not a crash
+        m.predict_f(np.zeros((3, 2)))
+    m.append_(np.zeros((3, 0)), np.zeros(0))                 # p == 0 append is a no-op
+    X, y, Xs = synth(50, 3, 10, seed=2)
+    m.append_(X.T, y)
+    sc, bv, bi = m.score("EI", [0.0], np.zeros((3, 0)))      # R == 0 -> (-Inf, -1), like acquire_max's initial state
+    assert len(sc) == 0 and bv == -math.inf and bi == -1
+    with pytest.raises(ValueError):
+        m.predict_f(np.zeros((4, 2)))                        # wrong d
+    with pytest.raises(ValueError):
+        m.append_(np.zeros((3, 2)), np.zeros(3))             # x / y length mismatch
+
+
+def test_nan_and_inf_never_win(bohip):
+    X, y, Xs = synth(40, 2, 20, seed=4)
+    m = make_model(bohip, X, y, [-0.5, -0.5], 0.0, -2.0, 0.0)
+    Xs[7] = np.nan
+    sc, bv, bi = m.score("EI", [y.max()], Xs.T)
+    assert math.isnan(sc[7]) and bi != 7 and bi == int(np.nanargmax(sc))
+    sc, bv, bi = m.score("EI", [y.max()], np.full((2, 3), np.nan))
+    assert bi == -1 and bv == -math.inf                      # `f > maxf` is false for NaN (src/acquisition.jl:62)
+
+
+def test_not_positive_definite_is_reported_not_fatal(bohip):
+    X = np.zeros((40, 2)); y = np.arange(40.0)               # forty identical points, almost no noise
+    m = bohip.ElasticGPE(2, kernel=bohip.SEArd([0.0, 0.0], 10.0), logNoise=-30.0)
+    with pytest.raises(bohip.NotPositiveDefinite):
+        m.append_(X.T, y)
+    assert m.info(0) >= 2                                    # failing pivot index is retrievable
+    m.set_params_(logNoise=-2.0)                             # handle stays usable
+    m.fit_()
+    assert np.all(np.isfinite(m.predict_f(np.ones((2, 1)))[0]))
+
+
+def test_capacity_growth_and_incremental_append(bohip, orc):
+    X, y, Xs = synth(400, 4, 64, seed=8)
+    ll = np.full(4, -0.6)
+    m = bohip.ElasticGPE(4, kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0, capacity=100)
+    m.append_(X[:90].T, y[:90])
+    for lo, hi in [(90, 91), (91, 96), (96, 130), (130, 255), (255, 256), (256, 257), (257, 400)]:
+        m.append_(X[lo:hi].T, y[lo:hi])                      # crosses tile (128) and capacity (100, 200, 400) boundaries
+        assert bohip.dims(m) == (4, hi)
+    L, alpha = orc.fit(X, y, ll, 0.0, -2.0, 0.0)
+    np.testing.assert_allclose(m.factor(), L, rtol=1e-9, atol=1e-12)
+    sc_o, _, bi_o = orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [y.max()], Xs)
+    sc, _, bi = m.score("EI", [y.max()], Xs.T)
+    check_scores(sc, sc_o, mu_floor(alpha, 1.0) + 1e-13)
+    assert bi == bi_o
+    assert m.info(1) >= 400
+    np.testing.assert_array_equal(m.x, X.T)
+    np.testing.assert_array_equal(m.y, y)
+
+
+def test_hyperparameter_change_refits(bohip, orc):
+    X, y, Xs = synth(150, 3, 30, seed=6)
+    m = make_model(bohip, X, y, np.zeros(3), 0.0, -2.0, 0.0)
+    before = m.predict_f(Xs.T)[0]
+    m.set_params_(ll=np.array([-0.7, -0.2, 0.1]), lsigma=0.4, logNoise=-1.0, beta=0.5)
+    L, alpha = orc.fit(X, y, [-0.7, -0.2, 0.1], 0.4, -1.0, 0.5)
+    mu_o, var_o = orc.predict(X, [-0.7, -0.2, 0.1], 0.4, 0.5, L, alpha, Xs)
+    mu, var = m.predict_f(Xs.T)
+    assert not np.allclose(mu, before)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=mu_floor(alpha, math.exp(0.8)))
+    assert np.all(np.abs(var - var_o) <= var_tol(var_o, 150, math.exp(0.8)))
+    # mll against the textbook expression evaluated with the oracle factor
+    ref = -0.5 * (y - 0.5) @ alpha - np.log(np.diag(L)).sum() - 0.5 * len(y) * math.log(2 * math.pi)
+    assert m.mll() == pytest.approx(ref, rel=1e-9)
+
+
+def test_thompson_draws_match_oracle(bohip, orc):
+    from bohip import _lib
+
+    lib = _lib.load()
+    X, y, Xs = synth(200, 4, 500, seed=10)
+    ll = np.full(4, -0.5)
+    m = make_model(bohip, X, y, ll, 0.0, -2.0, 0.0)
+    mu, var = m.predict_f(Xs.T)
+    S, seed, j0 = 16, 42, 1000
+    z = np.array([[lib.bohip_thompson_normal(seed, s, j0 + j) for j in range(500)] for s in range(S)])
+    bv_o, bi_o = orc.thompson(mu, var, z)
+    bv, bi = m.thompson(Xs.T, S, seed=seed, j0=j0)
+    np.testing.assert_array_equal(bi, bi_o)                  # host/device z agree to an ulp; winners are well separated
+    np.testing.assert_allclose(bv, bv_o, rtol=1e-12)
+    # sharding invariance: the same global columns split in two give the same winners
+    bv1, bi1 = m.thompson(Xs[:250].T, S, seed=seed, j0=j0)
+    bv2, bi2 = m.thompson(Xs[250:].T, S, seed=seed, j0=j0 + 250)
+    glob = np.where(bv1 >= bv2, bi1, bi2 + 250)
+    np.testing.assert_array_equal(glob, bi)
+
+
+# ---- BASELINE.json full sizes: size-independent properties + a bounded oracle sample ------------------
+def test_full_size_c2_properties(bohip, orc):
+    N, d, R = 3000, 8, 4096
+    X, y, Xs = synth(N, d, R, seed=0)
+    ll = np.full(d, math.log(0.5))
+    m = make_model(bohip, X, y, ll, 0.0, -2.0, 0.0)
+    tau = float(y.max())
+    sc, bv, bi = m.score("EI", [tau], Xs.T)
+    mu, var = m.predict_f(Xs.T)
+    assert np.all(np.isfinite(sc)) and np.all(var >= 0) and np.all(var <= 1.0 + 1e-12)     # 0 <= sigma^2 <= s_f^2
+    assert bi == int(np.argmax(sc)) and bv == sc[bi]
+    # determinism: same call twice -> bit-identical; permuted candidates -> permuted scores, same winner
+    sc2, bv2, bi2 = m.score("EI", [tau], Xs.T)
+    np.testing.assert_array_equal(sc, sc2)
+    perm = np.random.default_rng(1).permutation(R)
+    scp, bvp, bip = m.score("EI", [tau], Xs[perm].T)
+    np.testing.assert_array_equal(scp, sc[perm])
+    assert perm[bip] == bi and bvp == bv
+    # sharding invariance: 8 shards of 512 (the 8-GPU partition) reduce to the same winner
+    from bohip.dist import reduce_best, shard_bounds
+    recs = []
+    for g in range(8):
+        lo, hi = shard_bounds(R, 8, g)
+        s_g, v_g, i_g = m.score("EI", [tau], Xs[lo:hi].T)
+        np.testing.assert_array_equal(s_g, sc[lo:hi])
+        recs.append((v_g, i_g + lo))
+    assert reduce_best(*zip(*recs)) == (bv, bi)
+    # at an observation the posterior mean interpolates within the noise level and sigma^2 collapses
+    mu_x, var_x = m.predict_f(X[:64].T)
+    assert np.all(var_x < 0.05)
+    # factor identity L L' = cK on a row sample (checks Cholesky without an O(N^3) CPU run)
+    Lg = m.factor()
+    cK = orc.build_cK(X, ll, 0.0, -2.0)
+    rows = np.random.default_rng(2).choice(N, 24, replace=False)
+    np.testing.assert_allclose(Lg[rows] @ Lg.T, cK[rows], rtol=0, atol=1e-11)
+    # bounded oracle sample at full N (the winner plus 47 others)
+    L, alpha = orc.fit(X, y, ll, 0.0, -2.0, 0.0)
+    sel = np.unique(np.concatenate([[bi], np.random.default_rng(3).choice(R, 47, replace=False)]))
+    sc_o, _, _ = orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], Xs[sel], nthreads=8)
+    check_scores(sc[sel], sc_o, mu_floor(alpha, 1.0) + 1e-13)
+    mu_o, var_o = orc.predict(X, ll, 0.0, 0.0, L, alpha, Xs[sel], nthreads=8)
+    assert np.all(np.abs(var[sel] - var_o) <= var_tol(var_o, N, 1.0))
+    assert np.all(np.abs(mu[sel] - mu_o) <= 1e-6 * np.abs(mu_o) + mu_floor(alpha, 1.0))
+
+
+def test_device_resident_entry_point_matches_host_entry_point(bohip):
+    torch = pytest.importorskip("torch")
+    from bohip import _lib
+    from bohip.dist import allgather_best
+
+    lib = _lib.load()
+    X, y, Xs = synth(300, 8, 1000, seed=12)
+    m = make_model(bohip, X, y, np.full(8, -0.6), 0.0, -2.0, 0.0)
+    sc, bv, bi = m.score("EI", [y.max()], Xs.T)
+    dXs = torch.from_numpy(Xs).cuda()
+    dsc = torch.empty(1000, dtype=torch.float64, device="cuda")
+    rec = torch.zeros(2, dtype=torch.int64, device="cuda")
+    _lib.check(lib.bohip_gp_set_stream(m._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    p = (C.c_double * 2)(float(y.max()), 0.0)
+    _lib.check(lib.bohip_gp_score_dev(m._h, _lib.ACQ["EI"], p, C.c_void_p(dXs.data_ptr()), 1000,
+                                      C.c_void_p(dsc.data_ptr()), C.c_void_p(rec.data_ptr())))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dsc.cpu().numpy(), sc)
+    assert allgather_best(rec, 0, 1) == (bv, bi)
+    _lib.check(lib.bohip_gp_set_stream(m._h, None))

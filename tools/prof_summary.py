@@ -1,0 +1,46 @@
+"""Condenses a tools/prof.sh output directory into the text summary committed under profiles/."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+out = sys.argv[1]
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+print("== rocprofv3 --kernel-trace --stats: python bench.py --no-cpu-baseline ==")
+for f in find("kt/**/*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    print(f"{'kernel':60s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}")
+    for r in rows[:14]:
+        name = r.get("Name", "")[:60]
+        print(f"{name:60s} {r.get('Calls',''):>6s} {float(r.get('AverageNs',0))/1e3:10.1f} {float(r.get('TotalDurationNs',0))/1e6:10.3f} {r.get('Percentage',''):>6s}")
+kt = find("kt/**/*kernel_trace.csv")
+if kt:
+    d = defaultdict(list)
+    for r in csv.DictReader(open(kt[0])):
+        d[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Grid_Size"), r.get("Workgroup_Size")))
+    print("\n== per-kernel launch geometry (kernel trace) ==")
+    for k, v in d.items():
+        if "bohip" in k:
+            print(f"{k[:70]:70s} n={len(v)} vgpr={v[0][1]} sgpr={v[0][2]} lds={v[0][3]} grid={v[-1][4]} wg={v[-1][5]}")
+print("\n== PMC passes (separate runs; per-dispatch averages for bohip kernels) ==")
+traffic = {}
+for f in find("pmc_*/**/*counter_collection.csv"):
+    acc = defaultdict(lambda: defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in acc.items():
+        if "trigemm" in k or "kstar" in k or "k_score" in k:
+            for c, vals in cs.items():
+                avg = sum(vals) / len(vals)
+                print(f"{k[:48]:48s} {c:32s} n={len(vals):4d} avg={avg:.6g}")
+                if "trigemm" in k and c in ("FETCH_SIZE", "WRITE_SIZE"):
+                    traffic[c] = avg
+if traffic:
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly half of a
+    # wide coalesced streaming read -> double it.  WRITE_SIZE uncalibrated (taken as reported).
+    fetch = traffic.get("FETCH_SIZE", 0.0) * 1024 * 2
+    write = traffic.get("WRITE_SIZE", 0.0) * 1024
+    rec = {"kernel": "k_trigemm_sq", "fetch_kib_raw": traffic.get("FETCH_SIZE"), "write_kib_raw": traffic.get("WRITE_SIZE"),
+           "hbm_bytes_per_launch": fetch + write, "correction": "FETCH_SIZE x2 (gfx950, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported"}
+    print("\ntraffic:", json.dumps(rec))
+    json.dump(rec, open(os.path.join(out, "traffic_trigemm_sq.json"), "w"))
