@@ -45,6 +45,8 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 static_assert(sizeof(bohip_best) == sizeof(Best), "record layout");
+static constexpr int APP_KSPLIT = 8;
+static constexpr int APP_ROWS = APPEND_PMAX + (APPEND_PMAX / APPEND_CHUNK) * APP_KSPLIT * APPEND_CHUNK;
 
 struct StageTimer {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
@@ -56,6 +58,7 @@ struct bohip_gp {
     int64_t n = 0, cap = 0, ld = 0;
     double *dX = nullptr, *dy = nullptr, *dL = nullptr, *dW = nullptr, *dS = nullptr;
     double *dalpha = nullptr, *dr = nullptr, *dt = nullptr, *dmll = nullptr;
+    double* dApp = nullptr;  // [APP_ROWS][ld] scratch of the incremental append
     int* dinfo = nullptr;
     std::vector<double> hX, hy;
     double loglen[DMAX], logsig = 0.0, lognoise = -2.0, beta = 0.0;
@@ -65,6 +68,8 @@ struct bohip_gp {
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
+    double *dVT = nullptr, *dUT = nullptr;  // gradient path: V' and U' = V' W chunks, candidate-major
+    int64_t vt_rows = 0;
     double *dq = nullptr, *dmu_raw = nullptr, *dXs = nullptr, *dmu = nullptr, *dvar = nullptr, *dscore = nullptr;
     int64_t q_cap = 0, r_cap = 0, xs_cap = 0;
     Best *dblock_best = nullptr, *dbest = nullptr;
@@ -123,12 +128,16 @@ static void t_collect(bohip_gp* g) {
 
 // ---- allocation -----------------------------------------------------------------------------------
 static int free_model(bohip_gp* g) {
-    for (double** p : {&g->dX, &g->dy, &g->dL, &g->dW, &g->dS, &g->dalpha, &g->dr, &g->dt})
+    for (double** p : {&g->dX, &g->dy, &g->dL, &g->dW, &g->dS, &g->dalpha, &g->dr, &g->dt, &g->dApp})
         if (*p) { hipFree(*p); *p = nullptr; }
     return 0;
 }
 static int alloc_model(bohip_gp* g, int64_t cap) {
     free_model(g);
+    // chunk buffers are sized by ld: drop them, they are re-made on demand
+    for (double** p : {&g->dKsT, &g->dVT, &g->dUT, &g->dq})
+        if (*p) { hipFree(*p); *p = nullptr; }
+    g->kst_rows = g->vt_rows = g->q_cap = 0;
     g->cap = cap;
     g->ld = round_up(cap + 1, TILE);
     const size_t mat = (size_t)g->ld * g->ld * sizeof(double);
@@ -140,6 +149,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
     HIPCHK(hipMalloc(&g->dalpha, g->ld * 8));
     HIPCHK(hipMalloc(&g->dr, g->ld * 8));
     HIPCHK(hipMalloc(&g->dt, g->ld * 8));
+    HIPCHK(hipMalloc(&g->dApp, (size_t)APP_ROWS * g->ld * 8));
     HIPCHK(hipMemsetAsync(g->dL, 0, mat, g->stream));
     HIPCHK(hipMemsetAsync(g->dW, 0, mat, g->stream));
     HIPCHK(hipMemsetAsync(g->dS, 0, mat, g->stream));
@@ -277,6 +287,53 @@ static int refit(bohip_gp* g) {
     return 0;
 }
 
+// ---- A2': incremental extension by p new observations (already in dX/dy and the host mirror) ----------
+static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
+    CHK(one_time_kernel_setup());
+    const int64_t N1 = N0 + p, Npad1 = round_up(N1 + 1, TILE), ld = g->ld;
+    const KernelHyper hp = make_hyper(g);
+    const double noise = std::exp(2.0 * g->lognoise) + std::numeric_limits<double>::epsilon();
+    HIPCHK(hipMemsetAsync(g->dinfo, 0, sizeof(int), g->stream));
+    t_begin(g, "append_cov_rows");
+    hipLaunchKernelGGL(k_cov_rows, dim3((Npad1 + 255) / 256, Npad1 - N0), dim3(256), 0, g->stream, g->dX, N0, N1, Npad1,
+                       hp, noise, g->dL, g->dW, ld);
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    const int nch = (int)((p + APPEND_CHUNK - 1) / APPEND_CHUNK);
+    t_begin(g, "append_L21");
+    for (int ch = 0; ch < nch; ++ch) {
+        const int P = (int)std::min<int64_t>(APPEND_CHUNK, p - ch * APPEND_CHUNK);
+        hipLaunchKernelGGL(k_rows_trimv, dim3((N0 + 3) / 4), dim3(256), 0, g->stream, g->dW, ld, N0,
+                           g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, g->dApp + (int64_t)ch * APPEND_CHUNK * ld, ld);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy2DAsync(g->dL + N0 * ld, ld * 8, g->dApp, ld * 8, N0 * 8, p, hipMemcpyDeviceToDevice, g->stream));
+    t_end(g);
+    t_begin(g, "append_schur_chol");
+    hipLaunchKernelGGL(k_schur_chol, dim3(1), dim3(256), 0, g->stream, g->dL, g->dW, ld, N0, (int)p, g->dinfo);
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    t_begin(g, "append_W21");
+    double* part = g->dApp + (int64_t)APPEND_PMAX * ld;
+    for (int ch = 0; ch < nch; ++ch) {
+        const int P = (int)std::min<int64_t>(APPEND_CHUNK, p - ch * APPEND_CHUNK);
+        hipLaunchKernelGGL(k_rows_times_W, dim3((N0 + 255) / 256, APP_KSPLIT), dim3(256), 0, g->stream, g->dW, ld, N0,
+                           g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, APP_KSPLIT,
+                           part + (int64_t)ch * APP_KSPLIT * APPEND_CHUNK * ld, ld);
+    }
+    hipLaunchKernelGGL(k_apply_w22, dim3((N0 + 255) / 256), dim3(256), 0, g->stream, g->dW, ld, N0, (int)p, part, ld,
+                       APP_KSPLIT, nch);
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    t_begin(g, "alpha");
+    CHK(compute_alpha(g));
+    t_end(g);
+    CHK(check_info(g));
+    g->n_factored = N1;
+    g->appends++;
+    return 0;
+}
+
 static int ensure_fresh(bohip_gp* g) {
     if (g->stale || g->n_factored != g->n) return refit(g);
     return 0;
@@ -321,6 +378,17 @@ static int ensure_score_scratch(bohip_gp* g, int64_t R) {
         HIPCHK(hipMalloc(&g->dblock_best, nb * sizeof(Best)));
         g->bb_cap = nb;
     }
+    return 0;
+}
+static int ensure_grad_scratch(bohip_gp* g) {
+    if (g->vt_rows >= g->kst_rows && g->dVT) return 0;
+    for (double** p : {&g->dVT, &g->dUT})
+        if (*p) { hipFree(*p); *p = nullptr; }
+    const size_t bytes = (size_t)g->kst_rows * g->ld * 8;
+    HIPCHK(hipMalloc(&g->dVT, bytes));
+    HIPCHK(hipMalloc(&g->dUT, bytes));
+    HIPCHK(hipMemsetAsync(g->dVT, 0, bytes, g->stream));  // padding columns (>= N) must stay zero
+    g->vt_rows = g->kst_rows;
     return 0;
 }
 static int ensure_xs(bohip_gp* g, int64_t R) {
@@ -394,6 +462,72 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     return 0;
 }
 
+template <int DT>
+static void launch_grad(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, const KernelHyper& hp, const AcqParams& ap,
+                        double* d_grad) {
+    hipLaunchKernelGGL(k_grad_finish<DT>, dim3((r1 - r0 + 3) / 4), dim3(256), 0, g->stream, g->dX, g->n, dXs, r0, r1, hp,
+                       g->dalpha, g->dUT, g->ld, g->dmu, g->dvar, 0.0, ap, d_grad);
+}
+
+// A8: scores + gradients for R candidates (device pointers).  Per chunk: K*' -> V' (trigemm, V stored)
+// -> U' = V' W (k_gemm) -> mu, sigma^2, score -> gradient.
+static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, const double* dXs, int64_t R, double* d_score,
+                           double* d_grad) {
+    if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
+    CHK(ensure_fresh(g));
+    CHK(ensure_score_scratch(g, R));
+    CHK(ensure_grad_scratch(g));
+    CHK(one_time_kernel_setup());
+    AcqParams ap{acq_id, 0.0, 0.0};
+    if (acq_params) {
+        if (acq_id != BOHIP_ACQ_MAXMEAN) ap.p0 = acq_params[0];
+        if (acq_id == BOHIP_ACQ_MI) ap.p1 = acq_params[1];
+    } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
+        return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
+    }
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE);
+    const int T = (int)(Npad / TILE);
+    const KernelHyper hp = make_hyper(g);
+    const int64_t rc = g->kst_rows;
+    for (int64_t r0 = 0; r0 < R; r0 += rc) {
+        const int64_t r1 = std::min(R, r0 + rc);
+        t_begin(g, "kstar");
+        if (g->d <= 2) launch_kstar<2>(g, dXs, r0, r1, Npad, hp);
+        else if (g->d <= 4) launch_kstar<4>(g, dXs, r0, r1, Npad, hp);
+        else if (g->d <= 8) launch_kstar<8>(g, dXs, r0, r1, Npad, hp);
+        else if (g->d <= 16) launch_kstar<16>(g, dXs, r0, r1, Npad, hp);
+        else if (g->d <= 32) launch_kstar<32>(g, dXs, r0, r1, Npad, hp);
+        else launch_kstar<64>(g, dXs, r0, r1, Npad, hp);
+        t_end(g);
+        const int CT = (int)((r1 - r0 + TILE - 1) / TILE);
+        const int n_local = (CT + 7) / 8;
+        t_begin(g, "trigemm_sq+V");
+        hipLaunchKernelGGL(k_trigemm_sq, dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, g->dVT, g->ld);
+        HIPCHK(hipGetLastError());
+        t_end(g);
+        t_begin(g, "gemm_U");
+        GemmParams p{};
+        p.A = g->dVT; p.lda = g->ld; p.B = g->dW; p.ldb = g->ld; p.C = g->dUT; p.ldc = g->ld;
+        p.mt = CT; p.nt = T; p.kc = T * (TILE / KC); p.alpha = 1.0; p.beta = 0.0; p.klo_from_n = 1;
+        CHK(launch_gemm(g, true, p, 1));
+        t_end(g);
+        t_begin(g, "score+grad");
+        const int nb = (int)((r1 - r0 + 255) / 256);
+        hipLaunchKernelGGL(k_score, dim3(nb), dim3(256), 0, g->stream, g->dq + r0, Rpad, T, g->dmu_raw + r0, r1 - r0,
+                           std::exp(2.0 * g->logsig), g->beta, ap, g->dmu + r0, g->dvar + r0, d_score + r0, (Best*)nullptr);
+        if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad);
+        else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad);
+        else if (g->d <= 8) launch_grad<8>(g, dXs, r0, r1, hp, ap, d_grad);
+        else if (g->d <= 16) launch_grad<16>(g, dXs, r0, r1, hp, ap, d_grad);
+        else if (g->d <= 32) launch_grad<32>(g, dXs, r0, r1, hp, ap, d_grad);
+        else launch_grad<64>(g, dXs, r0, r1, hp, ap, d_grad);
+        HIPCHK(hipGetLastError());
+        t_end(g);
+    }
+    return 0;
+}
+
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
@@ -442,7 +576,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     hipSetDevice(g->device);
     if (g->own_stream) hipStreamSynchronize(g->own_stream);
     free_model(g);
-    for (double** p : {&g->dKsT, &g->dq, &g->dmu_raw, &g->dXs, &g->dmu, &g->dvar, &g->dscore, &g->dmll})
+    for (double** p : {&g->dKsT, &g->dq, &g->dmu_raw, &g->dXs, &g->dmu, &g->dvar, &g->dscore, &g->dmll, &g->dVT, &g->dUT})
         if (*p) hipFree(*p);
     if (g->dblock_best) hipFree(g->dblock_best);
     if (g->dbest) hipFree(g->dbest);
@@ -469,10 +603,12 @@ int bohip_gp_append(bohip_gp* g, const double* X, const double* y, int64_t p) {
     if (!g || p < 0 || (p > 0 && (!X || !y))) return fail(BOHIP_E_ARG, "bad arguments");
     HIPCHK(hipSetDevice(g->device));
     t_reset(g);
+    int rc = 0;
+    bool done = false;
     if (p > 0) {
         g->hX.insert(g->hX.end(), X, X + p * g->d);
         g->hy.insert(g->hy.end(), y, y + p);
-        const int64_t n_new = g->n + p;
+        const int64_t n_old = g->n, n_new = g->n + p;
         if (n_new > g->cap) {
             g->n = n_new;
             CHK(alloc_model(g, std::max<int64_t>(2 * g->cap, n_new)));
@@ -481,9 +617,14 @@ int bohip_gp_append(bohip_gp* g, const double* X, const double* y, int64_t p) {
             HIPCHK(hipMemcpyAsync(g->dy + g->n, y, (size_t)p * 8, hipMemcpyHostToDevice, g->stream));
             HIPCHK(hipStreamSynchronize(g->stream));  // caller's buffers are only valid during the call
             g->n = n_new;
+            if (!g->stale && g->n_factored == n_old && n_old > 0 && p <= APPEND_PMAX) {
+                rc = append_incremental(g, n_old, p);
+                if (rc != 0) g->stale = true;
+                done = true;
+            }
         }
     }
-    int rc = ensure_fresh(g);
+    if (!done) rc = ensure_fresh(g);
     HIPCHK(hipStreamSynchronize(g->stream));
     t_collect(g);
     return rc;
@@ -593,8 +734,28 @@ int bohip_gp_score(bohip_gp* g, int acq_id, const double* acq_params, const doub
     return 0;
 }
 
-int bohip_gp_score_grad(bohip_gp*, int, const double*, const double*, int64_t, double*, double*) {
-    return fail(BOHIP_E_UNSUPPORTED, "score_grad: not built yet");
+int bohip_gp_score_grad(bohip_gp* g, int acq_id, const double* acq_params, const double* Xs, int64_t R, double* score,
+                        double* grad) {
+    if (!g || R < 0 || (R > 0 && (!Xs || !score || !grad))) return fail(BOHIP_E_ARG, "bad arguments");
+    if (acq_id < 0 || acq_id > BOHIP_ACQ_MAXMEAN) return fail(BOHIP_E_ARG, "unknown acq_id");
+    if (R == 0) return 0;
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    CHK(ensure_xs(g, R));
+    double* dgrad = nullptr;
+    HIPCHK(hipMalloc(&dgrad, (size_t)R * g->d * 8));
+    HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
+    int rc = ensure_score_scratch(g, R);
+    if (rc == 0) rc = score_grad_core(g, acq_id, acq_params, g->dXs, R, g->dscore, dgrad);
+    if (rc == 0) {
+        hipError_t e = hipMemcpyAsync(score, g->dscore, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(grad, dgrad, (size_t)R * g->d * 8, hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) rc = fail(BOHIP_E_HIP, hipGetErrorString(e));
+    }
+    hipFree(dgrad);
+    t_collect(g);
+    return rc;
 }
 
 double bohip_thompson_normal(uint64_t seed, int64_t s, int64_t j) { return thompson_normal(seed, s, j); }

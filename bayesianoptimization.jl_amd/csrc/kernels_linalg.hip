@@ -437,3 +437,167 @@ __global__ __launch_bounds__(256) void k_mll(const double* __restrict__ L, int64
 }
 
 }  // namespace bohip
+
+// ================================================================================================
+// A2': incremental extension of the factor by p <= APPEND_PMAX observations (role of ElasticPDMats
+// append!: U12 = U11' \ K12, U22 = chol(K22 - U12'U12), reference src/models/gp.jl:11).
+// With W = L^-1 resident the new rows are products, not solves:
+//     L21 = K21 W11'                      (k_rows_trimv  : one pass over W, HBM-bound)
+//     L22 = chol(K22 - L21 L21'), W22     (k_schur_chol  : one workgroup)
+//     W21 = -W22 (L21 W11)                (k_rows_times_W: one pass over W, then k_apply_w22)
+// ================================================================================================
+namespace bohip {
+
+constexpr int APPEND_PMAX = 32;   // larger batches take the full refit
+constexpr int APPEND_CHUNK = 8;   // right-hand sides per pass over W
+
+// New rows [N0, Npad1) of cK into L (cols 0..i) and identity padding rows into L and W.
+__global__ __launch_bounds__(256) void k_cov_rows(const double* __restrict__ X, int64_t N0, int64_t N1, int64_t Npad1,
+                                                  KernelHyper hp, double noise, double* __restrict__ L,
+                                                  double* __restrict__ W, int64_t ld) {
+#pragma clang fp contract(off)
+    const int64_t i = N0 + blockIdx.y;
+    const int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad1 || j >= Npad1) return;
+    const int d = hp.d;
+    if (i < N1) {
+        if (j > i) { if (j < N1) L[i * ld + j] = 0.0; return; }
+        double r = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double t = X[i * d + k] - X[j * d + k];
+            r += hp.il2[k] * (t * t);
+        }
+        double v = cov_from_r(hp.kern, hp.sigma2, r);
+        if (i == j) v += noise;
+        L[i * ld + j] = v;
+    } else {  // identity padding (also clears a stale alpha row)
+        const double v = (i == j) ? 1.0 : 0.0;
+        L[i * ld + j] = v;
+        W[i * ld + j] = v;
+    }
+}
+
+// out[r][j] = sum_{k<=j} W[j][k] * rows[r][k]   for j < N0, r < P (P <= APPEND_CHUNK).
+// One wave per j (coalesced along k), P running sums, fixed-order butterfly.
+__global__ __launch_bounds__(256) void k_rows_trimv(const double* __restrict__ W, int64_t ld, int64_t N0,
+                                                    const double* __restrict__ rows, int64_t ldr, int P,
+                                                    double* __restrict__ out, int64_t ldo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= N0) return;
+    double s[APPEND_CHUNK];
+#pragma unroll
+    for (int r = 0; r < APPEND_CHUNK; ++r) s[r] = 0.0;
+    for (int64_t k = lane; k <= j; k += 64) {
+        const double w = W[j * ld + k];
+#pragma unroll
+        for (int r = 0; r < APPEND_CHUNK; ++r)
+            if (r < P) s[r] += w * rows[r * ldr + k];
+    }
+#pragma unroll
+    for (int r = 0; r < APPEND_CHUNK; ++r) {
+        double v = s[r];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0 && r < P) out[r * ldo + j] = v;
+    }
+}
+
+// One workgroup: S = K22 - L21 L21' (p x p), L22 = chol(S), W22 = L22^-1.
+// K22 sits in L[N0+r][N0+s]; L21 in L[N0+r][0..N0).  Results overwrite L22 in place and go to W22.
+__global__ __launch_bounds__(256) void k_schur_chol(double* __restrict__ L, double* __restrict__ W, int64_t ld,
+                                                    int64_t N0, int p, int* __restrict__ info) {
+    __shared__ double S[APPEND_PMAX][APPEND_PMAX + 1];
+    __shared__ double Winv[APPEND_PMAX][APPEND_PMAX + 1];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = 0; e < p * (p + 1) / 2; ++e) {  // (r, s), s <= r; every thread strides the dot product
+        int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((r + 1) * (r + 2) / 2 <= e) ++r;
+        while (r * (r + 1) / 2 > e) --r;
+        const int sidx = e - r * (r + 1) / 2;
+        const double* a = L + (N0 + r) * ld;
+        const double* b = L + (N0 + sidx) * ld;
+        double acc = 0.0;
+        for (int64_t k = tid; k < N0; k += 256) acc += a[k] * b[k];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (tid == 0) S[r][sidx] = a[N0 + sidx] - ((red[0] + red[1]) + (red[2] + red[3]));
+        __syncthreads();
+    }
+    if (tid == 0) {  // p <= 32: sequential Cholesky + inverse is a few microseconds
+        for (int j = 0; j < p; ++j) {
+            double ajj = S[j][j];
+            for (int k = 0; k < j; ++k) ajj -= S[j][k] * S[j][k];
+            if (!(ajj > 0.0)) { atomicCAS(info, 0, (int)(N0 + j + 1)); ajj = 1.0; }
+            const double dd = sqrt(ajj);
+            S[j][j] = dd;
+            for (int i = j + 1; i < p; ++i) {
+                double v = S[i][j];
+                for (int k = 0; k < j; ++k) v -= S[i][k] * S[j][k];
+                S[i][j] = v / dd;
+            }
+        }
+        for (int c = 0; c < p; ++c) {
+            Winv[c][c] = 1.0 / S[c][c];
+            for (int i = c + 1; i < p; ++i) {
+                double v = 0.0;
+                for (int k = c; k < i; ++k) v += S[i][k] * Winv[k][c];
+                Winv[i][c] = -v / S[i][i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < p * p; e += 256) {
+        const int r = e / p, c = e % p;
+        L[(N0 + r) * ld + N0 + c] = (c <= r) ? S[r][c] : 0.0;
+        W[(N0 + r) * ld + N0 + c] = (c <= r) ? Winv[r][c] : 0.0;
+    }
+}
+
+// part[ks][r][c] = sum_{k in slice ks, k >= c} rows[r][k] * W[k][c]   for c < N0 (thread = column c).
+__global__ __launch_bounds__(256) void k_rows_times_W(const double* __restrict__ W, int64_t ld, int64_t N0,
+                                                      const double* __restrict__ rows, int64_t ldr, int P,
+                                                      int ksplit, double* __restrict__ part, int64_t ldp) {
+    const int64_t c = blockIdx.x * 256 + threadIdx.x;
+    const int ks = blockIdx.y;
+    if (c >= N0) return;
+    const int64_t span = (N0 + ksplit - 1) / ksplit;
+    int64_t k0 = ks * span, k1 = min(N0, k0 + span);
+    if (k0 < c) k0 = c;
+    double s[APPEND_CHUNK];
+#pragma unroll
+    for (int r = 0; r < APPEND_CHUNK; ++r) s[r] = 0.0;
+    for (int64_t k = k0; k < k1; ++k) {
+        const double w = W[k * ld + c];
+#pragma unroll
+        for (int r = 0; r < APPEND_CHUNK; ++r)
+            if (r < P) s[r] += rows[r * ldr + k] * w;
+    }
+#pragma unroll
+    for (int r = 0; r < APPEND_CHUNK; ++r)
+        if (r < P) part[((int64_t)ks * APPEND_CHUNK + r) * ldp + c] = s[r];
+}
+
+// W21[r][c] = -sum_s W22[r][s] * T[s][c],  T[s][c] = sum_ks part[ks][s][c]  (fixed order).
+__global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, int64_t ld, int64_t N0, int p,
+                                                   const double* __restrict__ part, int64_t ldp, int ksplit,
+                                                   int nchunks) {
+    const int64_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N0) return;
+    double T[APPEND_PMAX];
+    for (int s = 0; s < p; ++s) {
+        const int ch = s / APPEND_CHUNK, rr = s % APPEND_CHUNK;
+        double v = 0.0;
+        for (int ks = 0; ks < ksplit; ++ks) v += part[(((int64_t)ch * ksplit + ks) * APPEND_CHUNK + rr) * ldp + c];
+        T[s] = v;
+    }
+    (void)nchunks;
+    for (int r = 0; r < p; ++r) {
+        double v = 0.0;
+        for (int s = 0; s <= r; ++s) v += W[(N0 + r) * ld + N0 + s] * T[s];
+        W[(N0 + r) * ld + c] = -v;
+    }
+}
+
+}  // namespace bohip

@@ -201,6 +201,94 @@ __global__ __launch_bounds__(256) void k_argmax_final(const Best* __restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------------
+// A8: gradient of the acquisition w.r.t. the candidate (role of ForwardDiff in wrap_gradient,
+// reference src/acquisition.jl:11-17), analytic:
+//     d k*_j / d x_k = fac(r_j) il2_k (x_k - X_jk)      fac = -k (SE), -(5/3) s2 (1+s) e^-s (Mat52)
+//     grad mu  = sum_j alpha_j dk*_j          grad s2 = -2 sum_j u_j dk*_j,   u = K^-1 k* = W'(W k*)
+// U' = V' W is a second triangular contraction on the MFMA engine (k_gemm, B = W in N-major form);
+// this kernel finishes: one wave per candidate, lanes stride the observations, 2d butterfly sums,
+// then the chain rule through the REFERENCE's acquisition formulas (not the textbook EI).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void acq_partials(const AcqParams& a, double mu, double s2, double& dmu, double& ds2) {
+    const double inv_sqrt_2pi = 0.3989422804014327;
+    switch (a.acq) {
+        case ACQ_EI: {
+            if (s2 == 0.0) { dmu = mu > a.p0 ? 1.0 : 0.0; ds2 = 0.0; return; }
+            const double D = mu - a.p0, s = sqrt(s2), z = D / s;
+            const double Phi = 0.5 * (1.0 + erf(z / sqrt(2.0))), phi = inv_sqrt_2pi * exp(-0.5 * z * z);
+            dmu = Phi + D * phi / s - z * phi / s;
+            ds2 = (D * phi - z * phi) * (-z / (2.0 * s2));
+            return;
+        }
+        case ACQ_PI: {
+            if (s2 == 0.0) { dmu = 0.0; ds2 = 0.0; return; }
+            const double D = mu - a.p0, s = sqrt(s2), z = D / s, phi = inv_sqrt_2pi * exp(-0.5 * z * z);
+            dmu = phi / s;
+            ds2 = phi * (-z / (2.0 * s2));
+            return;
+        }
+        case ACQ_UCB: dmu = 1.0; ds2 = s2 > 0.0 ? a.p0 / (2.0 * sqrt(s2)) : 0.0; return;
+        case ACQ_MI: dmu = 1.0; ds2 = a.p0 / (2.0 * sqrt(s2 + a.p1)); return;
+        default: dmu = 1.0; ds2 = 0.0; return;
+    }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ X, int64_t N,
+                                                     const double* __restrict__ Xs, int64_t r_begin, int64_t r_end,
+                                                     KernelHyper hp, const double* __restrict__ alpha,
+                                                     const double* __restrict__ UT, int64_t ldu,
+                                                     const double* __restrict__ mu, const double* __restrict__ var,
+                                                     double sigma2_minus_q_raw_sign, AcqParams ap,
+                                                     double* __restrict__ grad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = r_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= r_end) return;
+    const int d = hp.d;
+    const double* xs = Xs + r * d;
+    double gm[DT], gv[DT];
+#pragma unroll
+    for (int k = 0; k < DT; ++k) { gm[k] = 0.0; gv[k] = 0.0; }
+    const double* u = UT + (r - r_begin) * ldu;
+    for (int64_t j = lane; j < N; j += 64) {
+        double t[DT], rr = 0.0;
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+            if (k < d) {
+                t[k] = xs[k] - X[j * d + k];
+                rr += hp.il2[k] * (t[k] * t[k]);
+            }
+        double fac;
+        if (hp.kern == KERN_MAT52ARD) {
+            const double s = sqrt(5.0) * sqrt(rr);
+            fac = -(5.0 / 3.0) * hp.sigma2 * (1.0 + s) * exp(-s);
+        } else {
+            fac = -(hp.sigma2 * exp(-0.5 * rr));
+        }
+        const double a = alpha[j], uj = u[j];
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+            if (k < d) {
+                const double dk = fac * t[k] * hp.il2[k];
+                gm[k] += dk * a;
+                gv[k] += dk * uj;
+            }
+    }
+    double dmu, ds2;
+    const double m = mu[r], v = var[r];
+    acq_partials(ap, m, v, dmu, ds2);
+    (void)sigma2_minus_q_raw_sign;
+#pragma unroll
+    for (int k = 0; k < DT; ++k)
+        if (k < d) {
+            double a = gm[k], b = gv[k];
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
+            if (lane == 0) grad[r * d + k] = dmu * a + (v > 0.0 ? ds2 * (-2.0 * b) : 0.0);
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // A9: counter-based standard normals.  z(seed, s, j) = Box-Muller of two splitmix64-derived
 // uniforms keyed on (seed, s, j); identical on host and device, independent of sharding.
 // ------------------------------------------------------------------------------------------------

@@ -266,13 +266,24 @@ void oracle_score(int kern, int64_t d, int64_t N, const double *X, const double 
 /* A8: value and analytic gradient of (mu, s2) w.r.t. x* for SEArd/SEIso (the role of
  * ForwardDiff in wrap_gradient, src/acquisition.jl:11-17):
  *   dk_i/dx_k = -k_i (x_k - X_ki) il2_k;  dmu = (dk)'alpha;  ds2 = -2 (dk)' L^-T v.       */
-void oracle_predict_grad(int64_t d, int64_t N, const double *X, const double *il2, double s2f, double beta,
+/* d k(r)/d x_k = fac(r) * il2_k * (x_k - X_ik):  SE: fac = -k;  Mat52: fac = -(5/3) s2 (1 + s) exp(-s), s = sqrt(5 r) */
+static double cov_grad_fac(int kern, double s2, double r) {
+    if (kern == KERN_MAT52ARD) {
+        double s = sqrt(5.0) * sqrt(r);
+        return -(5.0 / 3.0) * s2 * (1.0 + s) * exp(-s);
+    }
+    return -(s2 * exp(-0.5 * r));
+}
+void oracle_predict_grad(int kern, int64_t d, int64_t N, const double *X, const double *il2, double s2f, double beta,
                          const double *L, int64_t ld, const double *alpha, const double *xs, double *mu,
                          double *var, double *dmu, double *dvar) {
     double *ks = (double *)malloc(sizeof(double) * N), *u = (double *)malloc(sizeof(double) * N);
+    double *fac = (double *)malloc(sizeof(double) * N);
     double m = 0.0;
     for (int64_t i = 0; i < N; ++i) {
-        ks[i] = s2f * exp(-0.5 * wsqdist(d, X + d * i, xs, il2));
+        double r = wsqdist(d, X + d * i, xs, il2);
+        ks[i] = cov_from_r(kern, s2f, r);
+        fac[i] = cov_grad_fac(kern, s2f, r);
         m += ks[i] * alpha[i];
         u[i] = ks[i];
     }
@@ -290,7 +301,7 @@ void oracle_predict_grad(int64_t d, int64_t N, const double *X, const double *il
     for (int64_t k = 0; k < d; ++k) {
         double gm = 0.0, gv = 0.0;
         for (int64_t i = 0; i < N; ++i) {
-            double dk = -ks[i] * (xs[k] - X[d * i + k]) * il2[k];
+            double dk = fac[i] * (xs[k] - X[d * i + k]) * il2[k];
             gm += dk * alpha[i];
             gv += dk * u[i];
         }
@@ -299,6 +310,7 @@ void oracle_predict_grad(int64_t d, int64_t N, const double *X, const double *il
     }
     free(ks);
     free(u);
+    free(fac);
 }
 /* d(score)/d(mu), d(score)/d(s2) of the REFERENCE's formulas (not textbook EI).
  * EI_ref = D*Phi(z) + phi(z), z = D/sqrt(s2):  dEI/dmu = Phi(z) + (D - z)/sqrt(s2) * phi(z)... expanded below. */
@@ -326,16 +338,16 @@ void oracle_acq_partials(int acq, const double *p, double mu, double s2, double 
     default: *dmu = 1.0; *ds2 = 0.0; return;
     }
 }
-void oracle_score_grad(int64_t d, int64_t N, const double *X, const double *loglen, double logsig,
+void oracle_score_grad(int kern, int64_t d, int64_t N, const double *X, const double *loglen, double logsig,
                        double beta, const double *L, int64_t ld, const double *alpha, int acq,
                        const double *acq_params, const double *Xs, int64_t R, double *score, double *grad) {
     double *il2 = (double *)malloc(sizeof(double) * d);
-    oracle_il2(KERN_SEARD, d, loglen, il2);
+    oracle_il2(kern, d, loglen, il2);
     double s2f = exp(2.0 * logsig);
     double *gm = (double *)malloc(sizeof(double) * d), *gv = (double *)malloc(sizeof(double) * d);
     for (int64_t r = 0; r < R; ++r) {
         double mu, var, a, b;
-        oracle_predict_grad(d, N, X, il2, s2f, beta, L, ld, alpha, Xs + d * r, &mu, &var, gm, gv);
+        oracle_predict_grad(kern, d, N, X, il2, s2f, beta, L, ld, alpha, Xs + d * r, &mu, &var, gm, gv);
         score[r] = oracle_acq(acq, acq_params, mu, var);
         oracle_acq_partials(acq, acq_params, mu, var, &a, &b);
         for (int64_t k = 0; k < d; ++k) grad[d * r + k] = a * gm[k] + b * gv[k];

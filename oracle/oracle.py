@@ -146,7 +146,7 @@ class COracle:
                               C.byref(bi), C.c_int(nthreads))
         return score, bv.value, bi.value
 
-    def score_grad(self, X, loglen, logsig, beta, L, alpha, acq, params, Xs):
+    def score_grad(self, X, loglen, logsig, beta, L, alpha, acq, params, Xs, kern="SEArd"):
         X = np.ascontiguousarray(X, dtype=np.float64)
         Xs = np.ascontiguousarray(Xs, dtype=np.float64)
         N, d = X.shape
@@ -157,7 +157,7 @@ class COracle:
             p = np.zeros(1)
         score = np.empty(R)
         grad = np.empty((R, d))
-        self.lib.oracle_score_grad(C.c_int64(d), C.c_int64(N), _p(X), _p(ll), C.c_double(logsig),
+        self.lib.oracle_score_grad(C.c_int(KERN[kern]), C.c_int64(d), C.c_int64(N), _p(X), _p(ll), C.c_double(logsig),
                                    C.c_double(beta), _p(L), C.c_int64(L.shape[1]), _p(alpha),
                                    C.c_int(ACQ[acq]), _p(p), _p(Xs), C.c_int64(R), _p(score), _p(grad))
         return score, grad

@@ -143,18 +143,19 @@ def test_not_positive_definite_reports_pivot(orc):
         orc.cholesky(A)
 
 
-def test_gradient_matches_finite_difference(orc):
+@pytest.mark.parametrize("kern", ["SEArd", "Mat52Ard"])
+def test_gradient_matches_finite_difference(orc, kern):
     X, y, Xs = synth(60, 3, 6, seed=7)
     ll = np.array([-0.3, 0.1, -0.6])
-    L, alpha = orc.fit(X, y, ll, 0.2, -2.0, 0.1)
+    L, alpha = orc.fit(X, y, ll, 0.2, -2.0, 0.1, kern=kern)
     for acq, p in [("EI", [y.max()]), ("UCB", [2.0]), ("PI", [y.max()]), ("MI", [1.0, 0.3]), ("MaxMean", [])]:
-        sc, grad = orc.score_grad(X, ll, 0.2, 0.1, L, alpha, acq, p, Xs)
+        sc, grad = orc.score_grad(X, ll, 0.2, 0.1, L, alpha, acq, p, Xs, kern=kern)
         h = 1e-6
         for k in range(3):
             Xp, Xm = Xs.copy(), Xs.copy()
             Xp[:, k] += h; Xm[:, k] -= h
-            fp, _, _ = orc.score(X, ll, 0.2, 0.1, L, alpha, acq, p, Xp)
-            fm, _, _ = orc.score(X, ll, 0.2, 0.1, L, alpha, acq, p, Xm)
+            fp, _, _ = orc.score(X, ll, 0.2, 0.1, L, alpha, acq, p, Xp, kern=kern)
+            fm, _, _ = orc.score(X, ll, 0.2, 0.1, L, alpha, acq, p, Xm, kern=kern)
             np.testing.assert_allclose(grad[:, k], (fp - fm) / (2 * h), rtol=2e-5, atol=1e-8)
 
 

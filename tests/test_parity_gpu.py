@@ -191,6 +191,57 @@ def test_capacity_growth_and_incremental_append(bohip, orc):
     np.testing.assert_array_equal(m.y, y)
 
 
+def test_incremental_append_is_used_and_matches_refit(bohip, orc):
+    """A2': single / few-point appends extend the factor on the device (no refit), across a tile boundary
+    (alpha row moves from a padding row into a new tile) and with duplicated columns (repetitions > 1)."""
+    X, y, Xs = synth(140, 3, 50, seed=14)
+    ll = np.array([-0.4, -0.7, -0.2])
+    m = bohip.ElasticGPE(3, kernel=bohip.SEArd(ll, 0.3), logNoise=-1.5, mean=bohip.MeanConst(0.2), capacity=400)
+    m.append_(X[:120].T, y[:120])
+    refits0 = m.info(2)
+    n = 120
+    for p_ in (1, 1, 5, 1, 2, 1, 1, 8):                       # 120 -> 140, crossing 127/128
+        m.append_(X[n:n + p_].T, y[n:n + p_]); n += p_
+    assert n == 140 and m.info(2) == refits0 and m.info(3) == 8
+    L, alpha = orc.fit(X, y, ll, 0.3, -1.5, 0.2)
+    np.testing.assert_allclose(m.factor(), L, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(m.alpha(), alpha, rtol=1e-7, atol=1e-10 * np.abs(alpha).max())
+    mu_o, var_o = orc.predict(X, ll, 0.3, 0.2, L, alpha, Xs)
+    mu, var = m.predict_f(Xs.T)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=mu_floor(alpha, math.exp(0.6)))
+    assert np.all(np.abs(var - var_o) <= var_tol(var_o, 140, math.exp(0.6)))
+    # README-style repetitions: the same point appended 5 times (rank-deficient up to the noise term)
+    xr = np.repeat(Xs[:1].T, 5, axis=1); yr = np.linspace(0.1, 0.5, 5)
+    m.append_(xr, yr)
+    X2 = np.concatenate([X, xr.T]); y2 = np.concatenate([y, yr])
+    L2, a2 = orc.fit(X2, y2, ll, 0.3, -1.5, 0.2)
+    np.testing.assert_allclose(m.factor(), L2, rtol=1e-8, atol=1e-11)
+    m2 = make_model(bohip, X2, y2, ll, 0.3, -1.5, 0.2)        # full refit of the same data
+    sc_i, _, bi_i = m.score("EI", [y2.max()], Xs.T)
+    sc_f, _, bi_f = m2.score("EI", [y2.max()], Xs.T)
+    np.testing.assert_allclose(sc_i, sc_f, rtol=1e-7, atol=1e-12)
+    assert bi_i == bi_f
+
+
+@pytest.mark.parametrize("kern,N,d,R", [("SEArd", 200, 3, 40), ("SEArd", 1000, 8, 300), ("Mat52Ard", 300, 6, 130), ("SEIso", 130, 2, 5)])
+def test_score_grad_vs_oracle(bohip, orc, kern, N, d, R):
+    """A8: analytic d(score)/dx through the reference's formulas, against the oracle's analytic gradient."""
+    X, y, Xs = synth(N, d, R, seed=31 + d)
+    ll = np.array([-0.5]) if kern == "SEIso" else np.linspace(-0.8, -0.2, d)
+    L, alpha = orc.fit(X, y, ll, 0.1, -2.0, 0.05, kern=kern)
+    m = make_model(bohip, X, y, ll, 0.1, -2.0, 0.05, kern=kern)
+    tau = float(y.max())
+    for acq, p in [("EI", [tau]), ("UCB", [2.5]), ("PI", [tau]), ("MI", [1.0, 0.3]), ("MaxMean", [])]:
+        sc_o, g_o = orc.score_grad(X, ll, 0.1, 0.05, L, alpha, acq, p, Xs, kern=kern)
+        sc, g = m.score_grad(acq, p, Xs.T)
+        assert g.shape == (d, R)
+        np.testing.assert_allclose(sc, sc_o, rtol=1e-6, atol=mu_floor(alpha, math.exp(0.2)) + 1e-12)
+        scale = np.abs(g_o).max()
+        np.testing.assert_allclose(g.T, g_o, rtol=1e-6, atol=1e-9 * scale + 1e-12)
+        # value path and gradient path agree on the scores bit-for-bit
+        np.testing.assert_array_equal(sc, m.score(acq, p, Xs.T)[0])
+
+
 def test_hyperparameter_change_refits(bohip, orc):
     X, y, Xs = synth(150, 3, 30, seed=6)
     m = make_model(bohip, X, y, np.zeros(3), 0.0, -2.0, 0.0)
