@@ -1,0 +1,268 @@
+"""Acquisition types and the multi-restart search, mirroring reference src/acquisitionfunctions.jl and
+src/acquisition.jl.  The functors keep the reference's formulas verbatim (host versions, used for single
+points and documentation); batches are scored on the device through ``model.score``.
+
+Where the reference runs R sequential NLopt ascents (src/acquisition.jl:58-66), ``acquire_max`` scores /
+ascends ALL R Latin-hypercube starts in lock-step on the GPU:
+    method :LD_*  -> batched projected L-BFGS driven by the device's analytic gradient (score_grad)
+    method :GN_* / :LN_* -> derivative-free: ``maxeval`` candidates scored in one batch
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from types import SimpleNamespace
+
+import numpy as np
+
+from .model import ElasticGPE, dims, maxy, mean_var, myrand
+from .utils import latin_hypercube_sampling, normal_cdf, normal_pdf
+
+
+class AbstractAcquisition:
+    acq_id = None
+
+    def params(self):
+        return []
+
+
+def setparams_(a, model):                                     # setparams!(a, model) = nothing :3
+    f = getattr(a, "_setparams", None)
+    return f(model) if f else None
+
+
+class ProbabilityOfImprovement(AbstractAcquisition):          # :21-28
+    acq_id = "PI"
+
+    def __init__(self, tau=-math.inf):
+        self.tau = float(tau)
+
+    def __call__(self, mu, s2):
+        if s2 == 0:
+            return float(mu > self.tau)
+        return normal_cdf(mu - self.tau, s2)
+
+    def _setparams(self, model):                              # :44-46
+        self.tau = max(maxy(model), self.tau)
+        return self.tau
+
+    def params(self):
+        return [self.tau]
+
+
+class ExpectedImprovement(AbstractAcquisition):               # :40-50
+    acq_id = "EI"
+
+    def __init__(self, tau=-math.inf):
+        self.tau = float(tau)
+
+    def __call__(self, mu, s2):
+        if s2 == 0:
+            return mu - self.tau if mu > self.tau else 0.0
+        return (mu - self.tau) * normal_cdf(mu - self.tau, s2) + math.sqrt(s2) * normal_pdf(mu - self.tau, s2)
+
+    _setparams = ProbabilityOfImprovement._setparams
+    params = ProbabilityOfImprovement.params
+
+
+class BrochuBetaScaling:                                      # :66-68
+    def __init__(self, delta=0.1):
+        self.delta = float(delta)
+
+
+class NoBetaScaling:                                          # :72
+    pass
+
+
+class UpperConfidenceBound(AbstractAcquisition):              # :81-96
+    acq_id = "UCB"
+
+    def __init__(self, scaling=None, beta_t=1.0):
+        self.scaling = scaling if scaling is not None else BrochuBetaScaling(0.1)
+        self.beta_t = float(beta_t)
+
+    def __call__(self, mu, s2):
+        return mu + self.beta_t * math.sqrt(s2)
+
+    def _setparams(self, model):                              # :91-95 (BrochuBetaScaling only)
+        if isinstance(self.scaling, BrochuBetaScaling):
+            D, nobs = dims(model)
+            nobs = 1 if nobs == 0 else nobs
+            self.beta_t = math.sqrt(2 * math.log(nobs ** (D / 2 + 2) * math.pi ** 2 / (3 * self.scaling.delta)))
+        return self.beta_t
+
+    def params(self):
+        return [self.beta_t]
+
+
+class ThompsonSamplingSimple(AbstractAcquisition):            # :107-108
+    acq_id = "Thompson"
+
+
+class MaxMean(AbstractAcquisition):                           # :110-111
+    acq_id = "MaxMean"
+
+    def __call__(self, mu, s2):
+        return mu
+
+
+class MutualInformation(AbstractAcquisition):                 # :126-141
+    acq_id = "MI"
+
+    def __init__(self, alpha=1.0, gamma_hat=0.0):
+        self.sqrt_alpha = math.sqrt(alpha)
+        self.gamma_hat = float(gamma_hat)
+
+    def __call__(self, mu, s2):
+        return mu + self.sqrt_alpha * (math.sqrt(s2 + self.gamma_hat) - math.sqrt(self.gamma_hat))
+
+    def _setparams(self, model):                              # :131-140
+        D, nobs = dims(model)
+        if nobs == 0:
+            self.gamma_hat = 0.0
+        else:
+            last_x = model.x[:, -1]
+            _, s2 = mean_var(model, last_x)
+            self.gamma_hat += s2
+        return self.gamma_hat
+
+    def params(self):
+        return [self.sqrt_alpha, self.gamma_hat]
+
+
+def acquisitionfunction(a, model, rng=None):
+    """:4-9, :108, :111.  x (vector or d x R matrix) -> score(s); batches run fused on the device."""
+    if isinstance(a, ThompsonSamplingSimple):
+        return lambda x: myrand(model, x, rng)
+    if isinstance(a, MaxMean):
+        return lambda x: mean_var(model, x)[0]
+
+    def f(x):
+        x = np.asarray(x, dtype=np.float64)
+        sc, _, _ = model.score(a.acq_id, a.params(), x)
+        return float(sc[0]) if x.ndim == 1 else sc
+
+    return f
+
+
+# ---- src/acquisition.jl ----------------------------------------------------------------------------------
+def defaultoptions(model_type, acq_type):                    # :4-9
+    if isinstance(acq_type, type) and issubclass(acq_type, ThompsonSamplingSimple):
+        return dict(method="GN_DIRECT_L", restarts=1, maxeval=2000)
+    return dict(method="LD_LBFGS", restarts=10, maxeval=2000)
+
+
+def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-10, history=8):
+    """Lock-step projected L-BFGS ascent of R independent d-dimensional problems (role of NLopt :LD_LBFGS
+    with lower/upper bounds, src/acquisition.jl:23-35).  fg(X) -> (f[R], G[d,R]) is ONE device call.
+    Returns (f, X) at the best point seen per column."""
+    d, R = X0.shape
+    lbc, ubc = lb.reshape(-1, 1), ub.reshape(-1, 1)
+    X = np.clip(X0, lbc, ubc)
+    f, G = fg(X)
+    evals = 1
+    S, Y = [], []
+    active = np.isfinite(f)
+    best_f, best_X = f.copy(), X.copy()
+    while evals < maxeval and active.any():
+        # two-loop recursion, vectorised over columns
+        q = G.copy()
+        al = []
+        for s_, y_ in zip(reversed(S), reversed(Y)):
+            rho = 1.0 / np.maximum(np.einsum("dr,dr->r", y_, s_), 1e-300)
+            a_ = rho * np.einsum("dr,dr->r", s_, q)
+            q -= a_ * y_
+            al.append((a_, rho))
+        if S:
+            sy = np.einsum("dr,dr->r", S[-1], Y[-1])
+            yy = np.maximum(np.einsum("dr,dr->r", Y[-1], Y[-1]), 1e-300)
+            q *= np.where(sy > 0, sy / yy, 1.0)
+        for (a_, rho), s_, y_ in zip(reversed(al), S, Y):
+            b_ = rho * np.einsum("dr,dr->r", y_, q)
+            q += (a_ - b_) * s_
+        D = q                                                     # ascent direction (maximisation: H * grad)
+        # bounds: do not push active constraints outward; fall back to the gradient if not an ascent direction
+        blocked = ((X <= lbc) & (D < 0)) | ((X >= ubc) & (D > 0))
+        D = np.where(blocked, 0.0, D)
+        Gp = np.where(((X <= lbc) & (G < 0)) | ((X >= ubc) & (G > 0)), 0.0, G)
+        slope = np.einsum("dr,dr->r", Gp, D)
+        bad = ~(slope > 0)
+        D[:, bad] = Gp[:, bad]
+        slope = np.einsum("dr,dr->r", Gp, D)
+        step = np.ones(R) if S else 1.0 / np.maximum(np.sqrt(np.einsum("dr,dr->r", D, D)), 1e-12) * 0.1 * np.min(ub - lb + 1e-300)
+        step = np.where(active & (slope > 0), step, 0.0)
+        accepted = ~active | ~(slope > 0)
+        Xn, fn, Gn = X.copy(), f.copy(), G.copy()
+        for _ in range(12):                                       # backtracking Armijo, all columns per device call
+            Xt = np.clip(X + step * D, lbc, ubc)
+            ft, Gt = fg(Xt)
+            evals += 1
+            ok = (~accepted) & np.isfinite(ft) & (ft >= f + 1e-4 * np.einsum("dr,dr->r", Gp, Xt - X))
+            Xn[:, ok], fn[ok], Gn[:, ok] = Xt[:, ok], ft[ok], Gt[:, ok]
+            accepted |= ok
+            if accepted.all() or evals >= maxeval:
+                break
+            step = np.where(accepted, step, step * 0.5)
+        s_ = Xn - X
+        y_ = -(Gn - G)                                            # curvature pair for maximisation
+        df = fn - f
+        moved = np.sqrt(np.einsum("dr,dr->r", s_, s_))
+        active = active & (df > ftol_rel * np.maximum(np.abs(fn), 1e-300)) & (moved > xtol_abs)
+        good = np.einsum("dr,dr->r", s_, y_) > 1e-14
+        S.append(np.where(good, s_, 0.0)); Y.append(np.where(good, y_, 0.0))
+        if len(S) > history:
+            S.pop(0); Y.pop(0)
+        X, f, G = Xn, fn, Gn
+        better = f > best_f
+        best_f[better], best_X[:, better] = f[better], X[:, better]
+    return best_f, best_X
+
+
+def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None):
+    """src/acquisition.jl:48-68: R Latin-hypercube starts (utils.jl:96-120), local search from each, keep the
+    best under strict '>' (first maximum wins).  Returns (maxf, maxx)."""
+    lb = np.asarray(lowerbounds, dtype=np.float64)
+    ub = np.asarray(upperbounds, dtype=np.float64)
+    opts = options if isinstance(options, dict) else dict(vars(options))
+    setparams_(a, model)                                          # nlopt_setup :30
+    method = str(opts.get("method", "LD_LBFGS")).lstrip(":")
+    restarts = int(opts.get("restarts", 10))
+    maxeval = int(opts.get("maxeval", 2000))
+    maxf, maxx = -math.inf, lb.copy()                             # :55-56
+    if model.nobs == 0 or restarts <= 0:
+        return maxf, maxx
+    derivative = len(method) > 1 and method[1] == "D" and not isinstance(a, ThompsonSamplingSimple)   # :31
+    if isinstance(a, ThompsonSamplingSimple):
+        # one joint draw of the posterior at `maxeval` candidates per restart, arg-max on the device
+        n = max(maxeval, 1)
+        for _ in range(restarts):
+            starts = latin_hypercube_sampling(lb, ub, n, rng)
+            seed = int((rng or np.random.default_rng()).integers(0, 2 ** 63 - 1))
+            bv, bi = model.thompson(starts, 1, seed=seed)
+            if bi[0] >= 0 and bv[0] > maxf:
+                maxf, maxx = float(bv[0]), starts[:, int(bi[0])].copy()
+        return maxf, maxx
+    acq, p = a.acq_id, a.params()
+    if derivative:
+        starts = latin_hypercube_sampling(lb, ub, restarts, rng)
+        iters = max(2, min(maxeval, 200))
+
+        def fg(X):
+            return model.score_grad(acq, p, X)
+
+        f, X = _batched_lbfgs_ascent(fg, starts, lb, ub, iters,
+                                     ftol_rel=float(opts.get("ftol_rel", 1e-10)), xtol_abs=float(opts.get("xtol_abs", 1e-10)))
+    else:
+        n = max(restarts, min(maxeval * restarts, 1 << 20))
+        X = latin_hypercube_sampling(lb, ub, n, rng)
+        f, _, _ = model.score(acq, p, X)
+    for j in range(X.shape[1]):                                   # :58-66, strict '>' => first maximum wins
+        if f[j] > maxf:
+            maxf, maxx = float(f[j]), X[:, j].copy()
+    if not np.isfinite(maxf):
+        warnings.warn("acquisition returned no finite value; keeping the lower bounds as maximiser")
+    return maxf, maxx
+
+
+def acquire_model_max(o, options=None):                           # :45-47
+    return acquire_max(MaxMean(), o.model, o.lowerbounds, o.upperbounds, options or o.acquisitionoptions, o.rng)

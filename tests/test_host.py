@@ -1,0 +1,130 @@
+"""CPU tests of the host mirror: the reference's own host-side tests restated (test/utils.jl, test/BayesianOptimization.jl,
+test/acquisition.jl option plumbing) plus the pure-host parts of acquisition.py."""
+import math
+import time
+
+import numpy as np
+import pytest
+
+import bohip
+from bohip import acquisition as A
+from bohip.utils import DurationCounter, IterationCounter, init_, isdone, latin_hypercube_sampling, step_
+
+
+def test_counters_like_reference_test_utils():                      # reference test/utils.jl:4-23
+    it = IterationCounter(0, 0, 10)
+    for _ in range(10):
+        step_(it)
+    assert isdone(it) is True
+    bohip.maxiterations_(it, 40)
+    assert it.N == 40
+    init_(it)
+    assert it.c == 0 and it.i == 10
+    now = time.time()
+    du = DurationCounter(now, 0.05, now, now + 0.05)
+    time.sleep(0.06)
+    assert isdone(du)
+    bohip.maxduration_(du, 0.15)
+    init_(du)
+    assert not isdone(du)
+    time.sleep(0.16)
+    assert isdone(du)
+
+
+def test_merge_with_defaults_errors():                               # reference test/BayesianOptimization.jl:16-23
+    f = lambda x: x[0] + x[1]
+    l, u = [-1, -2], [3, 4]
+    with pytest.raises(ValueError):
+        bohip.merge_with_defaults(f, l, u, dict(func=lambda x: x[0]))
+    with pytest.raises(ValueError):
+        bohip.merge_with_defaults(f, l, u, dict(lowerbounds=[], upperbounds=[-1, -100]))
+    with pytest.raises(ValueError):
+        bohip.merge_with_defaults(f, l, u, dict(hello="world"))
+    with pytest.raises(ValueError):
+        bohip.merge_with_defaults(f, [1.0], [3.0, 4.0], {})
+
+
+def test_merge_with_defaults_ordering_with_explicit_model():         # :6-15 (model passed, so no device is needed)
+    f = lambda x: x[0] + x[1]
+    sentinel = object()
+    args, kwargs = bohip.merge_with_defaults(f, [-1, -2], [3, 4], dict(sense=bohip.Max, model=sentinel,
+                                                                      acquisition=bohip.ProbabilityOfImprovement(),
+                                                                      maxiterations=20))
+    assert len(args) == 6 and args[0] is f and args[1] is sentinel
+    assert isinstance(args[2], bohip.ProbabilityOfImprovement) and isinstance(args[3], bohip.MAPGPOptimizer)
+    assert kwargs["sense"] == bohip.Max and kwargs["maxiterations"] == 20
+
+
+def test_defaultoptions():                                           # src/acquisition.jl:4-9, test/acquisition.jl:4-9
+    assert bohip.defaultoptions(bohip.ElasticGPE, bohip.ExpectedImprovement) == dict(method="LD_LBFGS", restarts=10, maxeval=2000)
+    assert bohip.defaultoptions(bohip.ElasticGPE, bohip.ThompsonSamplingSimple) == dict(method="GN_DIRECT_L", restarts=1, maxeval=2000)
+    merged = {**bohip.defaultoptions(bohip.ElasticGPE, bohip.MaxMean), **dict(maxtime=3.0, ftol_abs=np.finfo(float).eps)}
+    assert merged["maxeval"] == 2000 and merged["maxtime"] == 3.0 and merged["ftol_abs"] == np.finfo(float).eps
+
+
+def test_host_functors_match_oracle_formulas(orc):
+    ei, pi = bohip.ExpectedImprovement(0.5), bohip.ProbabilityOfImprovement(0.5)
+    ucb, mi = bohip.UpperConfidenceBound(bohip.NoBetaScaling(), 2.5), bohip.MutualInformation(alpha=1.69, gamma_hat=0.4)
+    for mu, s2 in [(0.3, 4.0), (0.7, 0.0), (0.3, 0.0), (-3.0, 0.2), (5.0, 1e-6)]:
+        assert ei(mu, s2) == orc.acq("EI", [0.5], mu, s2)
+        assert pi(mu, s2) == orc.acq("PI", [0.5], mu, s2)
+        assert ucb(mu, s2) == orc.acq("UCB", [2.5], mu, s2)
+        assert mi(mu, s2) == pytest.approx(orc.acq("MI", [1.3, 0.4], mu, s2), rel=1e-15)
+    assert bohip.ExpectedImprovement().tau == -math.inf               # ExpectedImprovement(; tau = -Inf)
+
+
+class FakeModel:
+    """Just enough of the model contract (dims / y / x) for setparams_ to run on the host."""
+    def __init__(self, d, y):
+        self.dim, self._y = d, np.asarray(y, float)
+        self.x = np.zeros((d, len(y)))
+    y = property(lambda s: s._y)
+    nobs = property(lambda s: s._y.size)
+
+
+def test_setparams_rules():                                          # src/acquisitionfunctions.jl:44-46, 91-95
+    m = FakeModel(8, np.linspace(-1, 2, 3000))
+    ei = bohip.ExpectedImprovement()
+    bohip.setparams_(ei, m)
+    assert ei.tau == 2.0                                             # test/warmstart.jl:64: tau == maximum(y)
+    m2 = FakeModel(8, [0.5])
+    bohip.setparams_(ei, m2)
+    assert ei.tau == 2.0                                             # monotone: max(maxy, tau)
+    ucb = bohip.UpperConfidenceBound()
+    bohip.setparams_(ucb, m)
+    assert ucb.beta_t == pytest.approx(10.152008469453344, rel=1e-15)  # SURVEY.md A6 probe (N=3000, d=8)
+    bohip.setparams_(ucb, FakeModel(2, []))
+    assert ucb.beta_t == pytest.approx(math.sqrt(2 * math.log(math.pi ** 2 / 0.3)), rel=1e-15)   # nobs == 0 -> 1
+    fixed = bohip.UpperConfidenceBound(bohip.NoBetaScaling(), 3.0)
+    bohip.setparams_(fixed, m)
+    assert fixed.beta_t == 3.0
+    assert bohip.setparams_(bohip.ThompsonSamplingSimple(), m) is None
+
+
+def test_lhs_initialiser_and_iterators():
+    rng = np.random.default_rng(0)
+    S = latin_hypercube_sampling([-5.0, 0.0], [10.0, 15.0], 20, rng)
+    assert S.shape == (2, 20)
+    for k, (lo, hi) in enumerate([(-5, 10), (0, 15)]):
+        strata = np.floor((S[k] - lo) / ((hi - lo) / 20)).astype(int)
+        assert sorted(strata) == list(range(20))
+    it = bohip.ScaledLHSIterator([0.0], [1.0], 7, rng)
+    assert len(it) == 7 and len(list(it)) == 7
+    sob = bohip.ScaledSobolIterator([-5.0, 0.0], [10.0, 15.0], 10)
+    pts = np.array(list(sob))
+    assert pts.shape == (10, 2) and np.all(pts >= [-5, 0]) and np.all(pts <= [10, 15])
+    assert len(bohip.ScaledSobolIterator([0.0], [1.0], 0)) == 0
+
+
+def test_batched_lbfgs_on_a_known_concave_problem():
+    """The lock-step projected L-BFGS (role of NLopt :LD_LBFGS) on f_r(x) = -|x - c_r|^2 with box bounds."""
+    rng = np.random.default_rng(3)
+    d, R = 4, 9
+    C_ = rng.uniform(-2, 2, (d, R))
+    lb, ub = np.full(d, -1.0), np.full(d, 1.0)
+
+    def fg(X):
+        return -((X - C_) ** 2).sum(0), -2 * (X - C_)
+
+    f, X = A._batched_lbfgs_ascent(fg, rng.uniform(-1, 1, (d, R)), lb, ub, maxeval=200)
+    np.testing.assert_allclose(X, np.clip(C_, -1, 1), atol=1e-6)     # box-constrained maximiser = projection of c
