@@ -139,7 +139,9 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
         if (*p) { hipFree(*p); *p = nullptr; }
     g->kst_rows = g->vt_rows = g->q_cap = 0;
     g->cap = cap;
-    g->ld = round_up(cap + 1, TILE);
+    // +16 doubles: row stride is an ODD multiple of 128 B, so the 128 rows of a tile spread over the L2/HBM
+    // channels instead of camping on one (a power-of-two stride sends every row of a tile to the same channel).
+    g->ld = round_up(cap + 1, TILE) + 16;
     const size_t mat = (size_t)g->ld * g->ld * sizeof(double);
     HIPCHK(hipMalloc(&g->dX, std::max<size_t>(8, (size_t)cap * g->d * 8)));
     HIPCHK(hipMalloc(&g->dy, std::max<size_t>(8, (size_t)cap * 8)));
@@ -162,6 +164,8 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 }
 
 // ---- GEMM launcher --------------------------------------------------------------------------------
+static constexpr int GEMM_LDS_BYTES_N64 = (2 * TILE_LDS_DOUBLES + 2 * 64 * LDSROW) * 8;  // 55296 B
+static int g_cand_tile = 64;
 static int launch_gemm(bohip_gp* g, bool b_nmajor, const GemmParams& p, int batch) {
     const int tiles = p.lower_tiles ? p.mt * (p.mt + 1) / 2 : p.mt * p.nt;
     if (tiles <= 0 || batch <= 0 || p.kc <= 0) return 0;
@@ -177,10 +181,12 @@ static int launch_gemm(bohip_gp* g, bool b_nmajor, const GemmParams& p, int batc
 static int one_time_kernel_setup() {
     static bool done = false;
     if (done) return 0;
+    if (const char* e = getenv("BOHIP_CAND_TILE")) g_cand_tile = atoi(e) == 128 ? 128 : 64;
     HIPCHK(hipFuncSetAttribute((const void*)k_potf2_inv, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return 0;
 }
@@ -408,6 +414,23 @@ static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1,
     hipLaunchKernelGGL(k_kstar<DT>, grid, dim3(256), 0, g->stream, g->dX, g->n, Npad, dXs, r0, r1, hp, g->dKsT, g->ld, rb);
 }
 
+// V = W K* with the fused epilogue.  Candidate tiles are 64 wide unless the batch is tiny: the job length is set
+// by the K extent (row tile), so halving the tile width halves the longest job and lets heaviest-first
+// list scheduling balance the 2 x 256 workgroup slots (128-wide tiles: makespan 24 units vs 18.75 average).
+static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t Rpad, int64_t r0, double* VT) {
+    if (g_cand_tile == 64) {
+        const int CT = (int)((ncand + 63) / 64), n_local = (CT + 7) / 8;
+        hipLaunchKernelGGL(k_trigemm_sq<4>, dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES_N64, g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+    } else {
+        const int CT = (int)((ncand + TILE - 1) / TILE), n_local = (CT + 7) / 8;
+        hipLaunchKernelGGL(k_trigemm_sq<8>, dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // posterior pass over all R candidates: fills dq (partials) and dmu_raw.  VT optional (chunk-local).
 static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
     CHK(one_time_kernel_setup());
@@ -426,12 +449,8 @@ static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
         else launch_kstar<64>(g, dXs, r0, r1, Npad, hp);
         HIPCHK(hipGetLastError());
         t_end(g);
-        const int CT = (int)((r1 - r0 + TILE - 1) / TILE);
-        const int n_local = (CT + 7) / 8;
         t_begin(g, "trigemm_sq");
-        hipLaunchKernelGGL(k_trigemm_sq, dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, (double*)nullptr, (int64_t)0);
-        HIPCHK(hipGetLastError());
+        CHK(launch_trigemm(g, T, r1 - r0, N, Rpad, r0, nullptr));
         t_end(g);
     }
     return 0;
@@ -500,11 +519,8 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
         else launch_kstar<64>(g, dXs, r0, r1, Npad, hp);
         t_end(g);
         const int CT = (int)((r1 - r0 + TILE - 1) / TILE);
-        const int n_local = (CT + 7) / 8;
         t_begin(g, "trigemm_sq+V");
-        hipLaunchKernelGGL(k_trigemm_sq, dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, g->dVT, g->ld);
-        HIPCHK(hipGetLastError());
+        CHK(launch_trigemm(g, T, r1 - r0, N, Rpad, r0, g->dVT));
         t_end(g);
         t_begin(g, "gemm_U");
         GemmParams p{};

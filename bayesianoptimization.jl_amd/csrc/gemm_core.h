@@ -27,18 +27,21 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
 // ---- global -> register staging (issued early, consumed after the MFMA block) ----------------
 // K-major operand: tile = 128 rows x 16 doubles at src (row stride ld).  8 lanes cover one
 // 128-B row segment, a wave covers 8 full cache lines per instruction.
-__device__ __forceinline__ void stage_load_kmajor(const double* __restrict__ src, int64_t ld, int tid, d2 (&r)[4]) {
+template <int NQ>  // NQ * 32 rows
+__device__ __forceinline__ void stage_load_kmajor(const double* __restrict__ src, int64_t ld, int tid, d2 (&r)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int row = q * 32 + (tid >> 3), seg = tid & 7;
         r[q] = *reinterpret_cast<const d2*>(src + (int64_t)row * ld + seg * 2);
     }
 }
-__device__ __forceinline__ void stage_store_kmajor(double* dst, int tid, const d2 (&r)[4]) {
+template <int NQ>
+__device__ __forceinline__ void stage_store_kmajor(double* dst, int tid, const d2 (&r)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int row = q * 32 + (tid >> 3), seg = tid & 7;
-        *reinterpret_cast<d2*>(dst + row * LDSROW + seg * 2) = r[q];
+        dst[row * LDSROW + seg * 2] = r[q].x;  // two ds_write_b64: the 136-B row stride is only 8-B aligned
+        dst[row * LDSROW + seg * 2 + 1] = r[q].y;
     }
 }
 // N-major operand (B[k][n], n contiguous): tile = 16 k-rows x 128 n; transposed while storing.
@@ -63,59 +66,83 @@ __device__ __forceinline__ void stage_store_nmajor(double* dst, int tid, const d
 // bank pair = (36*row + 2*col) mod 64 is distinct over the 8 rows x 2 columns of a 32-lane half).
 // One double per fragment keeps the live set at 128 (acc) + 16 + 16 VGPRs, so the kernel fits the
 // 256-VGPR budget of 2 waves/SIMD without spilling.
+template <int NJ>
+__device__ __forceinline__ void load_frags(const double* ap, const double* bp, int s, double (&av)[8], double (&bv)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) av[i] = ap[i * 8 * LDSROW + 4 * s];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[j] = bp[j * 8 * LDSROW + 4 * s];
+}
+template <int NJ>
+__device__ __forceinline__ void mma_step(const double (&av)[8], const double (&bv)[NJ], double (&acc)[8][NJ]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma444(av[i], bv[j], acc[i][j]);
+}
+// Software-pipelined: the fragments of k-step s+1 are read from LDS while the 8*NJ MFMAs of step s
+// issue; the sched_barriers keep hipcc from sinking the reads next to their first use (which exposes
+// the full LDS latency every few MFMAs) and from chaining two k-steps on one accumulator.
+template <int NJ>  // wave tile 64 x (8 * NJ)
 __device__ __forceinline__ void mma_chunk(const double* As, const double* Bs, int lane, int wr, int wc,
-                                          double (&acc)[8][8]) {
+                                          double (&acc)[8][NJ]) {
     const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
     const double* ap = As + (wr * 64 + 4 * (b >> 1) + t) * LDSROW + k;
-    const double* bp = Bs + (wc * 64 + 4 * (b & 1) + t) * LDSROW + k;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        double av[8], bv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            av[i] = ap[i * 8 * LDSROW + 4 * s];
-            bv[i] = bp[i * 8 * LDSROW + 4 * s];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = mfma444(av[i], bv[j], acc[i][j]);
-    }
+    const double* bp = Bs + (wc * 8 * NJ + 4 * (b & 1) + t) * LDSROW + k;
+    double a0[8], b0[NJ], a1[8], b1[NJ];
+    load_frags<NJ>(ap, bp, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags<NJ>(ap, bp, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step<NJ>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags<NJ>(ap, bp, 2, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step<NJ>(a1, b1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags<NJ>(ap, bp, 3, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step<NJ>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_step<NJ>(a1, b1, acc);
 }
 
 // ---- K loop: acc += A[128 x K] * op(B) over chunks [kc_begin, kc_end) -------------------------
 // A points at (row0, 0) of a K-major matrix.  B points at (n0, 0) when K-major, (0, n0) when N-major.
 // Register-staged double buffering: loads of chunk c+1 are in flight during the MFMAs of chunk c;
 // one barrier per chunk.
-template <bool B_NMAJOR>
+template <bool B_NMAJOR, int NJ = 8>
 __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ A, int64_t lda,
                                                const double* __restrict__ B, int64_t ldb, int kc_begin,
-                                               int kc_end, double* smem, double (&acc)[8][8]) {
+                                               int kc_end, double* smem, double (&acc)[8][NJ]) {
+    static_assert(!B_NMAJOR || NJ == 8, "N-major staging exists for 128-wide tiles only");
+    constexpr int BQ = NJ / 2;                          // B tile = 16 * NJ rows = 32 * BQ
+    constexpr int BT = 16 * NJ * LDSROW;                // doubles per B buffer
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     double* As = smem;
     double* Bs = smem + 2 * TILE_LDS_DOUBLES;
-    d2 ra[4], rb[4];
+    d2 ra[4], rb[BQ];
     if (kc_begin >= kc_end) return;
-    stage_load_kmajor(A + (int64_t)kc_begin * KC, lda, tid, ra);
-    if (B_NMAJOR) stage_load_nmajor(B + (int64_t)kc_begin * KC * ldb, ldb, tid, rb);
-    else stage_load_kmajor(B + (int64_t)kc_begin * KC, ldb, tid, rb);
-    stage_store_kmajor(As, tid, ra);
-    if (B_NMAJOR) stage_store_nmajor(Bs, tid, rb);
-    else stage_store_kmajor(Bs, tid, rb);
+    stage_load_kmajor<4>(A + (int64_t)kc_begin * KC, lda, tid, ra);
+    if constexpr (B_NMAJOR) stage_load_nmajor(B + (int64_t)kc_begin * KC * ldb, ldb, tid, rb);
+    else stage_load_kmajor<BQ>(B + (int64_t)kc_begin * KC, ldb, tid, rb);
+    stage_store_kmajor<4>(As, tid, ra);
+    if constexpr (B_NMAJOR) stage_store_nmajor(Bs, tid, rb);
+    else stage_store_kmajor<BQ>(Bs, tid, rb);
     __syncthreads();
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         const int cur = (kc - kc_begin) & 1;
         const bool more = kc + 1 < kc_end;
         if (more) {
-            stage_load_kmajor(A + (int64_t)(kc + 1) * KC, lda, tid, ra);
-            if (B_NMAJOR) stage_load_nmajor(B + (int64_t)(kc + 1) * KC * ldb, ldb, tid, rb);
-            else stage_load_kmajor(B + (int64_t)(kc + 1) * KC, ldb, tid, rb);
+            stage_load_kmajor<4>(A + (int64_t)(kc + 1) * KC, lda, tid, ra);
+            if constexpr (B_NMAJOR) stage_load_nmajor(B + (int64_t)(kc + 1) * KC * ldb, ldb, tid, rb);
+            else stage_load_kmajor<BQ>(B + (int64_t)(kc + 1) * KC, ldb, tid, rb);
         }
-        mma_chunk(As + cur * TILE_LDS_DOUBLES, Bs + cur * TILE_LDS_DOUBLES, lane, wr, wc, acc);
+        mma_chunk<NJ>(As + cur * TILE_LDS_DOUBLES, Bs + cur * BT, lane, wr, wc, acc);
         if (more) {
-            stage_store_kmajor(As + (cur ^ 1) * TILE_LDS_DOUBLES, tid, ra);
-            if (B_NMAJOR) stage_store_nmajor(Bs + (cur ^ 1) * TILE_LDS_DOUBLES, tid, rb);
-            else stage_store_kmajor(Bs + (cur ^ 1) * TILE_LDS_DOUBLES, tid, rb);
+            stage_store_kmajor<4>(As + (cur ^ 1) * TILE_LDS_DOUBLES, tid, ra);
+            if constexpr (B_NMAJOR) stage_store_nmajor(Bs + (cur ^ 1) * BT, tid, rb);
+            else stage_store_kmajor<BQ>(Bs + (cur ^ 1) * BT, tid, rb);
         }
         __syncthreads();
     }
@@ -125,8 +152,9 @@ __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ A, int
 __device__ __forceinline__ int acc_row(int lane, int wr, int mi) {
     return wr * 64 + 8 * mi + 4 * (((lane >> 2) & 3) >> 1) + (lane >> 4);
 }
+template <int NJ = 8>
 __device__ __forceinline__ int acc_col(int lane, int wc, int nj) {
-    return wc * 64 + 8 * nj + 4 * (((lane >> 2) & 3) & 1) + (lane & 3);
+    return wc * 8 * NJ + 8 * nj + 4 * (((lane >> 2) & 3) & 1) + (lane & 3);
 }
 
 }  // namespace bohip

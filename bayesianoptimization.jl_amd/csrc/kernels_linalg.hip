@@ -377,7 +377,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(GemmParams p) {
         const int r = acc_row(lane, wr, mi);
 #pragma unroll
         for (int nj = 0; nj < 8; ++nj) {
-            const int c = acc_col(lane, wc, nj);
+            const int c = acc_col<8>(lane, wc, nj);
             double* dst = C + (int64_t)r * p.ldc + c;
             double v = p.alpha * acc[mi][nj];
             if (p.beta != 0.0) v += p.beta * *dst;

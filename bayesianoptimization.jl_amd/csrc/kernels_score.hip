@@ -60,51 +60,53 @@ __global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ X, int
 // Output: q_part[rt][r] = sum over the tile's rows of v^2 (fixed summation order -> deterministic),
 //         mu_raw[r] = alpha' k*_r taken from the row of W that stores alpha (alpha_row).
 // ------------------------------------------------------------------------------------------------
+template <int NJ>  // candidate tile width CW = 16 * NJ (128 or 64)
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
                                                                 const double* __restrict__ KsT, int64_t ldk,
                                                                 int T, int CT, int64_t alpha_row,
                                                                 double* __restrict__ q_part, int64_t ldq,
                                                                 double* __restrict__ mu_raw, int64_t r_off,
                                                                 double* __restrict__ VT, int64_t ldv) {
+    constexpr int CW = 16 * NJ;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int n_local = (CT + 7) >> 3;
     const int rt = T - 1 - slot / n_local;
     const int ct = xcd + 8 * (slot % n_local);
     if (ct >= CT || rt < 0) return;
-    double acc[8][8];
+    double acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
-    gemm_tile_loop<false>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * TILE * ldk, ldk, 0,
-                          (rt + 1) * (TILE / KC), smem, acc);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0;
+    gemm_tile_loop<false, NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+                              (rt + 1) * (TILE / KC), smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-    double* red = smem;  // [2][128]; safe: gemm_tile_loop ends with a barrier
+    double* red = smem;  // [2][CW]; safe: gemm_tile_loop ends with a barrier
     const int64_t row_base = (int64_t)rt * TILE;
 #pragma unroll
-    for (int nj = 0; nj < 8; ++nj) {
+    for (int nj = 0; nj < NJ; ++nj) {
         double s = 0.0;
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int64_t grow = row_base + acc_row(lane, wr, mi);
             const double v = acc[mi][nj];
             if (grow == alpha_row) {
-                mu_raw[r_off + (int64_t)ct * TILE + acc_col(lane, wc, nj)] = v;
+                mu_raw[r_off + (int64_t)ct * CW + acc_col<NJ>(lane, wc, nj)] = v;
             } else {
                 s += v * v;
             }
             if (VT != nullptr && grow < alpha_row)
-                VT[((int64_t)ct * TILE + acc_col(lane, wc, nj)) * ldv + grow] = v;
+                VT[((int64_t)ct * CW + acc_col<NJ>(lane, wc, nj)) * ldv + grow] = v;
         }
         s += __shfl_xor(s, 8);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        if (lane < 8) red[wr * TILE + wc * 64 + 8 * nj + lane] = s;
+        if (lane < 8) red[wr * CW + wc * 8 * NJ + 8 * nj + lane] = s;
     }
     __syncthreads();
-    if (threadIdx.x < TILE)
-        q_part[(int64_t)rt * ldq + r_off + (int64_t)ct * TILE + threadIdx.x] = red[threadIdx.x] + red[TILE + threadIdx.x];
+    if (threadIdx.x < CW)
+        q_part[(int64_t)rt * ldq + r_off + (int64_t)ct * CW + threadIdx.x] = red[threadIdx.x] + red[CW + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
