@@ -45,7 +45,7 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 static_assert(sizeof(bohip_best) == sizeof(Best), "record layout");
-static constexpr int APP_KSPLIT = 8;
+static constexpr int APP_KSPLIT = 32;
 static constexpr int APP_ROWS = APPEND_PMAX + (APPEND_PMAX / APPEND_CHUNK) * APP_KSPLIT * APPEND_CHUNK;
 
 struct StageTimer {
@@ -196,7 +196,10 @@ static int compute_alpha(bohip_gp* g) {
     const int64_t N = g->n;
     hipLaunchKernelGGL(k_sub_mean, dim3((N + 255) / 256), dim3(256), 0, g->stream, g->dy, g->beta, N, g->dr);
     hipLaunchKernelGGL(k_trimv, dim3((N + 3) / 4), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dr, g->dt);
-    hipLaunchKernelGGL(k_trimv_t, dim3((N + 63) / 64), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dt, g->dalpha);
+    const int nsplit = 16;  // dApp doubles as the [nsplit][ld] partial buffer (APP_ROWS >= 16)
+    hipLaunchKernelGGL(k_trimv_t_part, dim3((N + 63) / 64, nsplit), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dt, nsplit,
+                       g->dApp, g->ld);
+    hipLaunchKernelGGL(k_sum_parts, dim3((N + 255) / 256), dim3(256), 0, g->stream, g->dApp, g->ld, nsplit, N, g->dalpha);
     HIPCHK(hipGetLastError());
     // alpha' into the first padding row of W (cols < N); W[N][N] = 1 meets K*[N] = 0.
     HIPCHK(hipMemcpyAsync(g->dW + N * g->ld, g->dalpha, (size_t)N * 8, hipMemcpyDeviceToDevice, g->stream));
@@ -230,8 +233,14 @@ static int refit(bohip_gp* g) {
     const double noise = std::exp(2.0 * g->lognoise) + std::numeric_limits<double>::epsilon();
     HIPCHK(hipMemsetAsync(g->dinfo, 0, sizeof(int), g->stream));
     t_begin(g, "build_cov");
-    hipLaunchKernelGGL(k_build_cov, dim3(Npad / 64, Npad / 64), dim3(256), 2 * 64 * g->d * 8, g->stream, g->dX, N, Npad,
-                       hp, noise, g->dL, ld, (int64_t)0);
+    {
+        const int rpb = 32;
+        dim3 grid((Npad + 255) / 256, (Npad + rpb - 1) / rpb);
+#define BC(DTV) hipLaunchKernelGGL(k_build_cov<DTV>, grid, dim3(256), 0, g->stream, g->dX, N, Npad, hp, noise, g->dL, ld, rpb)
+        if (g->d <= 2) BC(2); else if (g->d <= 4) BC(4); else if (g->d <= 8) BC(8); else if (g->d <= 16) BC(16);
+        else if (g->d <= 32) BC(32); else BC(64);
+#undef BC
+    }
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "cholesky");

@@ -24,41 +24,38 @@ __device__ __forceinline__ double cov_from_r(int kern, double sigma2, double r) 
     return sigma2 * exp(-0.5 * r);
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void k_build_cov(const double* __restrict__ X, int64_t N, int64_t Npad,
                                                    KernelHyper hp, double noise, double* __restrict__ K,
-                                                   int64_t ld, int64_t row_begin) {
+                                                   int64_t ld, int rows_per_block) {
 #pragma clang fp contract(off)
-    extern __shared__ double sm[];  // xi[64][d], xj[64][d]
+    // thread = column j (its coordinates live in registers); the block walks rows_per_block rows whose
+    // coordinates are wave-uniform (scalar loads).  Stores are coalesced along j.
     const int d = hp.d;
-    double* xi = sm;
-    double* xj = sm + 64 * d;
-    // tile enumeration: blockIdx.y = tile row (64-granular, offset by row_begin), blockIdx.x = tile col
-    const int64_t i0 = row_begin + (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
-    if (j0 / TILE > i0 / TILE) return;  // strictly upper 128-tile: never touched (stays zero)
-    for (int e = threadIdx.x; e < 64 * d; e += 256) {
-        const int64_t gi = i0 + e / d, gj = j0 + e / d;
-        xi[e] = gi < N ? X[gi * d + e % d] : 0.0;
-        xj[e] = gj < N ? X[gj * d + e % d] : 0.0;
-    }
-    __syncthreads();
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // tx -> column (coalesced), ty -> 16 rows each
-    const int64_t gj = j0 + tx;
-    for (int rr = 0; rr < 16; ++rr) {
-        const int li = ty * 16 + rr;
-        const int64_t gi = i0 + li;
+    const int64_t j = blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
+    if (blockIdx.x * 256 / TILE > (i0 + rows_per_block - 1) / TILE) return;  // whole block above the diagonal tiles
+    double xj[DT];
+#pragma unroll
+    for (int k = 0; k < DT; ++k) xj[k] = (k < d && j < N) ? X[j * d + k] : 0.0;
+    for (int64_t i = i0; i < i0 + rows_per_block && i < Npad; ++i) {
+        if (j >= Npad || j / TILE > i / TILE) continue;  // strictly upper 128-tile: never touched (stays zero)
         double v;
-        if (gi < N && gj < N) {
+        if (i < N && j < N) {
+            const double* xi = X + i * d;
             double r = 0.0;
-            for (int k = 0; k < d; ++k) {
-                const double t = xi[li * d + k] - xj[tx * d + k];
-                r += hp.il2[k] * (t * t);
-            }
+#pragma unroll
+            for (int k = 0; k < DT; ++k)
+                if (k < d) {
+                    const double t = xi[k] - xj[k];
+                    r += hp.il2[k] * (t * t);
+                }
             v = cov_from_r(hp.kern, hp.sigma2, r);
-            if (gi == gj) v += noise;
+            if (i == j) v += noise;
         } else {
-            v = (gi == gj) ? 1.0 : 0.0;
+            v = (i == j) ? 1.0 : 0.0;
         }
-        if (gi < Npad && gj < Npad) K[gi * ld + gj] = v;
+        K[i * ld + j] = v;
     }
 }
 
@@ -407,18 +404,33 @@ __global__ __launch_bounds__(256) void k_trimv(const double* __restrict__ W, int
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if (lane == 0) t[i] = s;
 }
-// a[j] = sum_{i>=j} W[i][j] t[i] : block = 64 columns x 4 row-strides, coalesced along j.
-__global__ __launch_bounds__(256) void k_trimv_t(const double* __restrict__ W, int64_t ld, int64_t N,
-                                                 const double* __restrict__ t, double* __restrict__ a) {
+// a[j] = sum_{i>=j} W[i][j] t[i].  Stage 1: block = 64 columns x 4 row phases over one of `nsplit` row
+// slices -> part[slice][j]; stage 2 sums the slices in index order (bit-deterministic).
+__global__ __launch_bounds__(256) void k_trimv_t_part(const double* __restrict__ W, int64_t ld, int64_t N,
+                                                      const double* __restrict__ t, int nsplit,
+                                                      double* __restrict__ part, int64_t ldp) {
     __shared__ double red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int64_t j = blockIdx.x * 64 + tx;
+    const int64_t span = (N + nsplit - 1) / nsplit;
+    const int64_t i_lo = (int64_t)blockIdx.y * span, i_hi = min(N, i_lo + span);
     double s = 0.0;
-    if (j < N)
-        for (int64_t i = j + ty; i < N; i += 4) s += W[i * ld + j] * t[i];
+    if (j < N) {
+        int64_t i = max(i_lo, j);
+        i += (ty - (i & 3) + 4) & 3;  // align the row phase so the summation order does not depend on j
+        for (; i < i_hi; i += 4) s += W[i * ld + j] * t[i];
+    }
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && j < N) a[j] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+    if (ty == 0 && j < N) part[(int64_t)blockIdx.y * ldp + j] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+}
+__global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ part, int64_t ldp, int nsplit, int64_t N,
+                                                   double* __restrict__ out) {
+    const int64_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    double s = 0.0;
+    for (int q = 0; q < nsplit; ++q) s += part[(int64_t)q * ldp + j];
+    out[j] = s;
 }
 // mll = -0.5 r'alpha - sum log L_ii - N/2 log(2 pi)   (single workgroup, fixed order)
 __global__ __launch_bounds__(256) void k_mll(const double* __restrict__ L, int64_t ld, int64_t N,
