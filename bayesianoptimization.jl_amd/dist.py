@@ -33,12 +33,12 @@ def reduce_best(vals, idxs):
     return best_v, best_i
 
 
-def allgather_best(rec, offset, world):
+def allgather_best(rec, offset, world, force_collective=False):
     """rec: int64[2] tensor holding (value bits, local index) on this rank's device.
     Returns the global (value, index) on every rank."""
     import torch
 
-    if world == 1:
+    if world == 1 and not force_collective:
         h = rec.cpu().numpy()
         v = float(h[:1].view(np.float64)[0])
         return (v, int(h[1])) if h[1] >= 0 else (-math.inf, -1)

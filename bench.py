@@ -104,8 +104,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libbohip has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("BOHIP_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import bohip
@@ -139,14 +143,14 @@ def main():
     def step():
         _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()),
                                           R_PER_GPU, None, C.c_void_p(d_best.data_ptr())))
-        val, idx = allgather_best(d_best, lo, world)  # RCCL all_gather of 16 B/rank + identical local reduce
+        val, idx = allgather_best(d_best, lo, world, force_collective=use_dist)  # RCCL all_gather of 16 B/rank + local reduce
         _lib.check(lib.bohip_gp_synchronize(model._h))
         return val, idx
 
     for _ in range(args.warmup):
         step()
     stage_sum = {}
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -155,10 +159,10 @@ def main():
         for name, ms in model.timing():
             stage_sum[name] = stage_sum.get(name, 0.0) + ms
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -196,7 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, y, Xs_all, tau)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
