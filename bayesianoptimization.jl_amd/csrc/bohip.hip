@@ -166,6 +166,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 // ---- GEMM launcher --------------------------------------------------------------------------------
 static constexpr int GEMM_LDS_BYTES_N64 = (2 * TILE_LDS_DOUBLES + 2 * 64 * LDSROW) * 8;  // 55296 B
 static int g_cand_tile = 64;
+static int g_reg_staging = 0;
 static int launch_gemm(bohip_gp* g, bool b_nmajor, const GemmParams& p, int batch) {
     const int tiles = p.lower_tiles ? p.mt * (p.mt + 1) / 2 : p.mt * p.nt;
     if (tiles <= 0 || batch <= 0 || p.kc <= 0) return 0;
@@ -181,12 +182,16 @@ static int launch_gemm(bohip_gp* g, bool b_nmajor, const GemmParams& p, int batc
 static int one_time_kernel_setup() {
     static bool done = false;
     if (done) return 0;
-    if (const char* e = getenv("BOHIP_CAND_TILE")) g_cand_tile = atoi(e) == 128 ? 128 : 64;
+    if (const char* e = getenv("BOHIP_REG_STAGING")) g_reg_staging = atoi(e);
+    if (const char* e = getenv("BOHIP_CAND_TILE")) g_cand_tile = atoi(e) == 128 ? 128 : (atoi(e) == 96 ? 96 : 64);
     HIPCHK(hipFuncSetAttribute((const void*)k_potf2_inv, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<6>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<6>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return 0;
 }
@@ -365,22 +370,23 @@ static int ensure_score_scratch(bohip_gp* g, int64_t R) {
     const int64_t Rpad = round_up(std::max<int64_t>(R, 1), TILE);
     const int64_t T = g->ld / TILE;
     const int64_t rc = std::min(chunk_rows(g), Rpad);
+    const int64_t SLACK = TILE;  // 96-wide candidate tiles may overrun a 128-rounded count by < 128 columns
     if (g->kst_rows < rc || g->dKsT == nullptr) {
         if (g->dKsT) hipFree(g->dKsT);
         g->dKsT = nullptr;
-        HIPCHK(hipMalloc(&g->dKsT, (size_t)rc * g->ld * 8));
+        HIPCHK(hipMalloc(&g->dKsT, (size_t)(rc + SLACK) * g->ld * 8));
         g->kst_rows = rc;
     }
-    if (g->q_cap < T * Rpad) {
+    if (g->q_cap < T * (Rpad + SLACK)) {
         if (g->dq) hipFree(g->dq);
         g->dq = nullptr;
-        HIPCHK(hipMalloc(&g->dq, (size_t)T * Rpad * 8));
-        g->q_cap = T * Rpad;
+        HIPCHK(hipMalloc(&g->dq, (size_t)(T * (Rpad + SLACK)) * 8));
+        g->q_cap = T * (Rpad + SLACK);
     }
     if (g->r_cap < Rpad) {
         for (double** p : {&g->dmu_raw, &g->dmu, &g->dvar, &g->dscore})
             if (*p) { hipFree(*p); *p = nullptr; }
-        HIPCHK(hipMalloc(&g->dmu_raw, Rpad * 8));
+        HIPCHK(hipMalloc(&g->dmu_raw, (Rpad + SLACK) * 8));
         HIPCHK(hipMalloc(&g->dmu, Rpad * 8));
         HIPCHK(hipMalloc(&g->dvar, Rpad * 8));
         HIPCHK(hipMalloc(&g->dscore, Rpad * 8));
@@ -427,9 +433,21 @@ static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1,
 // by the K extent (row tile), so halving the tile width halves the longest job and lets heaviest-first
 // list scheduling balance the 2 x 256 workgroup slots (128-wide tiles: makespan 24 units vs 18.75 average).
 static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t Rpad, int64_t r0, double* VT) {
-    if (g_cand_tile == 64) {
+    if (g_cand_tile == 96) {
+        const int CT = (int)((ncand + 95) / 96), n_local = (CT + 7) / 8;
+        hipLaunchKernelGGL(k_trigemm_sq<6>, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<6>(), g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+    } else if (g_cand_tile == 64 && g_reg_staging) {
         const int CT = (int)((ncand + 63) / 64), n_local = (CT + 7) / 8;
-        hipLaunchKernelGGL(k_trigemm_sq<4>, dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES_N64, g->stream, g->dW,
+        hipLaunchKernelGGL((k_trigemm_sq<4, 0>), dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES_N64, g->stream,
+                           g->dW, g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+    } else if (g_cand_tile == 64 && g_reg_staging == 2) {
+        const int CT = (int)((ncand + 63) / 64), n_local = (CT + 7) / 8;
+        hipLaunchKernelGGL((k_trigemm_sq<4, 1>), dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES_N64, g->stream,
+                           g->dW, g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+    } else if (g_cand_tile == 64) {
+        const int CT = (int)((ncand + 63) / 64), n_local = (CT + 7) / 8;
+        hipLaunchKernelGGL(k_trigemm_sq<4>, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, g->dW,
                            g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
     } else {
         const int CT = (int)((ncand + TILE - 1) / TILE), n_local = (CT + 7) / 8;
@@ -443,7 +461,7 @@ static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t 
 // posterior pass over all R candidates: fills dq (partials) and dmu_raw.  VT optional (chunk-local).
 static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
     CHK(one_time_kernel_setup());
-    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE);
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: 96-wide tile overrun
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
     const int64_t rc = g->kst_rows;
@@ -478,7 +496,7 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
         return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
     }
-    const int64_t Npad = round_up(g->n + 1, TILE), Rpad = round_up(R, TILE);
+    const int64_t Npad = round_up(g->n + 1, TILE), Rpad = round_up(R, TILE) + TILE;
     const int T = (int)(Npad / TILE);
     const int nb = (int)((R + 255) / 256);
     t_begin(g, "score");
@@ -513,7 +531,7 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
         return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
     }
-    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE);
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: 96-wide tile overrun
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
     const int64_t rc = g->kst_rows;

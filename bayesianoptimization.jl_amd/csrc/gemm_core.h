@@ -148,6 +148,184 @@ __device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ A, int
     }
 }
 
+// ================================================================================================
+// LDS-DMA variant (K-major operands): global_load_lds_dwordx4 writes the tiles straight into LDS, so the
+// staging costs no VGPRs, no ds_write instructions and no vmcnt wait inside the wave's instruction
+// stream (only the vmcnt(0) that __syncthreads() carries).  The DMA destination is wave-uniform base +
+// lane*16 B, i.e. rows are exactly 128 B with no padding, so bank conflicts are removed by an XOR swizzle
+// of the 16-B segment index with (row & 7), applied on the SOURCE address (which segment a lane fetches)
+// and again on the fragment reads:   LDS[row][p] holds global segment p ^ (row & 7).
+// Fragment read of (row, col): bank pair = 32*(row&1) + 4*((col>>1) ^ (row&7)) + 2*(col&1) (mod 64) is
+// distinct over the 8 rows x 2 columns a 32-lane half touches -> conflict-free.
+// ================================================================================================
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+constexpr int GL_ROW = KC;  // 16 doubles = 128 B, unpadded
+
+template <int NQ>  // NQ * 32 rows
+__device__ __forceinline__ void glds_tile(const double* __restrict__ src_lane, int64_t ld, double* dst_wave) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src_lane + (int64_t)q * 32 * ld),
+                                         (lds_void_ptr)(dst_wave + q * 32 * GL_ROW), 16, 0, 0);
+}
+
+// Fragment reads as ds_read_b128: lane-group kq = lane>>4 reads the 16-B segment 4S + kq of its row, i.e.
+// the contraction-index PAIR (8S + 2kq, 8S + 2kq + 1); the first MFMA of a pair consumes the even member,
+// the second the odd one (A and B agree, and any permutation of the contraction index is legal).
+// b128 moves 256 B/clk against 128 B/clk for the ds_read2_b64 hipcc fuses two b64 reads into, halving the
+// LDS time of the fragment traffic that competes with the DMA writes.  Swizzled slot = (8*(row&1) +
+// (seg ^ (row&7))) mod 16 is distinct over each 16-lane service group -> conflict-free.
+template <int NJ>
+__device__ __forceinline__ void load_frags_swz(const double* ap, const double* bp, const int (&oa)[2], const int (&ob)[2],
+                                               int S, d2 (&av)[8], d2 (&bv)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const d2*>(ap + i * 8 * GL_ROW + oa[S]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const d2*>(bp + j * 8 * GL_ROW + ob[S]);
+}
+template <int NJ>
+__device__ __forceinline__ void mma_pair(const d2 (&av)[8], const d2 (&bv)[NJ], double (&acc)[8][NJ]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma444(av[i].x, bv[j].x, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma444(av[i].y, bv[j].y, acc[i][j]);
+}
+
+template <int NJ>
+__device__ __forceinline__ void mma_chunk_swz(const double* ap, const double* bp, const int (&oa)[2], const int (&ob)[2],
+                                              double (&acc)[8][NJ]) {
+    d2 a0[8], b0[NJ], a1[8], b1[NJ];
+    load_frags_swz<NJ>(ap, bp, oa, ob, 0, a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags_swz<NJ>(ap, bp, oa, ob, 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_pair<NJ>(a0, b0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_pair<NJ>(a1, b1, acc);
+}
+
+template <int NJ>
+constexpr int glds_lds_bytes() { return 2 * (TILE + 16 * NJ) * GL_ROW * 8; }
+
+template <int NJ>
+__device__ __forceinline__ void gemm_tile_loop_glds(const double* __restrict__ A, int64_t lda,
+                                                    const double* __restrict__ B, int64_t ldb, int kc_begin,
+                                                    int kc_end, double* smem, double (&acc)[8][NJ],
+                                                    int active_rows = TILE) {
+    // active_rows: rows of the A tile at or beyond it are structural padding; a wave whose 64 rows are all
+    // padding still stages and synchronises but issues no MFMAs (wave-uniform branch).
+    constexpr int BQ = NJ / 2;
+    constexpr int AT = TILE * GL_ROW, BT = 16 * NJ * GL_ROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    double* As = smem;             // [2][128][16]
+    double* Bs = smem + 2 * AT;    // [2][16*NJ][16]
+    if (kc_begin >= kc_end) return;
+    // DMA source of this lane: row (wave*8 + lane/8) of each 32-row pass, segment (lane%8) ^ (row%8)
+    const int srow = wave * 8 + (lane >> 3), sseg = (lane & 7) ^ (lane >> 3);
+    const double* a_src = A + (int64_t)srow * lda + sseg * 2;
+    const double* b_src = B + (int64_t)srow * ldb + sseg * 2;
+    double* a_dst = As + wave * 8 * GL_ROW;  // wave-uniform
+    double* b_dst = Bs + wave * 8 * GL_ROW;
+    // fragment addressing
+    const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
+    const int r7a = 4 * (b >> 1) + t, r7b = 4 * (b & 1) + t;
+    int oa[2], ob[2];
+#pragma unroll
+    for (int S = 0; S < 2; ++S) {
+        oa[S] = ((4 * S + k) ^ r7a) << 1;
+        ob[S] = ((4 * S + k) ^ r7b) << 1;
+    }
+    const int a_frag = (wr * 64 + r7a) * GL_ROW, b_frag = (wc * 8 * NJ + r7b) * GL_ROW;
+    glds_tile<4>(a_src + (int64_t)kc_begin * KC, lda, a_dst);
+    glds_tile<BQ>(b_src + (int64_t)kc_begin * KC, ldb, b_dst);
+    __syncthreads();
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int cur = (kc - kc_begin) & 1;
+        if (kc + 1 < kc_end) {
+            glds_tile<4>(a_src + (int64_t)(kc + 1) * KC, lda, a_dst + (cur ^ 1) * AT);
+            glds_tile<BQ>(b_src + (int64_t)(kc + 1) * KC, ldb, b_dst + (cur ^ 1) * BT);
+        }
+        if (wr * 64 < active_rows) mma_chunk_swz<NJ>(As + cur * AT + a_frag, Bs + cur * BT + b_frag, oa, ob, acc);
+        __syncthreads();
+    }
+}
+
+// ---- LDS-DMA with THREE buffers: two chunks in flight ------------------------------------------
+// With two buffers the DMA of chunk c+1 has exactly one chunk of MFMA time (~1 us) to land, and
+// __syncthreads() drains it with vmcnt(0).  Measured on this kernel: removing the staging altogether is
+// 15 % faster while removing 4 % of the MFMAs changes nothing -> the loop is bound by load latency x
+// bytes in flight per CU, not by the matrix pipe.  Three buffers + a COUNTED s_waitcnt vmcnt(n) + a raw
+// s_barrier keep the DMA of chunk c+2 in flight across the barrier (2 chunks of latency tolerance).
+template <int NJ>
+__device__ __forceinline__ void wait_all_but_one_chunk() {
+    static_assert(NJ == 4 || NJ == 6 || NJ == 8, "glds count per chunk = 4 + NJ/2");
+    if constexpr (NJ == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (NJ == 6) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if constexpr (NJ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+template <int NJ>
+constexpr int glds3_lds_bytes() { return 3 * (TILE + 16 * NJ) * GL_ROW * 8; }
+
+template <int NJ>
+__device__ __forceinline__ void gemm_tile_loop_glds3(const double* __restrict__ A, int64_t lda,
+                                                     const double* __restrict__ B, int64_t ldb, int kc_begin,
+                                                     int kc_end, double* smem, double (&acc)[8][NJ],
+                                                     int active_rows = TILE) {
+    constexpr int BQ = NJ / 2;
+    constexpr int AT = TILE * GL_ROW, BT = 16 * NJ * GL_ROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    double* As = smem;             // [3][128][16]
+    double* Bs = smem + 3 * AT;    // [3][16*NJ][16]
+    if (kc_begin >= kc_end) return;
+    const int srow = wave * 8 + (lane >> 3), sseg = (lane & 7) ^ (lane >> 3);
+    const double* a_src = A + (int64_t)srow * lda + sseg * 2;
+    const double* b_src = B + (int64_t)srow * ldb + sseg * 2;
+    double* a_dst = As + wave * 8 * GL_ROW;
+    double* b_dst = Bs + wave * 8 * GL_ROW;
+    const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
+    const int r7a = 4 * (b >> 1) + t, r7b = 4 * (b & 1) + t;
+    int oa[2], ob[2];
+#pragma unroll
+    for (int S = 0; S < 2; ++S) {
+        oa[S] = ((4 * S + k) ^ r7a) << 1;
+        ob[S] = ((4 * S + k) ^ r7b) << 1;
+    }
+    const int a_frag = (wr * 64 + r7a) * GL_ROW, b_frag = (wc * 8 * NJ + r7b) * GL_ROW;
+    const bool wave_active = wr * 64 < active_rows;
+    glds_tile<4>(a_src + (int64_t)kc_begin * KC, lda, a_dst);
+    glds_tile<BQ>(b_src + (int64_t)kc_begin * KC, ldb, b_dst);
+    if (kc_begin + 1 < kc_end) {
+        glds_tile<4>(a_src + (int64_t)(kc_begin + 1) * KC, lda, a_dst + AT);
+        glds_tile<BQ>(b_src + (int64_t)(kc_begin + 1) * KC, ldb, b_dst + BT);
+        wait_all_but_one_chunk<NJ>();
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int nxt2 = cur == 0 ? 2 : cur - 1;  // (cur + 2) % 3
+        const bool more2 = kc + 2 < kc_end;
+        if (more2) {
+            glds_tile<4>(a_src + (int64_t)(kc + 2) * KC, lda, a_dst + nxt2 * AT);
+            glds_tile<BQ>(b_src + (int64_t)(kc + 2) * KC, ldb, b_dst + nxt2 * BT);
+        }
+        if (wave_active) mma_chunk_swz<NJ>(As + cur * AT + a_frag, Bs + cur * BT + b_frag, oa, ob, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) wait_all_but_one_chunk<NJ>();           // chunk kc+1 has landed, chunk kc+2 stays in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+}
+
 // Where this lane's accumulator acc[mi][nj] lives inside the 128 x 128 workgroup tile.
 __device__ __forceinline__ int acc_row(int lane, int wr, int mi) {
     return wr * 64 + 8 * mi + 4 * (((lane >> 2) & 3) >> 1) + (lane >> 4);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ X, int
 // Output: q_part[rt][r] = sum over the tile's rows of v^2 (fixed summation order -> deterministic),
 //         mu_raw[r] = alpha' k*_r taken from the row of W that stores alpha (alpha_row).
 // ------------------------------------------------------------------------------------------------
-template <int NJ>  // candidate tile width CW = 16 * NJ (128 or 64)
+template <int NJ, int STAGING = (NJ != 8 ? 2 : 0)>  // STAGING: 0 registers, 1 LDS-DMA x2 buffers, 2 LDS-DMA x3 buffers  // candidate tile width CW = 16 * NJ (128, 96 or 64); LDS-DMA or register staging
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
                                                                 const double* __restrict__ KsT, int64_t ldk,
                                                                 int T, int CT, int64_t alpha_row,
@@ -79,10 +79,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0;
-    gemm_tile_loop<false, NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
-                              (rt + 1) * (TILE / KC), smem, acc);
+    if constexpr (STAGING == 2)
+        gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+                                 (rt + 1) * (TILE / KC), smem, acc,
+                                 (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE));
+    else if constexpr (STAGING == 1)
+        gemm_tile_loop_glds<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+                                (rt + 1) * (TILE / KC), smem, acc,
+                                (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE));  // rows past alpha' are padding
+    else
+        gemm_tile_loop<false, NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+                                  (rt + 1) * (TILE / KC), smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-    double* red = smem;  // [2][CW]; safe: gemm_tile_loop ends with a barrier
+    __syncthreads();     // (the raw-barrier loops end on s_barrier; make the reuse of smem below explicit)
+    double* red = smem;  // [2][CW]
     const int64_t row_base = (int64_t)rt * TILE;
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
