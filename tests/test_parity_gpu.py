@@ -324,6 +324,64 @@ def test_full_size_c2_properties(bohip, orc):
     assert np.all(np.abs(mu[sel] - mu_o) <= 1e-6 * np.abs(mu_o) + mu_floor(alpha, 1.0))
 
 
+def test_candidate_chunking_is_invisible(bohip, orc):
+    """R larger than one K*' chunk (8192 rows at this N): chunk boundaries, 64-wide tile padding and the per-chunk
+    gradient buffers must not show in the results."""
+    X, y, Xs = synth(200, 3, 20011, seed=17)
+    ll = np.array([-0.4, -0.9, -0.1])
+    L, alpha = orc.fit(X, y, ll, 0.0, -2.0, 0.1)
+    m = make_model(bohip, X, y, ll, 0.0, -2.0, 0.1)
+    tau = float(y.max())
+    sc_o, bv_o, bi_o = orc.score(X, ll, 0.0, 0.1, L, alpha, "EI", [tau], Xs, nthreads=8)
+    sc, bv, bi = m.score("EI", [tau], Xs.T)
+    check_scores(sc, sc_o, mu_floor(alpha, 1.0) + 1e-13)
+    assert bi == bi_o and sc[bi] == bv
+    for lo, hi in [(0, 8192), (8100, 8300), (16384, 20011)]:                  # any sub-batch reproduces its slice bit-for-bit
+        np.testing.assert_array_equal(m.score("EI", [tau], Xs[lo:hi].T)[0], sc[lo:hi])
+    sg, g = m.score_grad("EI", [tau], Xs.T)
+    np.testing.assert_array_equal(sg, sc)
+    _, g_o = orc.score_grad(X, ll, 0.0, 0.1, L, alpha, "EI", [tau], Xs[8000:8400])
+    np.testing.assert_allclose(g[:, 8000:8400].T, g_o, rtol=1e-6, atol=1e-9 * np.abs(g_o).max())
+    bvs, bis = m.thompson(Xs.T, 4, seed=3)
+    mu, var = m.predict_f(Xs.T)
+    from bohip import _lib
+    lib = _lib.load()
+    for s_ in range(4):
+        f = mu[bis[s_]] + math.sqrt(var[bis[s_]]) * lib.bohip_thompson_normal(3, s_, int(bis[s_]))
+        assert f == pytest.approx(bvs[s_], rel=1e-12)
+
+
+def test_full_size_c4_properties(bohip, orc):
+    """BASELINE configs[3]: N=10000, d=16 (blocked-Cholesky path).  An O(N^3) CPU factorisation is out of reach
+    for a test, so the factor is pinned by L L' = cK on sampled rows, W by L-solves against the oracle's
+    substitution on the SAME factor, and the scoring path by the oracle's predict on a candidate sample."""
+    from oracle.oracle import np_cov
+
+    N, d, R = 10000, 16, 640
+    X, y, Xs = synth(N, d, R, seed=4)
+    ll = np.full(d, math.log(0.7))
+    m = make_model(bohip, X, y, ll, 0.0, -2.0, 0.0)
+    Lg = m.factor()
+    assert np.all(np.diag(Lg) > 0) and np.all(np.triu(Lg, 1) == 0)
+    rows = np.random.default_rng(1).choice(N, 16, replace=False)
+    cK_rows = np_cov("SEArd", X[rows], X, ll, 0.0)
+    cK_rows[np.arange(16), rows] += math.exp(-4.0) + EPS
+    np.testing.assert_allclose(Lg[rows] @ Lg.T, cK_rows, rtol=0, atol=2e-11)
+    alpha = m.alpha()
+    np.testing.assert_allclose(Lg @ (Lg.T @ alpha), y, rtol=0, atol=1e-8)          # cK alpha = y - beta
+    tau = float(y.max())
+    sc, bv, bi = m.score("EI", [tau], Xs.T)
+    mu, var = m.predict_f(Xs.T)
+    assert bi == int(np.argmax(sc)) and np.all(var >= 0) and np.all(var <= 1 + 1e-12)
+    sel = np.unique(np.concatenate([[bi], np.arange(0, R, 40)]))
+    mu_o, var_o = orc.predict(X, ll, 0.0, 0.0, Lg, alpha, Xs[sel], nthreads=8)      # substitution on the same factor
+    assert np.all(np.abs(mu[sel] - mu_o) <= 1e-6 * np.abs(mu_o) + mu_floor(alpha, 1.0))
+    assert np.all(np.abs(var[sel] - var_o) <= var_tol(var_o, N, 1.0))
+    sc_o, _, _ = orc.score(X, ll, 0.0, 0.0, Lg, alpha, "EI", [tau], Xs[sel], nthreads=8)
+    check_scores(sc[sel], sc_o, mu_floor(alpha, 1.0) + var_tol(var_o, N, 1.0, rel=0) + 1e-13)
+    np.testing.assert_array_equal(sc, m.score("EI", [tau], Xs.T)[0])               # deterministic
+
+
 def test_device_resident_entry_point_matches_host_entry_point(bohip):
     torch = pytest.importorskip("torch")
     from bohip import _lib
