@@ -179,6 +179,13 @@ static int launch_gemm(bohip_gp* g, bool b_nmajor, const GemmParams& p, int batc
     return 0;
 }
 
+static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p) {
+    if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0) return 0;
+    hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, p);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int one_time_kernel_setup() {
     static bool done = false;
     if (done) return 0;
@@ -186,6 +193,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CAND_TILE")) g_cand_tile = atoi(e) == 128 ? 128 : (atoi(e) == 96 ? 96 : 64);
     HIPCHK(hipFuncSetAttribute((const void*)k_potf2_inv, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
@@ -249,26 +257,50 @@ static int refit(bohip_gp* g) {
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "cholesky");
-    for (int kb = 0; kb < T; ++kb) {
-        double* Lkk = g->dL + (int64_t)kb * TILE * (ld + 1);
-        double* Wkk = g->dW + (int64_t)kb * TILE * (ld + 1);
-        hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, Lkk, ld, Wkk, ld, g->dinfo,
-                           kb * TILE);
+    // Right-looking on 128-column panels, with the trailing update applied in two tiers: inside an outer block
+    // of OB panels only the block's own remaining columns are updated after every panel (K = 128); everything to
+    // the right of the outer block is updated ONCE per outer block with K = 128 * OB.  The C tiles of the bulk
+    // are therefore read-modified-written T/OB times instead of T times and the bulk contraction is OB x deeper.
+    const int OB = 4;
+    for (int ob = 0; ob < T; ob += OB) {
+        const int oe = std::min(T, ob + OB);
+        for (int kb = ob; kb < oe; ++kb) {
+            double* Lkk = g->dL + (int64_t)kb * TILE * (ld + 1);
+            double* Wkk = g->dW + (int64_t)kb * TILE * (ld + 1);
+            hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, Lkk, ld, Wkk, ld,
+                               g->dinfo, kb * TILE);
+            HIPCHK(hipGetLastError());
+            const int rem = T - kb - 1;
+            if (rem == 0) break;
+            const int64_t poff = (int64_t)(kb + 1) * TILE * ld + (int64_t)kb * TILE;
+            double* panel = g->dS + poff;  // solved panel L[kb+1:, kb] lives in the scratch matrix until the final copy
+            GemmNTParams p{};  // panel solve L[i,kb] = A[i,kb] * inv(L_kk)'   (out of place: dL -> dS)
+            p.A = g->dL + poff; p.lda = ld; p.B = Wkk; p.ldb = ld; p.C = panel; p.ldc = ld;
+            p.mt = rem; p.nt64 = 2; p.kc = TILE / KC; p.alpha = 1.0; p.beta = 0.0;
+            CHK(launch_gemm_nt(g, p));
+            const int inner_cols = oe - kb - 1;  // remaining panels of this outer block
+            if (inner_cols > 0) {
+                GemmNTParams u{};  // A[i, j] -= L[i,kb] L[j,kb]'  for j in (kb, oe), i >= j
+                u.A = panel; u.lda = ld; u.B = panel; u.ldb = ld;
+                u.C = g->dL + (int64_t)(kb + 1) * TILE * (ld + 1); u.ldc = ld;
+                u.mt = rem; u.nt64 = 2 * inner_cols; u.kc = TILE / KC; u.alpha = -1.0; u.beta = 1.0;
+                u.diag_skip = 1; u.row0 = (int64_t)(kb + 1) * TILE; u.col0 = (int64_t)(kb + 1) * TILE;
+                CHK(launch_gemm_nt(g, u));
+            }
+        }
+        const int rem = T - oe;
+        if (rem > 0) {
+            GemmNTParams b{};  // bulk: A[i, j] -= L[i, ob:oe] L[j, ob:oe]'  for i >= j >= oe
+            b.A = g->dS + (int64_t)oe * TILE * ld + (int64_t)ob * TILE; b.lda = ld; b.B = b.A; b.ldb = ld;
+            b.C = g->dL + (int64_t)oe * TILE * (ld + 1); b.ldc = ld;
+            b.mt = rem; b.nt64 = 2 * rem; b.kc = (oe - ob) * (TILE / KC); b.alpha = -1.0; b.beta = 1.0;
+            b.diag_skip = 1; b.row0 = (int64_t)oe * TILE; b.col0 = (int64_t)oe * TILE;
+            CHK(launch_gemm_nt(g, b));
+        }
+    }
+    if (T > 1) {
+        hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
         HIPCHK(hipGetLastError());
-        const int rem = T - kb - 1;
-        if (rem == 0) break;
-        GemmParams p{};
-        double* panel = g->dL + (int64_t)(kb + 1) * TILE * ld + (int64_t)kb * TILE;
-        // panel solve  L[i,kb] = A[i,kb] * inv(L_kk)'   (in place: each tile reads only its own rows)
-        p.A = panel; p.lda = ld; p.B = Wkk; p.ldb = ld; p.C = panel; p.ldc = ld;
-        p.mt = rem; p.nt = 1; p.kc = TILE / KC; p.alpha = 1.0; p.beta = 0.0;
-        CHK(launch_gemm(g, false, p, 1));
-        // trailing update  A[i,j] -= L[i,kb] L[j,kb]'  on lower tiles
-        GemmParams s{};
-        s.A = panel; s.lda = ld; s.B = panel; s.ldb = ld;
-        s.C = g->dL + (int64_t)(kb + 1) * TILE * (ld + 1); s.ldc = ld;
-        s.mt = rem; s.nt = rem; s.kc = TILE / KC; s.alpha = -1.0; s.beta = 1.0; s.lower_tiles = 1;
-        CHK(launch_gemm(g, false, s, 1));
     }
     t_end(g);
     // W = L^-1 by recursive doubling over diagonal blocks:

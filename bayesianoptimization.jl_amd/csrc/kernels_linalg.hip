@@ -383,6 +383,68 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(GemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// C = alpha * A * B' + beta * C with both operands K-major, on the LDS-DMA engine of the scoring kernel
+// (128 x 64 tiles, 3 LDS buffers, counted vmcnt).  Used by the factorisation: panel solve (B = inverse
+// diagonal block) and trailing updates.  `diag_skip`: tiles strictly above the block diagonal of the
+// GLOBAL matrix are skipped: tile (ti, tj64) is kept iff col0 + 64 tj64 < row0 + 128 (ti + 1)  (row0/col0 =
+// global offsets of C in elements), so rectangular panels that straddle the diagonal need no special grid.
+// ------------------------------------------------------------------------------------------------
+struct GemmNTParams {
+    const double* A;
+    const double* B;
+    double* C;
+    int64_t lda, ldb, ldc;
+    int mt, nt64, kc;
+    double alpha, beta;
+    int diag_skip;
+    int64_t row0, col0;
+};
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_nt(GemmNTParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // heaviest-first is irrelevant here (uniform K); deal blocks to XCDs so that one XCD owns a strip of rows
+    const int ti = blockIdx.x / p.nt64, tj = blockIdx.x % p.nt64;
+    if (p.diag_skip && p.col0 + 64 * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) return;
+    double acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    gemm_tile_loop_glds3<4>(p.A + (int64_t)ti * TILE * p.lda, p.lda, p.B + (int64_t)tj * 64 * p.ldb, p.ldb, 0, p.kc, smem, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    double* C = p.C + (int64_t)ti * TILE * p.ldc + (int64_t)tj * 64;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int r = acc_row(lane, wr, mi);
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) {
+            double* dst = C + (int64_t)r * p.ldc + acc_col<4>(lane, wc, nj);
+            double v = p.alpha * acc[mi][nj];
+            if (p.beta != 0.0) v += p.beta * *dst;
+            *dst = v;
+        }
+    }
+}
+
+// dst[i][j] = src[i][j] on every 128-tile strictly below the diagonal tiles (the factorisation parks the solved
+// panels in the scratch matrix so the panel solve never runs in place; this moves them home in one pass).
+__global__ __launch_bounds__(256) void k_copy_offdiag_tiles(const double* __restrict__ src, double* __restrict__ dst,
+                                                            int64_t ld, int T) {
+    const int b = blockIdx.x;  // strictly-lower tile index: (ti, tj), ti > tj
+    int ti = (int)((sqrt(8.0 * b + 1.0) + 1.0) * 0.5);
+    while (ti * (ti - 1) / 2 > b) --ti;
+    while ((ti + 1) * ti / 2 <= b) ++ti;
+    const int tj = b - ti * (ti - 1) / 2;
+    if (ti >= T) return;
+    const d2* s2 = reinterpret_cast<const d2*>(src + (int64_t)ti * TILE * ld + (int64_t)tj * TILE);
+    d2* t2 = reinterpret_cast<d2*>(dst + (int64_t)ti * TILE * ld + (int64_t)tj * TILE);
+    for (int e = threadIdx.x; e < TILE * TILE / 2; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        t2[(int64_t)r * (ld / 2) + c] = s2[(int64_t)r * (ld / 2) + c];
+    }
+}
+
 template __global__ void k_gemm<false>(GemmParams);
 template __global__ void k_gemm<true>(GemmParams);
 
