@@ -8,7 +8,8 @@
 //                   read column-major); strict-upper tiles stay zero; rows/cols >= N identity padding
 //   dW  [ld][ld]    W = L^-1 (lower).  Row N (first padding row) carries alpha' so the scoring
 //                   contraction V = W K* also produces mu - beta.
-//   dS  [ld][ld]    scratch for the recursive triangular inverse
+//   dWT [ld][ld]    W' (upper): lets every contraction run in the K-major x K-major form of the MFMA engine
+//   dS  [ld][ld]    scratch: solved panels during the factorisation, S' blocks during the recursive inverse
 //   dKsT [Rc][ld]   cross-covariance chunk, candidate-major
 // There is NO CPU fallback: every entry point that computes fails with BOHIP_E_NODEVICE / BOHIP_E_HIP
 // when the GPU is unavailable.
@@ -56,7 +57,7 @@ struct StageTimer {
 struct bohip_gp {
     int device = 0, d = 0, kern = 0;
     int64_t n = 0, cap = 0, ld = 0;
-    double *dX = nullptr, *dy = nullptr, *dL = nullptr, *dW = nullptr, *dS = nullptr;
+    double *dX = nullptr, *dy = nullptr, *dL = nullptr, *dW = nullptr, *dWT = nullptr, *dS = nullptr;
     double *dalpha = nullptr, *dr = nullptr, *dt = nullptr, *dmll = nullptr;
     double* dApp = nullptr;  // [APP_ROWS][ld] scratch of the incremental append
     int* dinfo = nullptr;
@@ -128,7 +129,7 @@ static void t_collect(bohip_gp* g) {
 
 // ---- allocation -----------------------------------------------------------------------------------
 static int free_model(bohip_gp* g) {
-    for (double** p : {&g->dX, &g->dy, &g->dL, &g->dW, &g->dS, &g->dalpha, &g->dr, &g->dt, &g->dApp})
+    for (double** p : {&g->dX, &g->dy, &g->dL, &g->dW, &g->dWT, &g->dS, &g->dalpha, &g->dr, &g->dt, &g->dApp})
         if (*p) { hipFree(*p); *p = nullptr; }
     return 0;
 }
@@ -147,6 +148,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
     HIPCHK(hipMalloc(&g->dy, std::max<size_t>(8, (size_t)cap * 8)));
     HIPCHK(hipMalloc(&g->dL, mat));
     HIPCHK(hipMalloc(&g->dW, mat));
+    HIPCHK(hipMalloc(&g->dWT, mat));
     HIPCHK(hipMalloc(&g->dS, mat));
     HIPCHK(hipMalloc(&g->dalpha, g->ld * 8));
     HIPCHK(hipMalloc(&g->dr, g->ld * 8));
@@ -154,6 +156,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
     HIPCHK(hipMalloc(&g->dApp, (size_t)APP_ROWS * g->ld * 8));
     HIPCHK(hipMemsetAsync(g->dL, 0, mat, g->stream));
     HIPCHK(hipMemsetAsync(g->dW, 0, mat, g->stream));
+    HIPCHK(hipMemsetAsync(g->dWT, 0, mat, g->stream));
     HIPCHK(hipMemsetAsync(g->dS, 0, mat, g->stream));
     if (g->n > 0) {
         HIPCHK(hipMemcpyAsync(g->dX, g->hX.data(), (size_t)g->n * g->d * 8, hipMemcpyHostToDevice, g->stream));
@@ -164,24 +167,9 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 }
 
 // ---- GEMM launcher --------------------------------------------------------------------------------
-static constexpr int GEMM_LDS_BYTES_N64 = (2 * TILE_LDS_DOUBLES + 2 * 64 * LDSROW) * 8;  // 55296 B
-static int g_cand_tile = 64;
-static int g_reg_staging = 0;
-static int launch_gemm(bohip_gp* g, bool b_nmajor, const GemmParams& p, int batch) {
-    const int tiles = p.lower_tiles ? p.mt * (p.mt + 1) / 2 : p.mt * p.nt;
-    if (tiles <= 0 || batch <= 0 || p.kc <= 0) return 0;
-    dim3 grid(tiles, batch);
-    if (b_nmajor)
-        hipLaunchKernelGGL(k_gemm<true>, grid, dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, p);
-    else
-        hipLaunchKernelGGL(k_gemm<false>, grid, dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, p);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p) {
-    if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0) return 0;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, p);
+static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1) {
+    if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
+    hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -189,17 +177,9 @@ static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p) {
 static int one_time_kernel_setup() {
     static bool done = false;
     if (done) return 0;
-    if (const char* e = getenv("BOHIP_REG_STAGING")) g_reg_staging = atoi(e);
-    if (const char* e = getenv("BOHIP_CAND_TILE")) g_cand_tile = atoi(e) == 128 ? 128 : (atoi(e) == 96 ? 96 : 64);
     HIPCHK(hipFuncSetAttribute((const void*)k_potf2_inv, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
-    HIPCHK(hipFuncSetAttribute((const void*)k_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<8>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<6>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<6>()));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<4, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     done = true;
     return 0;
 }
@@ -267,8 +247,8 @@ static int refit(bohip_gp* g) {
         for (int kb = ob; kb < oe; ++kb) {
             double* Lkk = g->dL + (int64_t)kb * TILE * (ld + 1);
             double* Wkk = g->dW + (int64_t)kb * TILE * (ld + 1);
-            hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, Lkk, ld, Wkk, ld,
-                               g->dinfo, kb * TILE);
+            hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, Lkk, ld, Wkk,
+                               g->dWT + (int64_t)kb * TILE * (ld + 1), ld, g->dinfo, kb * TILE);
             HIPCHK(hipGetLastError());
             const int rem = T - kb - 1;
             if (rem == 0) break;
@@ -303,30 +283,29 @@ static int refit(bohip_gp* g) {
         HIPCHK(hipGetLastError());
     }
     t_end(g);
-    // W = L^-1 by recursive doubling over diagonal blocks:
-    //   [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22]
+    // W = L^-1 by recursive doubling over diagonal blocks:  [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22].
+    // With W' kept beside W both products are K-major x K-major:
+    //     S'[c][i]  =  sum_k W11'[c][k] L21[i][k]          (A = W' block, upper-triangular: k >= c)
+    //     W21[i][c] = -sum_k W22[i][k]  S'[c][k]           (A = W22, lower-triangular: k <= i); W21' goes to W' too
+    // S' lives in the (otherwise unused) upper-right block of the scratch matrix.  All pairs of a level are one launch.
     t_begin(g, "tri_inverse");
     for (int h = 1; h < T; h *= 2) {  // h = half-block size in tiles
         const int pairs = (T + 2 * h - 1) / (2 * h);
-        const int64_t zstride = (int64_t)2 * h * TILE * (ld + 1);
-        // S21 = L21 * W11   (B = W11 in N-major form, lower-triangular -> k starts at the column tile)
-        GemmParams a{};
-        a.A = g->dL + (int64_t)h * TILE * ld; a.lda = ld;
-        a.B = g->dW; a.ldb = ld;
-        a.C = g->dS + (int64_t)h * TILE * ld; a.ldc = ld;
-        a.zA = a.zB = a.zC = zstride;
-        a.mt = h; a.nt = h; a.kc = h * (TILE / KC); a.alpha = 1.0; a.beta = 0.0; a.klo_from_n = 1;
-        a.z_row0 = h; a.z_rstride = 2 * h; a.total_rows = T;
-        CHK(launch_gemm(g, true, a, pairs));
-        // W21 = -W22 * S21  (A = W22 lower-triangular -> k stops at the row tile)
-        GemmParams b{};
-        b.A = g->dW + (int64_t)h * TILE * (ld + 1); b.lda = ld;
-        b.B = g->dS + (int64_t)h * TILE * ld; b.ldb = ld;
-        b.C = g->dW + (int64_t)h * TILE * ld; b.ldc = ld;
-        b.zA = b.zB = b.zC = zstride;
-        b.mt = h; b.nt = h; b.kc = h * (TILE / KC); b.alpha = -1.0; b.beta = 0.0; b.khi_from_m = 1;
-        b.z_row0 = h; b.z_rstride = 2 * h; b.total_rows = T;
-        CHK(launch_gemm(g, true, b, pairs));
+        const int64_t zs = (int64_t)2 * h * TILE * (ld + 1);
+        const int64_t off21 = (int64_t)h * TILE * ld, off12 = (int64_t)h * TILE, off22 = (int64_t)h * TILE * (ld + 1);
+        GemmNTParams a{};
+        a.A = g->dWT; a.lda = ld; a.B = g->dL + off21; a.ldb = ld; a.C = g->dS + off12; a.ldc = ld;
+        a.zA = a.zB = a.zC = zs;
+        a.mt = h; a.nt64 = 2 * h; a.kc = h * (TILE / KC); a.alpha = 1.0; a.beta = 0.0; a.klo_from_m = 1;
+        a.row_t0 = 0; a.row_ts = 2 * h; a.col_t0 = h; a.col_ts = 2 * h; a.total_t = T;
+        CHK(launch_gemm_nt(g, a, pairs));
+        GemmNTParams b{};
+        b.A = g->dW + off22; b.lda = ld; b.B = g->dS + off12; b.ldb = ld; b.C = g->dW + off21; b.ldc = ld;
+        b.CT = g->dWT + off12; b.ldct = ld;
+        b.zA = b.zB = b.zC = b.zCT = zs;
+        b.mt = h; b.nt64 = 2 * h; b.kc = h * (TILE / KC); b.alpha = -1.0; b.beta = 0.0; b.khi_from_m = 1;
+        b.row_t0 = h; b.row_ts = 2 * h; b.col_t0 = 0; b.col_ts = 2 * h; b.total_t = T;
+        CHK(launch_gemm_nt(g, b, pairs));
     }
     t_end(g);
     t_begin(g, "alpha");
@@ -348,7 +327,7 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
     HIPCHK(hipMemsetAsync(g->dinfo, 0, sizeof(int), g->stream));
     t_begin(g, "append_cov_rows");
     hipLaunchKernelGGL(k_cov_rows, dim3((Npad1 + 255) / 256, Npad1 - N0), dim3(256), 0, g->stream, g->dX, N0, N1, Npad1,
-                       hp, noise, g->dL, g->dW, ld);
+                       hp, noise, g->dL, g->dW, g->dWT, ld);
     HIPCHK(hipGetLastError());
     t_end(g);
     const int nch = (int)((p + APPEND_CHUNK - 1) / APPEND_CHUNK);
@@ -362,7 +341,7 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
     HIPCHK(hipMemcpy2DAsync(g->dL + N0 * ld, ld * 8, g->dApp, ld * 8, N0 * 8, p, hipMemcpyDeviceToDevice, g->stream));
     t_end(g);
     t_begin(g, "append_schur_chol");
-    hipLaunchKernelGGL(k_schur_chol, dim3(1), dim3(256), 0, g->stream, g->dL, g->dW, ld, N0, (int)p, g->dinfo);
+    hipLaunchKernelGGL(k_schur_chol, dim3(1), dim3(256), 0, g->stream, g->dL, g->dW, g->dWT, ld, N0, (int)p, g->dinfo);
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "append_W21");
@@ -373,7 +352,7 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
                            g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, APP_KSPLIT,
                            part + (int64_t)ch * APP_KSPLIT * APPEND_CHUNK * ld, ld);
     }
-    hipLaunchKernelGGL(k_apply_w22, dim3((N0 + 255) / 256), dim3(256), 0, g->stream, g->dW, ld, N0, (int)p, part, ld,
+    hipLaunchKernelGGL(k_apply_w22, dim3((N0 + 255) / 256), dim3(256), 0, g->stream, g->dW, g->dWT, ld, N0, (int)p, part, ld,
                        APP_KSPLIT, nch);
     HIPCHK(hipGetLastError());
     t_end(g);
@@ -461,31 +440,11 @@ static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1,
     hipLaunchKernelGGL(k_kstar<DT>, grid, dim3(256), 0, g->stream, g->dX, g->n, Npad, dXs, r0, r1, hp, g->dKsT, g->ld, rb);
 }
 
-// V = W K* with the fused epilogue.  Candidate tiles are 64 wide unless the batch is tiny: the job length is set
-// by the K extent (row tile), so halving the tile width halves the longest job and lets heaviest-first
-// list scheduling balance the 2 x 256 workgroup slots (128-wide tiles: makespan 24 units vs 18.75 average).
+// V = W K* with the fused epilogue (k_trigemm_sq): one launch per K*' chunk.
 static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t Rpad, int64_t r0, double* VT) {
-    if (g_cand_tile == 96) {
-        const int CT = (int)((ncand + 95) / 96), n_local = (CT + 7) / 8;
-        hipLaunchKernelGGL(k_trigemm_sq<6>, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<6>(), g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
-    } else if (g_cand_tile == 64 && g_reg_staging) {
-        const int CT = (int)((ncand + 63) / 64), n_local = (CT + 7) / 8;
-        hipLaunchKernelGGL((k_trigemm_sq<4, 0>), dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES_N64, g->stream,
-                           g->dW, g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
-    } else if (g_cand_tile == 64 && g_reg_staging == 2) {
-        const int CT = (int)((ncand + 63) / 64), n_local = (CT + 7) / 8;
-        hipLaunchKernelGGL((k_trigemm_sq<4, 1>), dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES_N64, g->stream,
-                           g->dW, g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
-    } else if (g_cand_tile == 64) {
-        const int CT = (int)((ncand + 63) / 64), n_local = (CT + 7) / 8;
-        hipLaunchKernelGGL(k_trigemm_sq<4>, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
-    } else {
-        const int CT = (int)((ncand + TILE - 1) / TILE), n_local = (CT + 7) / 8;
-        hipLaunchKernelGGL(k_trigemm_sq<8>, dim3(8 * n_local * T), dim3(GEMM_THREADS), GEMM_LDS_BYTES, g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
-    }
+    const int CT = (int)((ncand + CTILE - 1) / CTILE), n_local = (CT + 7) / 8;
+    hipLaunchKernelGGL(k_trigemm_sq, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, g->dW, g->ld,
+                       g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -582,10 +541,10 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
         CHK(launch_trigemm(g, T, r1 - r0, N, Rpad, r0, g->dVT));
         t_end(g);
         t_begin(g, "gemm_U");
-        GemmParams p{};
-        p.A = g->dVT; p.lda = g->ld; p.B = g->dW; p.ldb = g->ld; p.C = g->dUT; p.ldc = g->ld;
-        p.mt = CT; p.nt = T; p.kc = T * (TILE / KC); p.alpha = 1.0; p.beta = 0.0; p.klo_from_n = 1;
-        CHK(launch_gemm(g, true, p, 1));
+        GemmNTParams p{};  // U'[r][j] = sum_i V'[r][i] W'[j][i]   (B = W' upper-triangular: i >= j)
+        p.A = g->dVT; p.lda = g->ld; p.B = g->dWT; p.ldb = g->ld; p.C = g->dUT; p.ldc = g->ld;
+        p.mt = CT; p.nt64 = 2 * T; p.kc = T * (TILE / KC); p.alpha = 1.0; p.beta = 0.0; p.klo_from_n = 1;
+        CHK(launch_gemm_nt(g, p));
         t_end(g);
         t_begin(g, "score+grad");
         const int nb = (int)((r1 - r0 + 255) / 256);

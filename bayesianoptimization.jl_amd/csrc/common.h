@@ -8,17 +8,12 @@
 namespace bohip {
 
 // ---- tiling of every dense FP64 contraction --------------------------------------------------
-// Workgroup tile 128 x 128, 4 waves (2 x 2), each wave 64 x 64 = 8 x 8 MFMA groups of 8 x 8.
-// K is consumed in chunks of KC = 16 doubles (128 B = one cache line per row).
-// LDS row stride 17 doubles (136 B): conflict-free for the ds_read_b64 fragment pattern (bank pair
-// (34*row + 2*col) mod 64 is distinct over the 8 rows x 2 columns a 32-lane half touches) and small
-// enough that THREE 128x64 workgroups (52.2 KB each) fit the 160 KB LDS of a CU.
-constexpr int TILE = 128;
+// Workgroup tile 128 rows x 64 columns, 4 waves (2 x 2), wave tile 64 x 32 = 8 x 4 MFMA groups of 8 x 8.
+// K is consumed in chunks of KC = 16 doubles (128 B = one cache line per row).  See gemm_core.h.
+constexpr int TILE = 128;      // row-tile height and the block size of all blocked algorithms
+constexpr int CTILE = 64;      // column-tile width of the contraction engine
 constexpr int KC = 16;
-constexpr int LDSROW = KC + 1;
-constexpr int TILE_LDS_DOUBLES = TILE * LDSROW;  // one operand tile, one buffer
 constexpr int GEMM_THREADS = 256;
-constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * 2 /*A,B*/ * TILE_LDS_DOUBLES * 8;  // 69632 B -> 2 WGs/CU
 
 __host__ __device__ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 

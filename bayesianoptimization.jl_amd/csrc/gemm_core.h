@@ -10,9 +10,9 @@
 //     rows 4*bi + i, cols 4*bj + j, A replicated over bj, B replicated over bi
 // which balances the operand footprint (32 + 32 distinct doubles per instruction).
 //
-// Workgroup tile 128 x 128, 256 threads = 4 waves in 2 x 2, wave tile 64 x 64 = 8 x 8 groups
-// -> 64 accumulator doubles per lane.  Both operand tiles are staged K-major in LDS as
-// [128 rows][KC=16 (+2 pad)]; lane-group k' = lane>>4 supplies contraction index 4s + k' of k-step s.
+// Workgroup tile 128 rows x 64 columns, 256 threads = 4 waves in 2 x 2, wave tile 64 x 32 = 8 x 4 groups
+// -> 32 accumulator doubles per lane.  Both operand tiles are K-major ([rows][16 contraction indices]),
+// brought into LDS by global_load_lds (LDS-DMA), three buffers deep.
 #pragma once
 #include "common.h"
 
@@ -24,134 +24,9 @@ __device__ __forceinline__ double mfma444(double a, double b, double c) {
     return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
-// ---- global -> register staging (issued early, consumed after the MFMA block) ----------------
-// K-major operand: tile = 128 rows x 16 doubles at src (row stride ld).  8 lanes cover one
-// 128-B row segment, a wave covers 8 full cache lines per instruction.
-template <int NQ>  // NQ * 32 rows
-__device__ __forceinline__ void stage_load_kmajor(const double* __restrict__ src, int64_t ld, int tid, d2 (&r)[NQ]) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int row = q * 32 + (tid >> 3), seg = tid & 7;
-        r[q] = *reinterpret_cast<const d2*>(src + (int64_t)row * ld + seg * 2);
-    }
-}
-template <int NQ>
-__device__ __forceinline__ void stage_store_kmajor(double* dst, int tid, const d2 (&r)[NQ]) {
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int row = q * 32 + (tid >> 3), seg = tid & 7;
-        dst[row * LDSROW + seg * 2] = r[q].x;  // two ds_write_b64: the 136-B row stride is only 8-B aligned
-        dst[row * LDSROW + seg * 2 + 1] = r[q].y;
-    }
-}
-// N-major operand (B[k][n], n contiguous): tile = 16 k-rows x 128 n; transposed while storing.
-__device__ __forceinline__ void stage_load_nmajor(const double* __restrict__ src, int64_t ld, int tid, d2 (&r)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = q * 4 + (tid >> 6), n = (tid & 63) * 2;
-        r[q] = *reinterpret_cast<const d2*>(src + (int64_t)k * ld + n);
-    }
-}
-__device__ __forceinline__ void stage_store_nmajor(double* dst, int tid, const d2 (&r)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int k = q * 4 + (tid >> 6), n = (tid & 63) * 2;
-        dst[n * LDSROW + k] = r[q].x;
-        dst[(n + 1) * LDSROW + k] = r[q].y;
-    }
-}
-
-// ---- one K-chunk (16) of MFMA work for this wave: 256 x v_mfma_f64_4x4x4 ---------------------
-// Four k-steps of 4; lane-group k' = lane>>4 reads column 4s + k' with ds_read_b64 (conflict-free:
-// bank pair = (36*row + 2*col) mod 64 is distinct over the 8 rows x 2 columns of a 32-lane half).
-// One double per fragment keeps the live set at 128 (acc) + 16 + 16 VGPRs, so the kernel fits the
-// 256-VGPR budget of 2 waves/SIMD without spilling.
-template <int NJ>
-__device__ __forceinline__ void load_frags(const double* ap, const double* bp, int s, double (&av)[8], double (&bv)[NJ]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) av[i] = ap[i * 8 * LDSROW + 4 * s];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) bv[j] = bp[j * 8 * LDSROW + 4 * s];
-}
-template <int NJ>
-__device__ __forceinline__ void mma_step(const double (&av)[8], const double (&bv)[NJ], double (&acc)[8][NJ]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma444(av[i], bv[j], acc[i][j]);
-}
-// Software-pipelined: the fragments of k-step s+1 are read from LDS while the 8*NJ MFMAs of step s
-// issue; the sched_barriers keep hipcc from sinking the reads next to their first use (which exposes
-// the full LDS latency every few MFMAs) and from chaining two k-steps on one accumulator.
-template <int NJ>  // wave tile 64 x (8 * NJ)
-__device__ __forceinline__ void mma_chunk(const double* As, const double* Bs, int lane, int wr, int wc,
-                                          double (&acc)[8][NJ]) {
-    const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
-    const double* ap = As + (wr * 64 + 4 * (b >> 1) + t) * LDSROW + k;
-    const double* bp = Bs + (wc * 8 * NJ + 4 * (b & 1) + t) * LDSROW + k;
-    double a0[8], b0[NJ], a1[8], b1[NJ];
-    load_frags<NJ>(ap, bp, 0, a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_frags<NJ>(ap, bp, 1, a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_step<NJ>(a0, b0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    load_frags<NJ>(ap, bp, 2, a0, b0);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_step<NJ>(a1, b1, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    load_frags<NJ>(ap, bp, 3, a1, b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_step<NJ>(a0, b0, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_step<NJ>(a1, b1, acc);
-}
-
-// ---- K loop: acc += A[128 x K] * op(B) over chunks [kc_begin, kc_end) -------------------------
-// A points at (row0, 0) of a K-major matrix.  B points at (n0, 0) when K-major, (0, n0) when N-major.
-// Register-staged double buffering: loads of chunk c+1 are in flight during the MFMAs of chunk c;
-// one barrier per chunk.
-template <bool B_NMAJOR, int NJ = 8>
-__device__ __forceinline__ void gemm_tile_loop(const double* __restrict__ A, int64_t lda,
-                                               const double* __restrict__ B, int64_t ldb, int kc_begin,
-                                               int kc_end, double* smem, double (&acc)[8][NJ]) {
-    static_assert(!B_NMAJOR || NJ == 8, "N-major staging exists for 128-wide tiles only");
-    constexpr int BQ = NJ / 2;                          // B tile = 16 * NJ rows = 32 * BQ
-    constexpr int BT = 16 * NJ * LDSROW;                // doubles per B buffer
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    double* As = smem;
-    double* Bs = smem + 2 * TILE_LDS_DOUBLES;
-    d2 ra[4], rb[BQ];
-    if (kc_begin >= kc_end) return;
-    stage_load_kmajor<4>(A + (int64_t)kc_begin * KC, lda, tid, ra);
-    if constexpr (B_NMAJOR) stage_load_nmajor(B + (int64_t)kc_begin * KC * ldb, ldb, tid, rb);
-    else stage_load_kmajor<BQ>(B + (int64_t)kc_begin * KC, ldb, tid, rb);
-    stage_store_kmajor<4>(As, tid, ra);
-    if constexpr (B_NMAJOR) stage_store_nmajor(Bs, tid, rb);
-    else stage_store_kmajor<BQ>(Bs, tid, rb);
-    __syncthreads();
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
-        const int cur = (kc - kc_begin) & 1;
-        const bool more = kc + 1 < kc_end;
-        if (more) {
-            stage_load_kmajor<4>(A + (int64_t)(kc + 1) * KC, lda, tid, ra);
-            if constexpr (B_NMAJOR) stage_load_nmajor(B + (int64_t)(kc + 1) * KC * ldb, ldb, tid, rb);
-            else stage_load_kmajor<BQ>(B + (int64_t)(kc + 1) * KC, ldb, tid, rb);
-        }
-        mma_chunk<NJ>(As + cur * TILE_LDS_DOUBLES, Bs + cur * BT, lane, wr, wc, acc);
-        if (more) {
-            stage_store_kmajor<4>(As + (cur ^ 1) * TILE_LDS_DOUBLES, tid, ra);
-            if constexpr (B_NMAJOR) stage_store_nmajor(Bs + (cur ^ 1) * BT, tid, rb);
-            else stage_store_kmajor<BQ>(Bs + (cur ^ 1) * BT, tid, rb);
-        }
-        __syncthreads();
-    }
-}
-
 // ================================================================================================
-// LDS-DMA variant (K-major operands): global_load_lds_dwordx4 writes the tiles straight into LDS, so the
-// staging costs no VGPRs, no ds_write instructions and no vmcnt wait inside the wave's instruction
-// stream (only the vmcnt(0) that __syncthreads() carries).  The DMA destination is wave-uniform base +
+// Staging: global_load_lds_dwordx4 (LDS-DMA) writes the tiles straight into LDS, so staging costs no VGPRs,
+// no ds_write instructions and no wait inside the MFMA stream.  The DMA destination is wave-uniform base +
 // lane*16 B, i.e. rows are exactly 128 B with no padding, so bank conflicts are removed by an XOR swizzle
 // of the 16-B segment index with (row & 7), applied on the SOURCE address (which segment a lane fetches)
 // and again on the fragment reads:   LDS[row][p] holds global segment p ^ (row & 7).
@@ -207,52 +82,6 @@ __device__ __forceinline__ void mma_chunk_swz(const double* ap, const double* bp
     mma_pair<NJ>(a0, b0, acc);
     __builtin_amdgcn_sched_barrier(0);
     mma_pair<NJ>(a1, b1, acc);
-}
-
-template <int NJ>
-constexpr int glds_lds_bytes() { return 2 * (TILE + 16 * NJ) * GL_ROW * 8; }
-
-template <int NJ>
-__device__ __forceinline__ void gemm_tile_loop_glds(const double* __restrict__ A, int64_t lda,
-                                                    const double* __restrict__ B, int64_t ldb, int kc_begin,
-                                                    int kc_end, double* smem, double (&acc)[8][NJ],
-                                                    int active_rows = TILE) {
-    // active_rows: rows of the A tile at or beyond it are structural padding; a wave whose 64 rows are all
-    // padding still stages and synchronises but issues no MFMAs (wave-uniform branch).
-    constexpr int BQ = NJ / 2;
-    constexpr int AT = TILE * GL_ROW, BT = 16 * NJ * GL_ROW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    double* As = smem;             // [2][128][16]
-    double* Bs = smem + 2 * AT;    // [2][16*NJ][16]
-    if (kc_begin >= kc_end) return;
-    // DMA source of this lane: row (wave*8 + lane/8) of each 32-row pass, segment (lane%8) ^ (row%8)
-    const int srow = wave * 8 + (lane >> 3), sseg = (lane & 7) ^ (lane >> 3);
-    const double* a_src = A + (int64_t)srow * lda + sseg * 2;
-    const double* b_src = B + (int64_t)srow * ldb + sseg * 2;
-    double* a_dst = As + wave * 8 * GL_ROW;  // wave-uniform
-    double* b_dst = Bs + wave * 8 * GL_ROW;
-    // fragment addressing
-    const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
-    const int r7a = 4 * (b >> 1) + t, r7b = 4 * (b & 1) + t;
-    int oa[2], ob[2];
-#pragma unroll
-    for (int S = 0; S < 2; ++S) {
-        oa[S] = ((4 * S + k) ^ r7a) << 1;
-        ob[S] = ((4 * S + k) ^ r7b) << 1;
-    }
-    const int a_frag = (wr * 64 + r7a) * GL_ROW, b_frag = (wc * 8 * NJ + r7b) * GL_ROW;
-    glds_tile<4>(a_src + (int64_t)kc_begin * KC, lda, a_dst);
-    glds_tile<BQ>(b_src + (int64_t)kc_begin * KC, ldb, b_dst);
-    __syncthreads();
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
-        const int cur = (kc - kc_begin) & 1;
-        if (kc + 1 < kc_end) {
-            glds_tile<4>(a_src + (int64_t)(kc + 1) * KC, lda, a_dst + (cur ^ 1) * AT);
-            glds_tile<BQ>(b_src + (int64_t)(kc + 1) * KC, ldb, b_dst + (cur ^ 1) * BT);
-        }
-        if (wr * 64 < active_rows) mma_chunk_swz<NJ>(As + cur * AT + a_frag, Bs + cur * BT + b_frag, oa, ob, acc);
-        __syncthreads();
-    }
 }
 
 // ---- LDS-DMA with THREE buffers: two chunks in flight ------------------------------------------
@@ -326,11 +155,11 @@ __device__ __forceinline__ void gemm_tile_loop_glds3(const double* __restrict__ 
     }
 }
 
-// Where this lane's accumulator acc[mi][nj] lives inside the 128 x 128 workgroup tile.
+// Where this lane's accumulator acc[mi][nj] lives inside the 128 x (16 NJ) workgroup tile.
 __device__ __forceinline__ int acc_row(int lane, int wr, int mi) {
     return wr * 64 + 8 * mi + 4 * (((lane >> 2) & 3) >> 1) + (lane >> 4);
 }
-template <int NJ = 8>
+template <int NJ>
 __device__ __forceinline__ int acc_col(int lane, int wc, int nj) {
     return wc * 8 * NJ + 8 * nj + 4 * (((lane >> 2) & 3) & 1) + (lane & 3);
 }

@@ -1,8 +1,8 @@
 // kernels_linalg.hip -- model-update kernels (rows A1-A3 of SURVEY.md section 8):
 //   k_build_cov      SEArd/SEIso/Mat52Ard kernel-matrix assembly, lower 128-tiles (HBM-write bound)
 //   k_potf2_inv      128x128 diagonal block: Cholesky + triangular inverse in LDS (latency bound)
-//   k_gemm           generic FP64 MFMA contraction C = alpha*A*op(B) + beta*C (panel solve, trailing
-//                    update, recursive triangular inverse W = L^-1)
+//   k_gemm_nt        FP64 MFMA contraction C = alpha*A*B' + beta*C, both operands K-major (panel solve,
+//                    trailing updates, recursive triangular inverse W = L^-1, U' = V'W of the gradient path)
 //   k_trimv / k_trimv_t, k_sub_mean, k_mll  -- alpha = W'(W(y - beta)) and the marginal likelihood
 // Reference call sites replaced: update!/append!/fit! in src/models/gp.jl:11-18 (GaussianProcesses.jl
 // update_cK! + ElasticPDMats Cholesky behind them).
@@ -201,7 +201,8 @@ __device__ long long pf_clocks[16];
 #endif
 
 __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ Lblk, int64_t ld, double* __restrict__ Wblk,
-                                                   int64_t ldw, int* __restrict__ info, int row0) {
+                                                   double* __restrict__ WTblk, int64_t ldw, int* __restrict__ info,
+                                                   int row0) {
     extern __shared__ double sm[];
 #ifdef BOHIP_POTF2_CLOCKS
     long long pf_t0 = clock64();
@@ -316,71 +317,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
         const int i = e >> 7, c = e & 127;
         Wblk[(int64_t)i * ldw + c] = (c <= i) ? a[i * PF_LD + c] : 0.0;
     }
+    for (int e = tid; e < TILE * TILE; e += PF_THREADS) {  // W' (upper): row c, column i; LDS stride 129 -> conflict-free
+        const int c = e >> 7, i = e & 127;
+        WTblk[(int64_t)c * ldw + i] = (c <= i) ? a[i * PF_LD + c] : 0.0;
+    }
     PF_CLK(9);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Generic contraction  C[z] = alpha * A[z] * op(B[z]) + beta * C[z]  on 128-tiles.
-//   A K-major [M][K]; B K-major [N][K] (B_NMAJOR=false) or N-major [K][N] (true); C row-major.
-//   lower_tiles : only tiles i >= j (symmetric trailing update)
-//   klo_from_n  : contraction starts at k = 128*j  (B lower-triangular in N-major form)
-//   khi_from_m  : contraction ends at  k = 128*(i+1) (A lower-triangular)
-//   ragged M    : batch z covers tile rows [z_row0 + z*z_rstride, ...); tiles beyond total_rows exit
-// ------------------------------------------------------------------------------------------------
-struct GemmParams {
-    const double* A;
-    const double* B;
-    double* C;
-    int64_t lda, ldb, ldc;
-    int64_t zA, zB, zC;
-    int mt, nt, kc;
-    double alpha, beta;
-    int lower_tiles, klo_from_n, khi_from_m;
-    int z_row0, z_rstride, total_rows;  // in tiles; total_rows <= 0 disables the check
-};
-
-template <bool B_NMAJOR>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    int ti, tj;
-    if (p.lower_tiles) {
-        const int b = blockIdx.x;
-        int i = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5);
-        while ((i + 1) * (i + 2) / 2 <= b) ++i;
-        while (i * (i + 1) / 2 > b) --i;
-        ti = i;
-        tj = b - i * (i + 1) / 2;
-    } else {
-        ti = blockIdx.x / p.nt;
-        tj = blockIdx.x % p.nt;
-    }
-    const int z = blockIdx.y;
-    if (p.total_rows > 0 && p.z_row0 + z * p.z_rstride + ti >= p.total_rows) return;
-    const double* A = p.A + z * p.zA + (int64_t)ti * TILE * p.lda;
-    const double* B = p.B + z * p.zB + (B_NMAJOR ? (int64_t)tj * TILE : (int64_t)tj * TILE * p.ldb);
-    double* C = p.C + z * p.zC + (int64_t)ti * TILE * p.ldc + (int64_t)tj * TILE;
-    int kb = 0, ke = p.kc;
-    if (p.klo_from_n) kb = tj * (TILE / KC);
-    if (p.khi_from_m) ke = min(ke, (ti + 1) * (TILE / KC));
-    double acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
-    gemm_tile_loop<B_NMAJOR>(A, p.lda, B, p.ldb, kb, ke, smem, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int r = acc_row(lane, wr, mi);
-#pragma unroll
-        for (int nj = 0; nj < 8; ++nj) {
-            const int c = acc_col<8>(lane, wc, nj);
-            double* dst = C + (int64_t)r * p.ldc + c;
-            double v = p.alpha * acc[mi][nj];
-            if (p.beta != 0.0) v += p.beta * *dst;
-            *dst = v;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,38 +332,54 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(GemmParams p) {
 // global offsets of C in elements), so rectangular panels that straddle the diagonal need no special grid.
 // ------------------------------------------------------------------------------------------------
 struct GemmNTParams {
-    const double* A;
-    const double* B;
-    double* C;
-    int64_t lda, ldb, ldc;
-    int mt, nt64, kc;
+    const double* A;      // [M][K]  K-major, row stride lda
+    const double* B;      // [N][K]  K-major, row stride ldb
+    double* C;            // [M][N]
+    double* CT;           // optional: also store C' here (CT[n][m], row stride ldct)
+    int64_t lda, ldb, ldc, ldct;
+    int64_t zA, zB, zC, zCT;  // element strides per batch (blockIdx.y)
+    int mt, nt64, kc;         // 128-row tiles, 64-column tiles, 16-deep chunks
     double alpha, beta;
-    int diag_skip;
+    int klo_from_m;   // A upper-triangular in (m, k): contraction starts at k = 128 ti
+    int khi_from_m;   // A lower-triangular: contraction ends at k = 128 (ti + 1)
+    int klo_from_n;   // B upper-triangular in (n, k): contraction starts at k = 128 (tj64 / 2)
+    int diag_skip;    // skip tiles strictly above the global block diagonal (row0/col0 = element offsets of C)
     int64_t row0, col0;
+    // ragged batches: tile (ti, tj64) of batch z exists iff  row_t0 + z row_ts + ti < total_t  and
+    // col_t0 + z col_ts + tj64/2 < total_t  (all in 128-tiles); total_t <= 0 disables the check
+    int row_t0, row_ts, col_t0, col_ts, total_t;
 };
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_nt(GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    // heaviest-first is irrelevant here (uniform K); deal blocks to XCDs so that one XCD owns a strip of rows
-    const int ti = blockIdx.x / p.nt64, tj = blockIdx.x % p.nt64;
-    if (p.diag_skip && p.col0 + 64 * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) return;
+    const int ti = blockIdx.x / p.nt64, tj = blockIdx.x % p.nt64, z = blockIdx.y;
+    if (p.diag_skip && p.col0 + CTILE * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) return;
+    if (p.total_t > 0 && (p.row_t0 + z * p.row_ts + ti >= p.total_t || p.col_t0 + z * p.col_ts + (tj >> 1) >= p.total_t)) return;
+    int kb = 0, ke = p.kc;
+    if (p.klo_from_m) kb = ti * (TILE / KC);
+    if (p.klo_from_n) kb = max(kb, (tj >> 1) * (TILE / KC));
+    if (p.khi_from_m) ke = min(ke, (ti + 1) * (TILE / KC));
     double acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    gemm_tile_loop_glds3<4>(p.A + (int64_t)ti * TILE * p.lda, p.lda, p.B + (int64_t)tj * 64 * p.ldb, p.ldb, 0, p.kc, smem, acc);
+    gemm_tile_loop_glds3<4>(p.A + z * p.zA + (int64_t)ti * TILE * p.lda, p.lda, p.B + z * p.zB + (int64_t)tj * CTILE * p.ldb,
+                            p.ldb, kb, ke, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-    double* C = p.C + (int64_t)ti * TILE * p.ldc + (int64_t)tj * 64;
+    double* C = p.C + z * p.zC + (int64_t)ti * TILE * p.ldc + (int64_t)tj * CTILE;
+    double* CT = p.CT ? p.CT + z * p.zCT + (int64_t)tj * CTILE * p.ldct + (int64_t)ti * TILE : nullptr;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const int r = acc_row(lane, wr, mi);
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj) {
-            double* dst = C + (int64_t)r * p.ldc + acc_col<4>(lane, wc, nj);
+            const int c = acc_col<4>(lane, wc, nj);
+            double* dst = C + (int64_t)r * p.ldc + c;
             double v = p.alpha * acc[mi][nj];
             if (p.beta != 0.0) v += p.beta * *dst;
             *dst = v;
+            if (CT) CT[(int64_t)c * p.ldct + r] = v;
         }
     }
 }
@@ -445,8 +402,6 @@ __global__ __launch_bounds__(256) void k_copy_offdiag_tiles(const double* __rest
     }
 }
 
-template __global__ void k_gemm<false>(GemmParams);
-template __global__ void k_gemm<true>(GemmParams);
 
 // ------------------------------------------------------------------------------------------------
 // A3: alpha = W' (W (y - beta)).  W is lower-triangular row-major.
@@ -528,7 +483,7 @@ constexpr int APPEND_CHUNK = 8;   // right-hand sides per pass over W
 // New rows [N0, Npad1) of cK into L (cols 0..i) and identity padding rows into L and W.
 __global__ __launch_bounds__(256) void k_cov_rows(const double* __restrict__ X, int64_t N0, int64_t N1, int64_t Npad1,
                                                   KernelHyper hp, double noise, double* __restrict__ L,
-                                                  double* __restrict__ W, int64_t ld) {
+                                                  double* __restrict__ W, double* __restrict__ WT, int64_t ld) {
 #pragma clang fp contract(off)
     const int64_t i = N0 + blockIdx.y;
     const int64_t j = blockIdx.x * 256 + threadIdx.x;
@@ -548,6 +503,7 @@ __global__ __launch_bounds__(256) void k_cov_rows(const double* __restrict__ X, 
         const double v = (i == j) ? 1.0 : 0.0;
         L[i * ld + j] = v;
         W[i * ld + j] = v;
+        WT[j * ld + i] = v;
     }
 }
 
@@ -578,8 +534,8 @@ __global__ __launch_bounds__(256) void k_rows_trimv(const double* __restrict__ W
 
 // One workgroup: S = K22 - L21 L21' (p x p), L22 = chol(S), W22 = L22^-1.
 // K22 sits in L[N0+r][N0+s]; L21 in L[N0+r][0..N0).  Results overwrite L22 in place and go to W22.
-__global__ __launch_bounds__(256) void k_schur_chol(double* __restrict__ L, double* __restrict__ W, int64_t ld,
-                                                    int64_t N0, int p, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void k_schur_chol(double* __restrict__ L, double* __restrict__ W, double* __restrict__ WT,
+                                                    int64_t ld, int64_t N0, int p, int* __restrict__ info) {
     __shared__ double S[APPEND_PMAX][APPEND_PMAX + 1];
     __shared__ double Winv[APPEND_PMAX][APPEND_PMAX + 1];
     __shared__ double red[4];
@@ -626,6 +582,7 @@ __global__ __launch_bounds__(256) void k_schur_chol(double* __restrict__ L, doub
         const int r = e / p, c = e % p;
         L[(N0 + r) * ld + N0 + c] = (c <= r) ? S[r][c] : 0.0;
         W[(N0 + r) * ld + N0 + c] = (c <= r) ? Winv[r][c] : 0.0;
+        WT[(N0 + c) * ld + N0 + r] = (c <= r) ? Winv[r][c] : 0.0;
     }
 }
 
@@ -654,7 +611,7 @@ __global__ __launch_bounds__(256) void k_rows_times_W(const double* __restrict__
 }
 
 // W21[r][c] = -sum_s W22[r][s] * T[s][c],  T[s][c] = sum_ks part[ks][s][c]  (fixed order).
-__global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, int64_t ld, int64_t N0, int p,
+__global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, double* __restrict__ WT, int64_t ld, int64_t N0, int p,
                                                    const double* __restrict__ part, int64_t ldp, int ksplit,
                                                    int nchunks) {
     const int64_t c = blockIdx.x * 256 + threadIdx.x;
@@ -671,6 +628,7 @@ __global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, int64
         double v = 0.0;
         for (int s = 0; s <= r; ++s) v += W[(N0 + r) * ld + N0 + s] * T[s];
         W[(N0 + r) * ld + c] = -v;
+        WT[c * ld + N0 + r] = -v;
     }
 }
 

@@ -53,21 +53,22 @@ __global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ X, int
 
 // ------------------------------------------------------------------------------------------------
 // V = W K*, fused epilogue.  Tile (rt, ct): rows [128 rt, 128 rt + 128) of W against candidates
-// [128 ct, ...) of the chunk; W is lower-triangular so the contraction stops at k = 128 (rt + 1).
-// Work per tile grows with rt, so tiles are issued heaviest-first; blocks are dealt to XCDs
+// [64 ct, 64 ct + 64) of the chunk; W is lower-triangular so the contraction stops at k = 128 (rt + 1).
+// Job length is set by that K extent, so the candidate tile is only 64 wide: with 128-wide tiles the longest
+// job (24 units at N=3000) exceeds the average load per workgroup slot (18.75) and list scheduling cannot
+// balance.  Work per tile grows with rt, so tiles are issued heaviest-first; blocks are dealt to XCDs
 // (block b runs on XCD b % 8) so that each XCD owns a fixed subset of candidate tiles and walks the
 // row tiles together: the W row-tile stream is then shared through that XCD's L2.
 // Output: q_part[rt][r] = sum over the tile's rows of v^2 (fixed summation order -> deterministic),
 //         mu_raw[r] = alpha' k*_r taken from the row of W that stores alpha (alpha_row).
 // ------------------------------------------------------------------------------------------------
-template <int NJ, int STAGING = (NJ != 8 ? 2 : 0)>  // STAGING: 0 registers, 1 LDS-DMA x2 buffers, 2 LDS-DMA x3 buffers  // candidate tile width CW = 16 * NJ (128, 96 or 64); LDS-DMA or register staging
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
                                                                 const double* __restrict__ KsT, int64_t ldk,
                                                                 int T, int CT, int64_t alpha_row,
                                                                 double* __restrict__ q_part, int64_t ldq,
                                                                 double* __restrict__ mu_raw, int64_t r_off,
                                                                 double* __restrict__ VT, int64_t ldv) {
-    constexpr int CW = 16 * NJ;
+    constexpr int NJ = 4, CW = CTILE;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int n_local = (CT + 7) >> 3;
@@ -79,17 +80,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0;
-    if constexpr (STAGING == 2)
-        gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
-                                 (rt + 1) * (TILE / KC), smem, acc,
-                                 (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE));
-    else if constexpr (STAGING == 1)
-        gemm_tile_loop_glds<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
-                                (rt + 1) * (TILE / KC), smem, acc,
-                                (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE));  // rows past alpha' are padding
-    else
-        gemm_tile_loop<false, NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
-                                  (rt + 1) * (TILE / KC), smem, acc);
+    gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0, (rt + 1) * (TILE / KC),
+                             smem, acc, (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE));  // rows past alpha' are padding
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
     __syncthreads();     // (the raw-barrier loops end on s_barrier; make the reuse of smem below explicit)
     double* red = smem;  // [2][CW]
