@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_build_cov(const double* __restrict__ X,
 #pragma unroll
     for (int k = 0; k < DT; ++k) xj[k] = (k < d && j < N) ? X[j * d + k] : 0.0;
     for (int64_t i = i0; i < i0 + rows_per_block && i < Npad; ++i) {
-        if (j >= Npad || j / TILE > i / TILE) continue;  // strictly upper 128-tile: never touched (stays zero)
+        if (j >= Npad || j > i) continue;  // only the lower triangle is ever written (the rest stays zero)
         double v;
         if (i < N && j < N) {
             const double* xi = X + i * d;
@@ -83,65 +83,80 @@ constexpr int POTF2_LDS_BYTES = (TILE * PF_LD + 2 * TILE) * 8;
 
 constexpr int PF_THREADS = 256;  // measured: 512 threads is slower (254k vs 228k cycles per block)
 
+// One level of the in-LDS recursive inverse on the matrix pipe: pairs of H-blocks [W11 0; W21 W22],
+//     S = L21 W11 (8x8 output blocks, k >= column block),  W21 = -W22 S (k <= row block).
+// Each wave owns whole 8 x 8 output blocks and runs v_mfma_f64_4x4x4 (2 x 2 block arrangement = 8 x 8 x 4 per
+// instruction, see gemm_core.h) with operands read straight from the LDS image; the triangular operands are
+// masked by index because the other triangle of the image holds L (mirror) / workspace.
+//   lane l: kq = l>>4, b = (l>>2)&3, t = l&3;  A element (row 4(b>>1)+t, k kq), B element (k kq, col 4(b&1)+t),
+//           D element (row 4(b>>1) + (l>>4), col 4(b&1) + (l&3)).
 template <int H>
 __device__ __forceinline__ void inv_level(double* a, int tid) {
-    // pairs of H-blocks: [W11 0; W21 W22], W21 = -W22 (L21 W11).  4H threads per pair;
-    // thread tile ROWS x 4 with rows cyclic (stride 16) so column walks of W22 stay conflict-free.
-    constexpr int ROWS = H / 16;
-    const int pair = tid / (4 * H), t = tid % (4 * H);
-    const int c0 = 4 * (t % (H / 4)), ti = t / (H / 4);
+    constexpr int NB = H / 8;                 // 8x8 blocks per side of an H-block
+    // each wave owns 2 block-rows x NB block-columns of ONE pair: 2 NB independent accumulator chains per k-step,
+    // 2 + NB operand reads for 2 NB MFMAs.
+    const int lane = tid & 63, wave = tid >> 6;
+    const int pair = wave / (NB / 2), ib0 = 2 * (wave % (NB / 2));
     const int q0 = 2 * H * pair, q1 = q0 + H;
-    double acc[ROWS][4];
+    const int kq = lane >> 4, bb = (lane >> 2) & 3, t = lane & 3;
+    const int ar = 4 * (bb >> 1) + t, bc = 4 * (bb & 1) + t;
+    const int dr = 4 * (bb >> 1) + (lane >> 4), dc = 4 * (bb & 1) + (lane & 3);
+    double acc[2][NB];
+    // ---- S = L21 W11;  L21[i][k] = mirror a[q0+k][q1+i],  W11[k][j] = a[q0+k][q0+j] for k >= j
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-    // S[i][c] = sum_{k>=c} L21[i][k] W11[k][c];  L21[i][k] = mirror a[q0+k][q1+i]
-#pragma unroll 4
-    for (int k = c0; k < H; ++k) {
-        double wv[4], lv[ROWS];
+        for (int j = 0; j < NB; ++j) acc[r][j] = 0.0;
+#pragma unroll 2
+    for (int k0 = 0; k0 < H; k0 += 4) {
+        const int k = k0 + kq;
+        const double* row = a + (q0 + k) * PF_LD;
+        double av[2], wv[NB];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double tv = a[(q0 + k) * PF_LD + q0 + c0 + c];
-            wv[c] = (k >= c0 + c) ? tv : 0.0;
+        for (int r = 0; r < 2; ++r) av[r] = row[q1 + 8 * (ib0 + r) + ar];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double w = row[q0 + 8 * j + bc];
+            wv[j] = (k >= 8 * j + bc) ? w : 0.0;
         }
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) lv[r] = a[(q0 + k) * PF_LD + q1 + ti + 16 * r];
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] += lv[r] * wv[c];
-    }
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a[(q1 + ti + 16 * r) * PF_LD + q0 + c0 + c] = acc[r][c];  // S into the (free) W21 slot
-    __syncthreads();
-    // W21[i][c] = -sum_{k<=i} W22[i][k] S[k][c]
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-#pragma unroll 4
-    for (int k = 0; k <= ti + 16 * (ROWS - 1); ++k) {
-        double sv[4], wv[ROWS];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) sv[c] = a[(q1 + k) * PF_LD + q0 + c0 + c];
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            const double tv = a[(q1 + ti + 16 * r) * PF_LD + q1 + k];
-            wv[r] = (k <= ti + 16 * r) ? tv : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] -= wv[r] * sv[c];
+            for (int j = 0; j < NB; ++j) acc[r][j] = mfma444(av[r], wv[j], acc[r][j]);
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r)
+    for (int r = 0; r < 2; ++r)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[(q1 + ti + 16 * r) * PF_LD + q0 + c0 + c] = acc[r][c];
+        for (int j = 0; j < NB; ++j) a[(q1 + 8 * (ib0 + r) + dr) * PF_LD + q0 + 8 * j + dc] = acc[r][j];   // S into the W21 slot
+    __syncthreads();
+    // ---- W21 = -W22 S;  W22[i][k] = a[q1+i][q1+k] for k <= i,  S[k][j] = a[q1+k][q0+j]
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[r][j] = 0.0;
+#pragma unroll 2
+    for (int k0 = 0; k0 < 8 * ib0 + 16; k0 += 4) {   // W22 lower-triangular: nothing beyond the second block-row's diagonal
+        const int k = k0 + kq;
+        double wv[2], sv[NB];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int i = 8 * (ib0 + r) + ar;
+            const double w = a[(q1 + i) * PF_LD + q1 + k];
+            wv[r] = (k <= i) ? w : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) sv[j] = a[(q1 + k) * PF_LD + q0 + 8 * j + bc];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[r][j] = mfma444(wv[r], sv[j], acc[r][j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[(q1 + 8 * (ib0 + r) + dr) * PF_LD + q0 + 8 * j + dc] = -acc[r][j];
     __syncthreads();
 }
 
@@ -161,7 +176,10 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
     return y;
 }
 
-// A3 for a trailing size of NB 16-blocks: cyclic NB x NB register tile per thread (lower half only).
+// A3 for a trailing size of NB 16-blocks: cyclic NB x NB register tile per thread (lower half only), FP64 VALU.
+// (An MFMA formulation was measured slower here: 96k vs 32k cycles per block -- the panels are only 16 deep, so
+// each 8x8 block is 4 dependent MFMAs behind ~10 LDS reads, while the register-tiled VALU form reuses every
+// operand NB times.)
 template <int NB>
 __device__ __forceinline__ void trailing_update(double* a, int P, int tid) {
     const int base = P + 16, ty = tid >> 4, tx = tid & 15;
@@ -285,9 +303,15 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
         PF_CLK(3);
     }
     // L out (coalesced along j): strict lower from the mirror, diagonal from dl, zeros above
-    for (int e = tid; e < TILE * TILE; e += PF_THREADS) {
-        const int i = e >> 7, j = e & 127;
-        Lblk[(int64_t)i * ld + j] = (j < i) ? a[j * PF_LD + i] : (j == i ? dl[i] : 0.0);
+    // (the strict upper triangle of the L block and of W, and the strict lower triangle of W', are zero from
+    //  allocation and never written by anyone: k_build_cov leaves the upper triangle of diagonal tiles alone)
+    for (int e = tid; e < TILE * TILE / 2; e += PF_THREADS) {  // 16-B stores; only the lower triangle
+        const int i = e >> 6, j = (e & 63) * 2;
+        if (j > i) continue;
+        d2 v;
+        v.x = (j < i) ? a[j * PF_LD + i] : dl[i];
+        v.y = (j + 1 < i) ? a[(j + 1) * PF_LD + i] : (j + 1 == i ? dl[i] : 0.0);
+        *reinterpret_cast<d2*>(Lblk + (int64_t)i * ld + j) = v;
     }
     PF_CLK(4);
     // B0: 16 x 16 diagonal inverses, thread = column
@@ -313,13 +337,21 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
     PF_CLK(7);
     inv_level<64>(a, tid);
     PF_CLK(8);
-    for (int e = tid; e < TILE * TILE; e += PF_THREADS) {
-        const int i = e >> 7, c = e & 127;
-        Wblk[(int64_t)i * ldw + c] = (c <= i) ? a[i * PF_LD + c] : 0.0;
-    }
-    for (int e = tid; e < TILE * TILE; e += PF_THREADS) {  // W' (upper): row c, column i; LDS stride 129 -> conflict-free
-        const int c = e >> 7, i = e & 127;
-        WTblk[(int64_t)c * ldw + i] = (c <= i) ? a[i * PF_LD + c] : 0.0;
+    for (int e = tid; e < TILE * TILE / 2; e += PF_THREADS) {  // W (lower) and W' (upper), 16-B stores
+        const int i = e >> 6, c = (e & 63) * 2;
+        if (c <= i) {
+            d2 v;
+            v.x = a[i * PF_LD + c];
+            v.y = (c + 1 <= i) ? a[i * PF_LD + c + 1] : 0.0;
+            *reinterpret_cast<d2*>(Wblk + (int64_t)i * ldw + c) = v;
+        }
+        // W'[r][q] = W[q][r] for q >= r: row r = i, columns q = c, c + 1
+        if (c + 1 >= i) {
+            d2 v;
+            v.x = (c >= i) ? a[c * PF_LD + i] : 0.0;
+            v.y = a[(c + 1) * PF_LD + i];
+            *reinterpret_cast<d2*>(WTblk + (int64_t)i * ldw + c) = v;
+        }
     }
     PF_CLK(9);
 }
@@ -375,6 +407,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_nt(GemmNTParams p) {
 #pragma unroll
         for (int nj = 0; nj < 4; ++nj) {
             const int c = acc_col<4>(lane, wc, nj);
+            // symmetric updates never touch the strict upper triangle of the global matrix (it must stay zero)
+            if (p.diag_skip && p.col0 + (int64_t)tj * CTILE + c > p.row0 + (int64_t)ti * TILE + r) continue;
             double* dst = C + (int64_t)r * p.ldc + c;
             double v = p.alpha * acc[mi][nj];
             if (p.beta != 0.0) v += p.beta * *dst;
