@@ -66,6 +66,8 @@ struct bohip_gp {
     bool stale = true;
     int64_t n_factored = 0;  // observations covered by the current factor
     hipStream_t stream = nullptr, own_stream = nullptr;
+    hipStream_t side_stream = nullptr;            // bulk trailing updates of the factorisation run here (look-ahead)
+    hipEvent_t ev_panels = nullptr, ev_bulk = nullptr;
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
@@ -167,9 +169,9 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 }
 
 // ---- GEMM launcher --------------------------------------------------------------------------------
-static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1) {
+static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, p);
+    hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), st ? st : g->stream, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -242,6 +244,7 @@ static int refit(bohip_gp* g) {
     // the right of the outer block is updated ONCE per outer block with K = 128 * OB.  The C tiles of the bulk
     // are therefore read-modified-written T/OB times instead of T times and the bulk contraction is OB x deeper.
     const int OB = 4;
+    bool side_pending = false;
     for (int ob = 0; ob < T; ob += OB) {
         const int oe = std::min(T, ob + OB);
         for (int kb = ob; kb < oe; ++kb) {
@@ -270,14 +273,36 @@ static int refit(bohip_gp* g) {
         }
         const int rem = T - oe;
         if (rem > 0) {
-            GemmNTParams b{};  // bulk: A[i, j] -= L[i, ob:oe] L[j, ob:oe]'  for i >= j >= oe
-            b.A = g->dS + (int64_t)oe * TILE * ld + (int64_t)ob * TILE; b.lda = ld; b.B = b.A; b.ldb = ld;
-            b.C = g->dL + (int64_t)oe * TILE * (ld + 1); b.ldc = ld;
-            b.mt = rem; b.nt64 = 2 * rem; b.kc = (oe - ob) * (TILE / KC); b.alpha = -1.0; b.beta = 1.0;
-            b.diag_skip = 1; b.row0 = (int64_t)oe * TILE; b.col0 = (int64_t)oe * TILE;
-            CHK(launch_gemm_nt(g, b));
+            // Bulk update with the OB solved panels, split for look-ahead: the columns of the NEXT outer block are
+            // updated on the critical stream; everything to their right goes to the side stream and overlaps the next
+            // block's diagonal factorisations.  Hazards: (1) the side stream needs the panels -> ev_panels;
+            // (2) next block's columns were last written by the previous side-stream update -> ev_bulk.
+            const int nxt = std::min(OB, rem), rest = rem - nxt;
+            auto bulk = [&](int r0t, int c0t, int mt, int nct) {
+                GemmNTParams b{};  // A[i, j] -= L[i, ob:oe] L[j, ob:oe]'  on rows >= r0t, columns [c0t, c0t + nct)
+                b.A = g->dS + (int64_t)r0t * TILE * ld + (int64_t)ob * TILE; b.lda = ld;
+                b.B = g->dS + (int64_t)c0t * TILE * ld + (int64_t)ob * TILE; b.ldb = ld;
+                b.C = g->dL + (int64_t)r0t * TILE * ld + (int64_t)c0t * TILE; b.ldc = ld;
+                b.mt = mt; b.nt64 = 2 * nct; b.kc = (oe - ob) * (TILE / KC); b.alpha = -1.0; b.beta = 1.0;
+                b.diag_skip = 1; b.row0 = (int64_t)r0t * TILE; b.col0 = (int64_t)c0t * TILE;
+                return b;
+            };
+            if (rest > 0) {
+                HIPCHK(hipEventRecord(g->ev_panels, g->stream));
+                HIPCHK(hipStreamWaitEvent(g->side_stream, g->ev_panels, 0));
+            }
+            if (side_pending) HIPCHK(hipStreamWaitEvent(g->stream, g->ev_bulk, 0));
+            CHK(launch_gemm_nt(g, bulk(oe, oe, rem, nxt)));
+            if (rest > 0) {
+                CHK(launch_gemm_nt(g, bulk(oe + nxt, oe + nxt, rest, rest), 1, g->side_stream));
+                HIPCHK(hipEventRecord(g->ev_bulk, g->side_stream));
+                side_pending = true;
+            } else {
+                side_pending = false;
+            }
         }
     }
+    if (side_pending) HIPCHK(hipStreamWaitEvent(g->stream, g->ev_bulk, 0));
     if (T > 1) {
         hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
         HIPCHK(hipGetLastError());
@@ -591,7 +616,13 @@ int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohi
     g->d = (int)d;
     g->kern = kernel_id;
     for (int k = 0; k < DMAX; ++k) g->loglen[k] = 0.0;
-    hipError_t e = hipStreamCreateWithFlags(&g->own_stream, hipStreamNonBlocking);
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hipError_t e = hipStreamCreateWithPriority(&g->own_stream, hipStreamNonBlocking, prio_hi);  // critical path of the factorisation
+    // (reserving CUs for the critical stream with a CU mask on the side stream was measured and does not help)
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->side_stream, hipStreamNonBlocking, prio_lo);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_panels, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_bulk, hipEventDisableTiming);
     if (e != hipSuccess) { delete g; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
     g->stream = g->own_stream;
     if (hipMalloc(&g->dinfo, sizeof(int)) != hipSuccess || hipMalloc(&g->dmll, 8) != hipSuccess ||
@@ -616,6 +647,9 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dbest) hipFree(g->dbest);
     if (g->dinfo) hipFree(g->dinfo);
     t_reset(g);
+    if (g->side_stream) { hipStreamSynchronize(g->side_stream); hipStreamDestroy(g->side_stream); }
+    if (g->ev_panels) hipEventDestroy(g->ev_panels);
+    if (g->ev_bulk) hipEventDestroy(g->ev_bulk);
     if (g->own_stream) hipStreamDestroy(g->own_stream);
     delete g;
 }

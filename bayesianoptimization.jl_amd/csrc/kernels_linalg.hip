@@ -135,7 +135,6 @@ __device__ __forceinline__ void inv_level(double* a, int tid) {
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[r][j] = 0.0;
-#pragma unroll 2
     for (int k0 = 0; k0 < 8 * ib0 + 16; k0 += 4) {   // W22 lower-triangular: nothing beyond the second block-row's diagonal
         const int k = k0 + kq;
         double wv[2], sv[NB];
