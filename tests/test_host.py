@@ -128,3 +128,89 @@ def test_batched_lbfgs_on_a_known_concave_problem():
 
     f, X = A._batched_lbfgs_ascent(fg, rng.uniform(-1, 1, (d, R)), lb, ub, maxeval=200)
     np.testing.assert_allclose(X, np.clip(C_, -1, 1), atol=1e-6)     # box-constrained maximiser = projection of c
+
+
+# ---- acquire_max on the host, with the ORACLE standing in for the device model (tests may use the oracle) ------------
+class OracleModel:
+    """Implements the slice of the ElasticGPE interface that acquisition.py touches (score / score_grad / thompson /
+    predict_f / nobs / dim / x / y) on top of the CPU oracle, so the host-side search logic runs without a GPU."""
+
+    def __init__(self, orc, X, y, ll, lsig=0.0, lnoise=-2.0, beta=0.0):
+        self.orc, self.X, self._y, self.ll, self.lsig, self.beta = orc, X, y, np.asarray(ll, float), lsig, beta
+        self.L, self.al = orc.fit(X, y, ll, lsig, lnoise, beta)
+        self.dim = X.shape[1]
+        self.calls = []
+
+    y = property(lambda s: s._y)
+    x = property(lambda s: np.asfortranarray(s.X.T))
+    nobs = property(lambda s: len(s._y))
+
+    def _pad(self, params):
+        return list(params) if len(params) else [0.0]
+
+    def predict_f(self, xs):
+        xs = np.asarray(xs, float)
+        xs = xs.reshape(self.dim, -1)
+        return self.orc.predict(self.X, self.ll, self.lsig, self.beta, self.L, self.al, np.ascontiguousarray(xs.T))
+
+    def score(self, acq, params, xs, want_scores=True):
+        xs = np.asarray(xs, float).reshape(self.dim, -1)
+        self.calls.append(("score", xs.shape[1]))
+        sc, bv, bi = self.orc.score(self.X, self.ll, self.lsig, self.beta, self.L, self.al, acq, self._pad(params),
+                                    np.ascontiguousarray(xs.T))
+        return sc, bv, bi
+
+    def score_grad(self, acq, params, xs):
+        xs = np.asarray(xs, float).reshape(self.dim, -1)
+        self.calls.append(("score_grad", xs.shape[1]))
+        sc, g = self.orc.score_grad(self.X, self.ll, self.lsig, self.beta, self.L, self.al, acq, self._pad(params),
+                                    np.ascontiguousarray(xs.T))
+        return sc, np.asfortranarray(g.T)
+
+
+def test_acquire_max_reference_known_answer_on_host(orc):           # reference test/acquisition.jl:2,11-12
+    m = OracleModel(orc, np.array([[1.0]]), np.array([2.0]), [1.0])  # GPE([1.0],[2.0],MeanZero(),SEIso(1.0,0.0))
+    opts = {**bohip.defaultoptions(type(m), bohip.MaxMean), "restarts": 10}
+    maxf, maxx = bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], opts, np.random.default_rng(0))
+    assert maxx == pytest.approx([1.0], abs=1e-5)
+    assert maxf == pytest.approx(2 / (1 + math.exp(-4.0)), rel=1e-9)
+    assert all(c[0] == "score_grad" and c[1] == 10 for c in m.calls)   # all 10 restarts ascend in lock-step: one call per evaluation
+
+
+def test_acquire_max_gradient_free_and_bounds(orc):
+    rng = np.random.default_rng(4)
+    X = rng.random((30, 2)) * 2 - 1
+    y = -((X - 0.3) ** 2).sum(1)
+    m = OracleModel(orc, X, y, [-0.5, -0.5], 0.0, -3.0, float(y.mean()))
+    ei = bohip.ExpectedImprovement()
+    f0, x0 = bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="GN_DIRECT_L", restarts=1, maxeval=500), np.random.default_rng(1))
+    assert ei.tau == y.max()                                            # setparams! ran (src/acquisition.jl:30)
+    assert m.calls[-1] == ("score", 500)                                # derivative-free: maxeval candidates in ONE batch
+    f1, x1 = bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="LD_LBFGS", restarts=16, maxeval=60), np.random.default_rng(1))
+    assert f1 >= f0 * 0.999                                             # ascent from 16 starts is at least as good as 500 samples
+    assert np.all(x1 >= -1) and np.all(x1 <= 1)
+    # the maximiser of a tight box sits on the bound and the returned point respects it
+    f2, x2 = bohip.acquire_max(bohip.MaxMean(), m, [0.6, 0.6], [1.0, 1.0], dict(method="LD_LBFGS", restarts=4, maxeval=60),
+                               np.random.default_rng(2))
+    assert x2 == pytest.approx([0.6, 0.6], abs=1e-6)
+
+
+def test_acquire_max_empty_model_returns_reference_initial_state():
+    class Empty:
+        nobs, dim = 0, 2
+        y = np.zeros(0)
+        x = np.zeros((2, 0))
+    maxf, maxx = bohip.acquire_max(bohip.UpperConfidenceBound(), Empty(), [-1.0, 0.0], [1.0, 2.0], dict(restarts=3))
+    assert maxf == -math.inf and list(maxx) == [-1.0, 0.0]              # maxf = -Inf, maxx = lowerbounds (src/acquisition.jl:55-56)
+
+
+def test_mutual_information_gamma_update(orc):                          # src/acquisitionfunctions.jl:131-140
+    rng = np.random.default_rng(8)
+    X = rng.random((12, 2)); y = rng.random(12)
+    m = OracleModel(orc, X, y, [-0.3, -0.3])
+    mi = bohip.MutualInformation()
+    _, s2_last = m.predict_f(X[-1])
+    bohip.setparams_(mi, m)
+    assert mi.gamma_hat == pytest.approx(float(s2_last[0]), rel=1e-12)  # gamma_hat += sigma^2(x_last)
+    bohip.setparams_(mi, m)
+    assert mi.gamma_hat == pytest.approx(2 * float(s2_last[0]), rel=1e-12)
