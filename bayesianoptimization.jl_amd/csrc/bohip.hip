@@ -169,6 +169,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 }
 
 // ---- GEMM launcher --------------------------------------------------------------------------------
+static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
     hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), st ? st : g->stream, p);
@@ -181,7 +182,9 @@ static int one_time_kernel_setup() {
     if (done) return 0;
     HIPCHK(hipFuncSetAttribute((const void*)k_potf2_inv, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     done = true;
     return 0;
 }
@@ -468,8 +471,12 @@ static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1,
 // V = W K* with the fused epilogue (k_trigemm_sq): one launch per K*' chunk.
 static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t Rpad, int64_t r0, double* VT) {
     const int CT = (int)((ncand + CTILE - 1) / CTILE), n_local = (CT + 7) / 8;
-    hipLaunchKernelGGL(k_trigemm_sq, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, g->dW, g->ld,
-                       g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+    if (g_ks8)
+        hipLaunchKernelGGL(k_trigemm_sq<2>, dim3(8 * n_local * T), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+    else
+        hipLaunchKernelGGL(k_trigemm_sq<1>, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
     HIPCHK(hipGetLastError());
     return 0;
 }

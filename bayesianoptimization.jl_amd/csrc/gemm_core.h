@@ -155,6 +155,94 @@ __device__ __forceinline__ void gemm_tile_loop_glds3(const double* __restrict__ 
     }
 }
 
+// ---- 8-wave variant: intra-workgroup split of the contraction index ------------------------------
+// Waves 0-3 take the first half (8 of 16 contraction indices) of every chunk, waves 4-7 the second half,
+// same 128 x 64 output tile; partial accumulators are added through LDS at the end.  Per SIMD this puts
+// 4 waves (2 workgroups x 2) instead of 2 behind the matrix pipe, so a wave stalled in VMEM issue /
+// barrier / LDS latency is far more likely to be covered.  Each wave issues 3 of the chunk's 24 DMA pieces.
+// Measured on k_trigemm_sq (C2): 0.69 ms vs 0.71 ms for the 4-wave loop; a 16-wave 4-way split drops to one
+// workgroup per CU (102 VGPRs x 16 waves) and is slower (0.77 ms).
+constexpr int GEMM_THREADS_8 = 512;
+template <int NJ>
+__device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict__ A, int64_t lda,
+                                                        const double* __restrict__ B, int64_t ldb, int kc_begin,
+                                                        int kc_end, double* smem, double (&acc)[8][NJ],
+                                                        int active_rows = TILE) {
+    static_assert(NJ == 4, "piece distribution below assumes 16 + 8 DMA pieces per chunk");
+    constexpr int AT = TILE * GL_ROW, BT = 16 * NJ * GL_ROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int khalf = wave >> 2, w4 = wave & 3, wr = w4 >> 1, wc = w4 & 1;
+    double* As = smem;             // [3][128][16]
+    double* Bs = smem + 3 * AT;    // [3][64][16]
+    if (kc_begin >= kc_end) return;
+    // DMA pieces (8 rows x 128 B each): A has 16, B has 8; wave w issues pieces w, w + 8 (A) and 16 + w (B)
+    const int prow = lane >> 3, sseg = (lane & 7) ^ (lane >> 3);
+    const double* a_src0 = A + (int64_t)(wave * 8 + prow) * lda + sseg * 2;
+    const double* a_src1 = A + (int64_t)((wave + 8) * 8 + prow) * lda + sseg * 2;
+    const double* b_src = B + (int64_t)(wave * 8 + prow) * ldb + sseg * 2;
+    double* a_dst0 = As + wave * 8 * GL_ROW;
+    double* a_dst1 = As + (wave + 8) * 8 * GL_ROW;
+    double* b_dst = Bs + wave * 8 * GL_ROW;
+    auto issue = [&](int kc, int buf) {
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a_src0 + (int64_t)kc * KC), (lds_void_ptr)(a_dst0 + buf * AT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a_src1 + (int64_t)kc * KC), (lds_void_ptr)(a_dst1 + buf * AT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(b_src + (int64_t)kc * KC), (lds_void_ptr)(b_dst + buf * BT), 16, 0, 0);
+    };
+    const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
+    const int r7a = 4 * (b >> 1) + t, r7b = 4 * (b & 1) + t;
+    const int oa = ((4 * khalf + k) ^ r7a) << 1, ob = ((4 * khalf + k) ^ r7b) << 1;
+    const int a_frag = (wr * 64 + r7a) * GL_ROW + oa, b_frag = (wc * 8 * NJ + r7b) * GL_ROW + ob;
+    const bool wave_active = wr * 64 < active_rows;
+    issue(kc_begin, 0);
+    if (kc_begin + 1 < kc_end) {
+        issue(kc_begin + 1, 1);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        const int nxt2 = cur == 0 ? 2 : cur - 1;
+        const bool more2 = kc + 2 < kc_end;
+        if (more2) issue(kc + 2, nxt2);
+        if (wave_active) {
+            d2 av[8], bv[NJ];
+            const double* ap = As + cur * AT + a_frag;
+            const double* bp = Bs + cur * BT + b_frag;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const d2*>(ap + i * 8 * GL_ROW);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const d2*>(bp + j * 8 * GL_ROW);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_pair<NJ>(av, bv, acc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    // add the second half's partial accumulators into the first half's (through LDS: 32 doubles per lane)
+    double* xch = smem;  // 256 lanes x 32 doubles = 64 KB <= staging area
+    if (khalf == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xch[(i * NJ + j) * 256 + (tid & 255)] = acc[i][j];
+    }
+    __syncthreads();
+    if (khalf == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] += xch[(i * NJ + j) * 256 + tid];
+    }
+    __syncthreads();
+}
+
 // Where this lane's accumulator acc[mi][nj] lives inside the 128 x (16 NJ) workgroup tile.
 __device__ __forceinline__ int acc_row(int lane, int wr, int mi) {
     return wr * 64 + 8 * mi + 4 * (((lane >> 2) & 3) >> 1) + (lane >> 4);

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ X, int
 // Output: q_part[rt][r] = sum over the tile's rows of v^2 (fixed summation order -> deterministic),
 //         mu_raw[r] = alpha' k*_r taken from the row of W that stores alpha (alpha_row).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
+template <int KS>  // 1: 4 waves; 2: 8 waves, contraction index halved inside the workgroup (default)
+__global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
                                                                 const double* __restrict__ KsT, int64_t ldk,
                                                                 int T, int CT, int64_t alpha_row,
                                                                 double* __restrict__ q_part, int64_t ldq,
@@ -80,11 +81,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0;
-    gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0, (rt + 1) * (TILE / KC),
-                             smem, acc, (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE));  // rows past alpha' are padding
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    const int active_rows = (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE);  // rows past alpha' are padding
+    if constexpr (KS == 2)
+        gemm_tile_loop_glds3_ks<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+                                    (rt + 1) * (TILE / KC), smem, acc, active_rows);
+    else
+        gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+                                 (rt + 1) * (TILE / KC), smem, acc, active_rows);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = (wave & 3) >> 1, wc = wave & 1;
     __syncthreads();     // (the raw-barrier loops end on s_barrier; make the reuse of smem below explicit)
     double* red = smem;  // [2][CW]
+    if (wave < 4) {
     const int64_t row_base = (int64_t)rt * TILE;
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
@@ -105,6 +112,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trigemm_sq(const double* __
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         if (lane < 8) red[wr * CW + wc * 8 * NJ + 8 * nj + lane] = s;
+    }
     }
     __syncthreads();
     if (threadIdx.x < CW)
