@@ -172,7 +172,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), st ? st : g->stream, p);
+    hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), st ? st : g->stream, p);
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -381,7 +381,7 @@ struct GemmNTParams {
     int row_t0, row_ts, col_t0, col_ts, total_t;
 };
 
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_nt(GemmNTParams p) {
+__global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int ti = blockIdx.x / p.nt64, tj = blockIdx.x % p.nt64, z = blockIdx.y;
     if (p.diag_skip && p.col0 + CTILE * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) return;
@@ -395,9 +395,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_nt(GemmNTParams p) {
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    gemm_tile_loop_glds3<4>(p.A + z * p.zA + (int64_t)ti * TILE * p.lda, p.lda, p.B + z * p.zB + (int64_t)tj * CTILE * p.ldb,
-                            p.ldb, kb, ke, smem, acc);
+    gemm_tile_loop_glds3_ks<4>(p.A + z * p.zA + (int64_t)ti * TILE * p.lda, p.lda, p.B + z * p.zB + (int64_t)tj * CTILE * p.ldb,
+                               p.ldb, kb, ke, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    if (wave >= 4) return;  // waves 4-7 only contributed partial sums (already folded into waves 0-3)
     double* C = p.C + z * p.zC + (int64_t)ti * TILE * p.ldc + (int64_t)tj * CTILE;
     double* CT = p.CT ? p.CT + z * p.zCT + (int64_t)tj * CTILE * p.ldct + (int64_t)ti * TILE : nullptr;
 #pragma unroll
