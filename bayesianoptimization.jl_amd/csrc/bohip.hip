@@ -46,8 +46,9 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 static_assert(sizeof(bohip_best) == sizeof(Best), "record layout");
-static constexpr int APP_KSPLIT = 32;
-static constexpr int APP_ROWS = APPEND_PMAX + (APPEND_PMAX / APPEND_CHUNK) * APP_KSPLIT * APPEND_CHUNK;
+static constexpr int APP_UT_ROW0 = APPEND_PMAX;            // rows [0, 32): V' / L21;  rows [32, 64): U' / T = L21 W11
+static constexpr int APP_ROWS = APP_UT_ROW0 + APPEND_PMAX;
+static_assert(SMALL_R <= APPEND_PMAX, "small-batch V' rows share the append's row area");
 
 struct StageTimer {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
@@ -77,8 +78,13 @@ struct bohip_gp {
     int64_t q_cap = 0, r_cap = 0, xs_cap = 0;
     Best *dblock_best = nullptr, *dbest = nullptr;
     int64_t bb_cap = 0;
+    double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
+    int64_t grad_cap = 0;
+    Best* dthompson = nullptr; // S arg-max records
+    int64_t thompson_cap = 0;
     // bookkeeping
     int64_t pivot = 0, refits = 0, appends = 0;
+    int q_tiles = 0;  // number of q_part rows the last posterior pass produced (T, or 1 on the small-batch path)
     bool timing = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> tev;
     std::vector<std::string> tnames;
@@ -194,7 +200,7 @@ static int compute_alpha(bohip_gp* g) {
     const int64_t N = g->n;
     hipLaunchKernelGGL(k_sub_mean, dim3((N + 255) / 256), dim3(256), 0, g->stream, g->dy, g->beta, N, g->dr);
     hipLaunchKernelGGL(k_trimv, dim3((N + 3) / 4), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dr, g->dt);
-    const int nsplit = 16;  // dApp doubles as the [nsplit][ld] partial buffer (APP_ROWS >= 16)
+    const int nsplit = 16;  // dApp doubles as the [nsplit][ld] partial buffer (APP_ROWS = 64 >= 16)
     hipLaunchKernelGGL(k_trimv_t_part, dim3((N + 63) / 64, nsplit), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dt, nsplit,
                        g->dApp, g->ld);
     hipLaunchKernelGGL(k_sum_parts, dim3((N + 255) / 256), dim3(256), 0, g->stream, g->dApp, g->ld, nsplit, N, g->dalpha);
@@ -362,8 +368,8 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
     t_begin(g, "append_L21");
     for (int ch = 0; ch < nch; ++ch) {
         const int P = (int)std::min<int64_t>(APPEND_CHUNK, p - ch * APPEND_CHUNK);
-        hipLaunchKernelGGL(k_rows_trimv, dim3((N0 + 3) / 4), dim3(256), 0, g->stream, g->dW, ld, N0,
-                           g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, g->dApp + (int64_t)ch * APPEND_CHUNK * ld, ld);
+        hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)N0), dim3(256), 0, g->stream, g->dW, ld, N0,
+                           g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, g->dApp + (int64_t)ch * APPEND_CHUNK * ld, ld, 0);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy2DAsync(g->dL + N0 * ld, ld * 8, g->dApp, ld * 8, N0 * 8, p, hipMemcpyDeviceToDevice, g->stream));
@@ -373,15 +379,13 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "append_W21");
-    double* part = g->dApp + (int64_t)APPEND_PMAX * ld;
+    double* Tm = g->dApp + (int64_t)APP_UT_ROW0 * ld;   // T = L21 W11, row-wise on W' (k >= c)
     for (int ch = 0; ch < nch; ++ch) {
         const int P = (int)std::min<int64_t>(APPEND_CHUNK, p - ch * APPEND_CHUNK);
-        hipLaunchKernelGGL(k_rows_times_W, dim3((N0 + 255) / 256, APP_KSPLIT), dim3(256), 0, g->stream, g->dW, ld, N0,
-                           g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, APP_KSPLIT,
-                           part + (int64_t)ch * APP_KSPLIT * APPEND_CHUNK * ld, ld);
+        hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)N0), dim3(256), 0, g->stream, g->dWT, ld, N0,
+                           g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, Tm + (int64_t)ch * APPEND_CHUNK * ld, ld, 1);
     }
-    hipLaunchKernelGGL(k_apply_w22, dim3((N0 + 255) / 256), dim3(256), 0, g->stream, g->dW, g->dWT, ld, N0, (int)p, part, ld,
-                       APP_KSPLIT, nch);
+    hipLaunchKernelGGL(k_apply_w22, dim3((N0 + 255) / 256), dim3(256), 0, g->stream, g->dW, g->dWT, ld, N0, (int)p, Tm, ld);
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "alpha");
@@ -482,22 +486,64 @@ static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t 
 }
 
 // posterior pass over all R candidates: fills dq (partials) and dmu_raw.  VT optional (chunk-local).
+template <int DT>
+static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, int64_t Npad, const KernelHyper& hp);
+static int launch_kstar_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, int64_t Npad, const KernelHyper& hp) {
+    if (g->d <= 2) launch_kstar<2>(g, dXs, r0, r1, Npad, hp);
+    else if (g->d <= 4) launch_kstar<4>(g, dXs, r0, r1, Npad, hp);
+    else if (g->d <= 8) launch_kstar<8>(g, dXs, r0, r1, Npad, hp);
+    else if (g->d <= 16) launch_kstar<16>(g, dXs, r0, r1, Npad, hp);
+    else if (g->d <= 32) launch_kstar<32>(g, dXs, r0, r1, Npad, hp);
+    else launch_kstar<64>(g, dXs, r0, r1, Npad, hp);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Small-batch posterior (R <= SMALL_R): V' rows into dApp[0..R), q and mu_raw; optionally U' = V' W into dApp[APP_UT_ROW0..).
+static int small_posterior(bohip_gp* g, const double* dXs, int64_t R, bool want_u) {
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), ld = g->ld;
+    const KernelHyper hp = make_hyper(g);
+    t_begin(g, "kstar");
+    CHK(launch_kstar_any(g, dXs, 0, R, Npad, hp));
+    t_end(g);
+    t_begin(g, "small_V");
+    const int nch = (int)((R + APPEND_CHUNK - 1) / APPEND_CHUNK);
+    for (int ch = 0; ch < nch; ++ch) {
+        const int P = (int)std::min<int64_t>(APPEND_CHUNK, R - ch * APPEND_CHUNK);
+        // rows 0..N of W (row N carries alpha'): V'[r][j] = sum_{k<=j} W[j][k] K*'[r][k]
+        hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)(N + 1)), dim3(256), 0, g->stream, g->dW, ld, N + 1,
+                           g->dKsT + (int64_t)ch * APPEND_CHUNK * ld, ld, P, g->dApp + (int64_t)ch * APPEND_CHUNK * ld, ld, 0);
+    }
+    hipLaunchKernelGGL(k_small_finish, dim3((unsigned)R), dim3(256), 0, g->stream, g->dApp, ld, N, g->dq, g->dmu_raw);
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    g->q_tiles = 1;
+    if (want_u) {
+        t_begin(g, "small_U");
+        for (int ch = 0; ch < nch; ++ch) {  // U'[r][c] = sum_{k>=c} W'[c][k] V'[r][k]
+            const int P = (int)std::min<int64_t>(APPEND_CHUNK, R - ch * APPEND_CHUNK);
+            hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)N), dim3(256), 0, g->stream, g->dWT, ld, N,
+                               g->dApp + (int64_t)ch * APPEND_CHUNK * ld, ld, P,
+                               g->dApp + (int64_t)(APP_UT_ROW0 + ch * APPEND_CHUNK) * ld, ld, 1);
+        }
+        HIPCHK(hipGetLastError());
+        t_end(g);
+    }
+    return 0;
+}
+
 static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
     CHK(one_time_kernel_setup());
+    if (R <= SMALL_R) return small_posterior(g, dXs, R, false);
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: 96-wide tile overrun
     const int T = (int)(Npad / TILE);
+    g->q_tiles = T;
     const KernelHyper hp = make_hyper(g);
     const int64_t rc = g->kst_rows;
     for (int64_t r0 = 0; r0 < R; r0 += rc) {
         const int64_t r1 = std::min(R, r0 + rc);
         t_begin(g, "kstar");
-        if (g->d <= 2) launch_kstar<2>(g, dXs, r0, r1, Npad, hp);
-        else if (g->d <= 4) launch_kstar<4>(g, dXs, r0, r1, Npad, hp);
-        else if (g->d <= 8) launch_kstar<8>(g, dXs, r0, r1, Npad, hp);
-        else if (g->d <= 16) launch_kstar<16>(g, dXs, r0, r1, Npad, hp);
-        else if (g->d <= 32) launch_kstar<32>(g, dXs, r0, r1, Npad, hp);
-        else launch_kstar<64>(g, dXs, r0, r1, Npad, hp);
-        HIPCHK(hipGetLastError());
+        CHK(launch_kstar_any(g, dXs, r0, r1, Npad, hp));
         t_end(g);
         t_begin(g, "trigemm_sq");
         CHK(launch_trigemm(g, T, r1 - r0, N, Rpad, r0, nullptr));
@@ -523,7 +569,7 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     const int T = (int)(Npad / TILE);
     const int nb = (int)((R + 255) / 256);
     t_begin(g, "score");
-    hipLaunchKernelGGL(k_score, dim3(nb), dim3(256), 0, g->stream, g->dq, Rpad, T, g->dmu_raw, R,
+    hipLaunchKernelGGL(k_score, dim3(nb), dim3(256), 0, g->stream, g->dq, Rpad, g->q_tiles, g->dmu_raw, R,
                        std::exp(2.0 * g->logsig), g->beta, ap, d_mu, d_var, d_score, d_best ? g->dblock_best : nullptr);
     if (d_best) hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, g->stream, g->dblock_best, nb, d_best);
     HIPCHK(hipGetLastError());
@@ -533,9 +579,20 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
 
 template <int DT>
 static void launch_grad(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, const KernelHyper& hp, const AcqParams& ap,
-                        double* d_grad) {
-    hipLaunchKernelGGL(k_grad_finish<DT>, dim3((r1 - r0 + 3) / 4), dim3(256), 0, g->stream, g->dX, g->n, dXs, r0, r1, hp,
-                       g->dalpha, g->dUT, g->ld, g->dmu, g->dvar, 0.0, ap, d_grad);
+                        double* d_grad, const double* UT) {
+    hipLaunchKernelGGL(k_grad_finish<DT>, dim3((unsigned)(r1 - r0)), dim3(256), 0, g->stream, g->dX, g->n, dXs, r0, r1, hp,
+                       g->dalpha, UT, g->ld, g->dmu, g->dvar, ap, d_grad);
+}
+static int launch_grad_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, const KernelHyper& hp, const AcqParams& ap,
+                           double* d_grad, const double* UT) {
+    if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad, UT);
+    else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad, UT);
+    else if (g->d <= 8) launch_grad<8>(g, dXs, r0, r1, hp, ap, d_grad, UT);
+    else if (g->d <= 16) launch_grad<16>(g, dXs, r0, r1, hp, ap, d_grad, UT);
+    else if (g->d <= 32) launch_grad<32>(g, dXs, r0, r1, hp, ap, d_grad, UT);
+    else launch_grad<64>(g, dXs, r0, r1, hp, ap, d_grad, UT);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // A8: scores + gradients for R candidates (device pointers).  Per chunk: K*' -> V' (trigemm, V stored)
@@ -545,7 +602,6 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
     CHK(ensure_fresh(g));
     CHK(ensure_score_scratch(g, R));
-    CHK(ensure_grad_scratch(g));
     CHK(one_time_kernel_setup());
     AcqParams ap{acq_id, 0.0, 0.0};
     if (acq_params) {
@@ -557,16 +613,21 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: 96-wide tile overrun
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
+    if (R <= SMALL_R) {  // the reference's default: a handful of L-BFGS restarts per call
+        CHK(small_posterior(g, dXs, R, true));
+        t_begin(g, "score+grad");
+        hipLaunchKernelGGL(k_score, dim3(1), dim3(256), 0, g->stream, g->dq, Rpad, 1, g->dmu_raw, R, std::exp(2.0 * g->logsig),
+                           g->beta, ap, g->dmu, g->dvar, d_score, (Best*)nullptr);
+        CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld));
+        t_end(g);
+        return 0;
+    }
+    CHK(ensure_grad_scratch(g));
     const int64_t rc = g->kst_rows;
     for (int64_t r0 = 0; r0 < R; r0 += rc) {
         const int64_t r1 = std::min(R, r0 + rc);
         t_begin(g, "kstar");
-        if (g->d <= 2) launch_kstar<2>(g, dXs, r0, r1, Npad, hp);
-        else if (g->d <= 4) launch_kstar<4>(g, dXs, r0, r1, Npad, hp);
-        else if (g->d <= 8) launch_kstar<8>(g, dXs, r0, r1, Npad, hp);
-        else if (g->d <= 16) launch_kstar<16>(g, dXs, r0, r1, Npad, hp);
-        else if (g->d <= 32) launch_kstar<32>(g, dXs, r0, r1, Npad, hp);
-        else launch_kstar<64>(g, dXs, r0, r1, Npad, hp);
+        CHK(launch_kstar_any(g, dXs, r0, r1, Npad, hp));
         t_end(g);
         const int CT = (int)((r1 - r0 + TILE - 1) / TILE);
         t_begin(g, "trigemm_sq+V");
@@ -582,13 +643,7 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
         const int nb = (int)((r1 - r0 + 255) / 256);
         hipLaunchKernelGGL(k_score, dim3(nb), dim3(256), 0, g->stream, g->dq + r0, Rpad, T, g->dmu_raw + r0, r1 - r0,
                            std::exp(2.0 * g->logsig), g->beta, ap, g->dmu + r0, g->dvar + r0, d_score + r0, (Best*)nullptr);
-        if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad);
-        else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad);
-        else if (g->d <= 8) launch_grad<8>(g, dXs, r0, r1, hp, ap, d_grad);
-        else if (g->d <= 16) launch_grad<16>(g, dXs, r0, r1, hp, ap, d_grad);
-        else if (g->d <= 32) launch_grad<32>(g, dXs, r0, r1, hp, ap, d_grad);
-        else launch_grad<64>(g, dXs, r0, r1, hp, ap, d_grad);
-        HIPCHK(hipGetLastError());
+        CHK(launch_grad_any(g, dXs, r0, r1, hp, ap, d_grad, g->dUT));
         t_end(g);
     }
     return 0;
@@ -652,6 +707,8 @@ void bohip_gp_destroy(bohip_gp* g) {
         if (*p) hipFree(*p);
     if (g->dblock_best) hipFree(g->dblock_best);
     if (g->dbest) hipFree(g->dbest);
+    if (g->dgrad) hipFree(g->dgrad);
+    if (g->dthompson) hipFree(g->dthompson);
     if (g->dinfo) hipFree(g->dinfo);
     t_reset(g);
     if (g->side_stream) { hipStreamSynchronize(g->side_stream); hipStreamDestroy(g->side_stream); }
@@ -817,8 +874,13 @@ int bohip_gp_score_grad(bohip_gp* g, int acq_id, const double* acq_params, const
     HIPCHK(hipSetDevice(g->device));
     t_reset(g);
     CHK(ensure_xs(g, R));
-    double* dgrad = nullptr;
-    HIPCHK(hipMalloc(&dgrad, (size_t)R * g->d * 8));
+    if (g->grad_cap < R * g->d) {
+        if (g->dgrad) hipFree(g->dgrad);
+        g->dgrad = nullptr;
+        HIPCHK(hipMalloc(&g->dgrad, (size_t)R * g->d * 8));
+        g->grad_cap = R * g->d;
+    }
+    double* dgrad = g->dgrad;
     HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
     int rc = ensure_score_scratch(g, R);
     if (rc == 0) rc = score_grad_core(g, acq_id, acq_params, g->dXs, R, g->dscore, dgrad);
@@ -828,7 +890,6 @@ int bohip_gp_score_grad(bohip_gp* g, int acq_id, const double* acq_params, const
         if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
         if (e != hipSuccess) rc = fail(BOHIP_E_HIP, hipGetErrorString(e));
     }
-    hipFree(dgrad);
     t_collect(g);
     return rc;
 }
@@ -843,14 +904,18 @@ int bohip_gp_thompson(bohip_gp* g, const double* Xs, int64_t R, int64_t S, uint6
     CHK(ensure_score_scratch(g, R));
     HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
     CHK(score_core(g, BOHIP_ACQ_MAXMEAN, nullptr, g->dXs, R, g->dmu, g->dvar, nullptr, nullptr));
-    Best* dout = nullptr;
-    HIPCHK(hipMalloc(&dout, S * sizeof(Best)));
+    if (g->thompson_cap < S) {
+        if (g->dthompson) hipFree(g->dthompson);
+        g->dthompson = nullptr;
+        HIPCHK(hipMalloc(&g->dthompson, S * sizeof(Best)));
+        g->thompson_cap = S;
+    }
+    Best* dout = g->dthompson;
     t_begin(g, "thompson");
     hipLaunchKernelGGL(k_thompson, dim3(S), dim3(256), 0, g->stream, g->dmu, g->dvar, R, seed, j0, dout);
     t_end(g);
     hipError_t e = hipMemcpyAsync(best, dout, S * sizeof(Best), hipMemcpyDeviceToHost, g->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
-    hipFree(dout);
     if (e != hipSuccess) return fail(BOHIP_E_HIP, hipGetErrorString(e));
     t_collect(g);
     return 0;

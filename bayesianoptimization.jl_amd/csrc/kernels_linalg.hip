@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_mll(const double* __restrict__ L, int64
 // With W = L^-1 resident the new rows are products, not solves:
 //     L21 = K21 W11'                      (k_rows_trimv  : one pass over W, HBM-bound)
 //     L22 = chol(K22 - L21 L21'), W22     (k_schur_chol  : one workgroup)
-//     W21 = -W22 (L21 W11)                (k_rows_times_W: one pass over W, then k_apply_w22)
+//     W21 = -W22 (L21 W11)                (k_rows_trimv on W': one pass, then k_apply_w22)
 // ================================================================================================
 namespace bohip {
 
@@ -542,17 +542,23 @@ __global__ __launch_bounds__(256) void k_cov_rows(const double* __restrict__ X, 
 }
 
 // out[r][j] = sum_{k<=j} W[j][k] * rows[r][k]   for j < N0, r < P (P <= APPEND_CHUNK).
-// One wave per j (coalesced along k), P running sums, fixed-order butterfly.
+// One workgroup per row j: 256 threads stride k (coalesced), P running sums each, fixed-order reduction
+// (wave butterfly, then the four waves in index order) -> bit-deterministic and independent of P.
+// upper != 0: W is an UPPER-triangular K-major matrix (rows of W'), the sum runs over k in [j, N0) instead:
+//     out[r][j] = sum_{k>=j} W'[j][k] * rows[r][k]  ( = (rows W)[r][j] for the lower-triangular W ).
 __global__ __launch_bounds__(256) void k_rows_trimv(const double* __restrict__ W, int64_t ld, int64_t N0,
                                                     const double* __restrict__ rows, int64_t ldr, int P,
-                                                    double* __restrict__ out, int64_t ldo) {
-    const int lane = threadIdx.x & 63;
-    const int64_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                    double* __restrict__ out, int64_t ldo, int upper) {
+    __shared__ double red[4][APPEND_CHUNK];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = blockIdx.x;
     if (j >= N0) return;
     double s[APPEND_CHUNK];
 #pragma unroll
     for (int r = 0; r < APPEND_CHUNK; ++r) s[r] = 0.0;
-    for (int64_t k = lane; k <= j; k += 64) {
+    const int64_t k_lo = upper ? j : 0, k_hi = upper ? N0 : j + 1;
+#pragma unroll 2
+    for (int64_t k = k_lo + threadIdx.x; k < k_hi; k += 256) {
         const double w = W[j * ld + k];
 #pragma unroll
         for (int r = 0; r < APPEND_CHUNK; ++r)
@@ -562,8 +568,10 @@ __global__ __launch_bounds__(256) void k_rows_trimv(const double* __restrict__ W
     for (int r = 0; r < APPEND_CHUNK; ++r) {
         double v = s[r];
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0 && r < P) out[r * ldo + j] = v;
+        if (lane == 0) red[wave][r] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < P) out[threadIdx.x * ldo + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // One workgroup: S = K22 - L21 L21' (p x p), L22 = chol(S), W22 = L22^-1.
@@ -620,50 +628,42 @@ __global__ __launch_bounds__(256) void k_schur_chol(double* __restrict__ L, doub
     }
 }
 
-// part[ks][r][c] = sum_{k in slice ks, k >= c} rows[r][k] * W[k][c]   for c < N0 (thread = column c).
-__global__ __launch_bounds__(256) void k_rows_times_W(const double* __restrict__ W, int64_t ld, int64_t N0,
-                                                      const double* __restrict__ rows, int64_t ldr, int P,
-                                                      int ksplit, double* __restrict__ part, int64_t ldp) {
-    const int64_t c = blockIdx.x * 256 + threadIdx.x;
-    const int ks = blockIdx.y;
-    if (c >= N0) return;
-    const int64_t span = (N0 + ksplit - 1) / ksplit;
-    int64_t k0 = ks * span, k1 = min(N0, k0 + span);
-    if (k0 < c) k0 = c;
-    double s[APPEND_CHUNK];
-#pragma unroll
-    for (int r = 0; r < APPEND_CHUNK; ++r) s[r] = 0.0;
-    for (int64_t k = k0; k < k1; ++k) {
-        const double w = W[k * ld + c];
-#pragma unroll
-        for (int r = 0; r < APPEND_CHUNK; ++r)
-            if (r < P) s[r] += rows[r * ldr + k] * w;
-    }
-#pragma unroll
-    for (int r = 0; r < APPEND_CHUNK; ++r)
-        if (r < P) part[((int64_t)ks * APPEND_CHUNK + r) * ldp + c] = s[r];
-}
-
-// W21[r][c] = -sum_s W22[r][s] * T[s][c],  T[s][c] = sum_ks part[ks][s][c]  (fixed order).
+// W21[r][c] = -sum_{s<=r} W22[r][s] * T[s][c]   with T = L21 W11 (rows of T at Tm, row stride ldt); W21' goes to W' too.
 __global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, double* __restrict__ WT, int64_t ld, int64_t N0, int p,
-                                                   const double* __restrict__ part, int64_t ldp, int ksplit,
-                                                   int nchunks) {
+                                                   const double* __restrict__ Tm, int64_t ldt) {
     const int64_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N0) return;
     double T[APPEND_PMAX];
-    for (int s = 0; s < p; ++s) {
-        const int ch = s / APPEND_CHUNK, rr = s % APPEND_CHUNK;
-        double v = 0.0;
-        for (int ks = 0; ks < ksplit; ++ks) v += part[(((int64_t)ch * ksplit + ks) * APPEND_CHUNK + rr) * ldp + c];
-        T[s] = v;
-    }
-    (void)nchunks;
+    for (int s = 0; s < p; ++s) T[s] = Tm[(int64_t)s * ldt + c];
     for (int r = 0; r < p; ++r) {
         double v = 0.0;
         for (int s = 0; s <= r; ++s) v += W[(N0 + r) * ld + N0 + s] * T[s];
         W[(N0 + r) * ld + c] = -v;
         WT[c * ld + N0 + r] = -v;
     }
+}
+
+// ---- small-batch posterior (R <= SMALL_R): the default use of the reference (10 L-BFGS restarts) scores a handful
+// of candidates per call.  A 128 x 64 MFMA tile would be almost empty and the call latency-bound by the longest K
+// loop; instead V' = K*' W' is computed row-wise like the incremental append (one pass over W per 8 candidates,
+// HBM-bound), k_small_finish turns V' into (sum v^2, mu - beta), and U' = V' W is the same row-wise kernel on W'.
+constexpr int SMALL_R = 32;
+
+// one block per candidate r:  q[r] = sum_{j<N} V'[r][j]^2,  mu_raw[r] = V'[r][N] (the alpha row)
+__global__ __launch_bounds__(256) void k_small_finish(const double* __restrict__ VT, int64_t ldv, int64_t N,
+                                                      double* __restrict__ q, double* __restrict__ mu_raw) {
+    __shared__ double red[256];
+    const int r = blockIdx.x;
+    const double* v = VT + (int64_t)r * ldv;
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < N; j += 256) s += v[j] * v[j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { q[r] = red[0]; mu_raw[r] = v[N]; }
 }
 
 }  // namespace bohip

@@ -251,10 +251,11 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
                                                      KernelHyper hp, const double* __restrict__ alpha,
                                                      const double* __restrict__ UT, int64_t ldu,
                                                      const double* __restrict__ mu, const double* __restrict__ var,
-                                                     double sigma2_minus_q_raw_sign, AcqParams ap,
-                                                     double* __restrict__ grad) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = r_begin + blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                     AcqParams ap, double* __restrict__ grad) {
+    // one workgroup per candidate: 256 threads stride the observations, 2d sums reduced in a fixed order
+    __shared__ double red[4][2 * DT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = r_begin + blockIdx.x;
     if (r >= r_end) return;
     const int d = hp.d;
     const double* xs = Xs + r * d;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < DT; ++k) { gm[k] = 0.0; gv[k] = 0.0; }
     const double* u = UT + (r - r_begin) * ldu;
-    for (int64_t j = lane; j < N; j += 64) {
+    for (int64_t j = threadIdx.x; j < N; j += 256) {
         double t[DT], rr = 0.0;
 #pragma unroll
         for (int k = 0; k < DT; ++k)
@@ -286,18 +287,24 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
                 gv[k] += dk * uj;
             }
     }
-    double dmu, ds2;
-    const double m = mu[r], v = var[r];
-    acq_partials(ap, m, v, dmu, ds2);
-    (void)sigma2_minus_q_raw_sign;
 #pragma unroll
     for (int k = 0; k < DT; ++k)
         if (k < d) {
             double a = gm[k], b = gv[k];
             for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-            // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
-            if (lane == 0) grad[r * d + k] = dmu * a + (v > 0.0 ? ds2 * (-2.0 * b) : 0.0);
+            if (lane == 0) { red[wave][2 * k] = a; red[wave][2 * k + 1] = b; }
         }
+    __syncthreads();
+    if (threadIdx.x < d) {
+        const int k = threadIdx.x;
+        const double a = (red[0][2 * k] + red[1][2 * k]) + (red[2][2 * k] + red[3][2 * k]);
+        const double b = (red[0][2 * k + 1] + red[1][2 * k + 1]) + (red[2][2 * k + 1] + red[3][2 * k + 1]);
+        double dmu, ds2;
+        const double m = mu[r], v = var[r];
+        acq_partials(ap, m, v, dmu, ds2);
+        // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
+        grad[r * d + k] = dmu * a + (v > 0.0 ? ds2 * (-2.0 * b) : 0.0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

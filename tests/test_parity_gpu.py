@@ -88,8 +88,14 @@ def test_batch_equals_single_bitexact_on_device(bohip, acq, params):
     batch, _, _ = m.score(acq, params, x)
     single, _, _ = m.score(acq, params, x[:, :1])
     assert len(batch) == 2 and batch[0] == single[0]
-    big = rng.random((3, 700)); big[:, 333] = x[:, 0]
-    assert m.score(acq, params, big)[0][333] == single[0]          # independent of position / batch size
+    mid = rng.random((3, 20)); mid[:, 13] = x[:, 0]
+    assert m.score(acq, params, mid)[0][13] == single[0]           # independent of position / batch size (same code path)
+    # batches above 32 candidates run on the MFMA engine (different summation order): equal to rounding, and
+    # again bit-identical among themselves wherever the column sits
+    big = rng.random((3, 700)); big[:, 333] = x[:, 0]; big[:, 600] = x[:, 0]
+    sb = m.score(acq, params, big)[0]
+    assert sb[333] == sb[600]
+    assert sb[333] == pytest.approx(single[0], rel=1e-12, abs=1e-14)
 
 
 # ---- seeded synthetic cases against the oracle, every acquisition ------------------------------------
@@ -322,6 +328,30 @@ def test_full_size_c2_properties(bohip, orc):
     mu_o, var_o = orc.predict(X, ll, 0.0, 0.0, L, alpha, Xs[sel], nthreads=8)
     assert np.all(np.abs(var[sel] - var_o) <= var_tol(var_o, N, 1.0))
     assert np.all(np.abs(mu[sel] - mu_o) <= 1e-6 * np.abs(mu_o) + mu_floor(alpha, 1.0))
+
+
+def test_small_batch_path_agrees_with_mfma_path(bohip, orc):
+    """R <= 32 takes the row-wise small-batch kernels (the reference's default: 10 L-BFGS restarts); larger batches
+    the MFMA engine.  Same numbers to rounding, both against the oracle, values and gradients."""
+    X, y, Xs = synth(900, 5, 200, seed=23)
+    ll = np.linspace(-0.7, -0.3, 5)
+    L, alpha = orc.fit(X, y, ll, 0.2, -2.0, 0.1)
+    m = make_model(bohip, X, y, ll, 0.2, -2.0, 0.1)
+    tau = float(y.max())
+    sc_big, g_big = m.score_grad("EI", [tau], Xs.T)                       # MFMA engine
+    for lo, n in [(0, 1), (3, 7), (10, 8), (40, 9), (100, 32)]:           # chunk sizes 1, 7, 8, 8+1, 4x8
+        sc, g = m.score_grad("EI", [tau], Xs[lo:lo + n].T)
+        np.testing.assert_allclose(sc, sc_big[lo:lo + n], rtol=1e-11, atol=1e-14)
+        np.testing.assert_allclose(g, g_big[:, lo:lo + n], rtol=1e-9, atol=1e-12 * np.abs(g_big).max())
+        sc_o, g_o = orc.score_grad(X, ll, 0.2, 0.1, L, alpha, "EI", [tau], Xs[lo:lo + n])
+        np.testing.assert_allclose(sc, sc_o, rtol=1e-6, atol=mu_floor(alpha, math.exp(0.4)) + 1e-12)
+        np.testing.assert_allclose(g.T, g_o, rtol=1e-6, atol=1e-9 * np.abs(g_o).max())
+        mu, var = m.predict_f(Xs[lo:lo + n].T)
+        mu_o, var_o = orc.predict(X, ll, 0.2, 0.1, L, alpha, Xs[lo:lo + n])
+        np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=mu_floor(alpha, math.exp(0.4)))
+        assert np.all(np.abs(var - var_o) <= var_tol(var_o, 900, math.exp(0.4)))
+        _, bv, bi = m.score("EI", [tau], Xs[lo:lo + n].T)
+        assert bi == int(np.argmax(sc)) and bv == sc[bi]
 
 
 def test_candidate_chunking_is_invisible(bohip, orc):
