@@ -383,7 +383,10 @@ struct GemmNTParams {
 
 __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int ti = blockIdx.x / p.nt64, tj = blockIdx.x % p.nt64, z = blockIdx.y;
+    // klo_from_n: the contraction of column tile tj starts at 128 (tj/2) -> low tj = long jobs: issue them first
+    const int ti = p.klo_from_n ? blockIdx.x % p.mt : blockIdx.x / p.nt64;
+    const int tj = p.klo_from_n ? blockIdx.x / p.mt : blockIdx.x % p.nt64;
+    const int z = blockIdx.y;
     if (p.diag_skip && p.col0 + CTILE * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) return;
     if (p.total_t > 0 && (p.row_t0 + z * p.row_ts + ti >= p.total_t || p.col_t0 + z * p.col_ts + (tj >> 1) >= p.total_t)) return;
     int kb = 0, ke = p.kc;
