@@ -34,20 +34,28 @@ def reduce_best(vals, idxs):
 
 
 def allgather_best(rec, offset, world, force_collective=False):
-    """rec: int64[2] tensor holding (value bits, local index) on this rank's device.
+    """rec: int64 tensor on this rank's device holding (value bits, local index[, global column offset]).
+    With the 3-element form the offset travels inside the record, so the exchange is exactly ONE collective and
+    no other device work; with the 2-element form `offset` is added on the device first.
     Returns the global (value, index) on every rank."""
     import torch
 
+    has_off = rec.numel() >= 3
     if world == 1 and not force_collective:
         h = rec.cpu().numpy()
         v = float(h[:1].view(np.float64)[0])
-        return (v, int(h[1])) if h[1] >= 0 else (-math.inf, -1)
+        off = int(h[2]) if has_off else int(offset)
+        return (v, int(h[1]) + off) if h[1] >= 0 else (-math.inf, -1)
     import torch.distributed as dist
 
-    g = rec.clone()
-    g[1] = torch.where(g[1] >= 0, g[1] + offset, g[1])
-    out = torch.empty(world * 2, dtype=torch.int64, device=rec.device)
+    g = rec
+    if not has_off:
+        g = rec.clone()
+        g[1] = torch.where(g[1] >= 0, g[1] + offset, g[1])
+    n = g.numel()
+    out = torch.empty(world * n, dtype=torch.int64, device=rec.device)
     dist.all_gather_into_tensor(out, g)
-    h = out.cpu().numpy().reshape(world, 2)
+    h = out.cpu().numpy().reshape(world, n)
     vals = h[:, 0].copy().view(np.float64)
-    return reduce_best(vals, h[:, 1])
+    idxs = h[:, 1] + h[:, 2] * (h[:, 1] >= 0) if has_off else h[:, 1]
+    return reduce_best(vals, idxs)

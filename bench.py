@@ -135,7 +135,9 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     dXs = torch.from_numpy(np.ascontiguousarray(Xs_local)).to(dev)  # [R][d] = d x R column-major
-    d_best = torch.zeros(2, dtype=torch.int64, device=dev)          # 16-byte (f64 value bits, i64 index) record
+    # (f64 value bits, i64 local index) written by the kernel + this rank's global column offset: the unit of the
+    # single all_gather; the offset rides along so the exchange needs no other device work
+    d_best = torch.tensor([0, -1, lo], dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
     _lib.check(lib.bohip_gp_set_stream(model._h, C.c_void_p(stream.cuda_stream)))
     params = (C.c_double * 2)(tau, 0.0)

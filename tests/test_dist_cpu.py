@@ -26,6 +26,8 @@ for i, v in enumerate(loc):
 rec = torch.zeros(2, dtype=torch.int64)
 rec[0] = int(np.array([best_v]).view(np.int64)[0]); rec[1] = best_i
 v, i = allgather_best(rec, lo, world)
+rec3 = torch.tensor([int(rec[0]), int(rec[1]), lo], dtype=torch.int64)      # offset carried inside the record
+assert allgather_best(rec3, 0, world) == (v, i)
 open(os.path.join(os.environ["BOHIP_OUT"], f"rank{rank}.json"), "w").write(json.dumps({"rank": rank, "val": v, "idx": i}))
 dist.destroy_process_group()
 '''
