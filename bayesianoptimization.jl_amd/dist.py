@@ -59,3 +59,28 @@ def allgather_best(rec, offset, world, force_collective=False):
     vals = h[:, 0].copy().view(np.float64)
     idxs = h[:, 1] + h[:, 2] * (h[:, 1] >= 0) if has_off else h[:, 1]
     return reduce_best(vals, idxs)
+
+
+def allgather_best_many(vals, idxs, offset, world):
+    """Thompson form (BASELINE configs[4]): this rank holds S per-draw records (vals float64[S], idxs int64[S], indices
+    local to its candidate shard starting at global column `offset`).  ONE all_gather of S x 16 bytes per rank, then
+    the same per-draw (value desc, index asc) reduction on every rank.  Tensors may live on any device."""
+    import torch
+
+    S = vals.numel()
+    gidx = torch.where(idxs >= 0, idxs + offset, idxs)
+    rec = torch.stack([vals.view(torch.int64), gidx], dim=1).contiguous()     # [S, 2] int64: value bits, global index
+    if world == 1:
+        h = rec.cpu().numpy().reshape(1, S, 2)
+    else:
+        import torch.distributed as dist
+
+        out = torch.empty(world * S * 2, dtype=torch.int64, device=rec.device)
+        dist.all_gather_into_tensor(out, rec.view(-1))
+        h = out.cpu().numpy().reshape(world, S, 2)
+    v = h[:, :, 0].copy().view(np.float64)
+    best_v = np.empty(S)
+    best_i = np.empty(S, dtype=np.int64)
+    for s_ in range(S):
+        best_v[s_], best_i[s_] = reduce_best(v[:, s_], h[:, s_, 1])
+    return best_v, best_i

@@ -28,6 +28,16 @@ rec[0] = int(np.array([best_v]).view(np.int64)[0]); rec[1] = best_i
 v, i = allgather_best(rec, lo, world)
 rec3 = torch.tensor([int(rec[0]), int(rec[1]), lo], dtype=torch.int64)      # offset carried inside the record
 assert allgather_best(rec3, 0, world) == (v, i)
+# Thompson form: S draws, every rank holds its shard's per-draw winners
+from bohip.dist import allgather_best_many
+S = 5
+mu = scores; sig = np.abs(np.nan_to_num(np.roll(scores, 7))) + 0.1
+zz = np.random.default_rng(99).standard_normal((S, len(scores)))
+f = np.where(np.isnan(mu), -np.inf, mu + sig * zz)
+floc = f[:, lo:hi]
+tv = torch.from_numpy(floc.max(1).copy()); ti = torch.from_numpy(floc.argmax(1).astype(np.int64))
+bv, bi = allgather_best_many(tv, ti, lo, world)
+assert np.array_equal(bi, f.argmax(1)) and np.array_equal(bv, f.max(1))
 open(os.path.join(os.environ["BOHIP_OUT"], f"rank{rank}.json"), "w").write(json.dumps({"rank": rank, "val": v, "idx": i}))
 dist.destroy_process_group()
 '''
