@@ -86,7 +86,9 @@ struct bohip_gp {
     int64_t pivot = 0, refits = 0, appends = 0;
     int q_tiles = 0;  // number of q_part rows the last posterior pass produced (T, or 1 on the small-batch path)
     bool timing = false;
-    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> tev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tpool;  // pooled event pairs
+    size_t tused = 0;
+    std::vector<const char*> tlabel;
     std::vector<std::string> tnames;
     std::vector<double> tms;
 };
@@ -101,35 +103,36 @@ static KernelHyper make_hyper(const bohip_gp* g) {
     return h;
 }
 
-// ---- stage timing (HIP events on the handle's stream) ---------------------------------------------
+// ---- stage timing (HIP events on the handle's stream; the event pairs are pooled, not re-created per call) -------
 static void t_begin(bohip_gp* g, const char* name) {
     if (!g->timing) return;
-    hipEvent_t a, b;
-    hipEventCreate(&a);
-    hipEventCreate(&b);
-    hipEventRecord(a, g->stream);
-    g->tev.push_back({name, {a, b}});
+    if (g->tused == g->tpool.size()) {
+        hipEvent_t a, b;
+        hipEventCreate(&a);
+        hipEventCreate(&b);
+        g->tpool.push_back({a, b});
+    }
+    hipEventRecord(g->tpool[g->tused].first, g->stream);
+    g->tlabel.push_back(name);
+    ++g->tused;
 }
 static void t_end(bohip_gp* g) {
-    if (!g->timing || g->tev.empty()) return;
-    hipEventRecord(g->tev.back().second.second, g->stream);
+    if (!g->timing || g->tused == 0) return;
+    hipEventRecord(g->tpool[g->tused - 1].second, g->stream);
 }
 static void t_reset(bohip_gp* g) {
-    for (auto& e : g->tev) {
-        hipEventDestroy(e.second.first);
-        hipEventDestroy(e.second.second);
-    }
-    g->tev.clear();
+    g->tused = 0;
+    g->tlabel.clear();
 }
 static void t_collect(bohip_gp* g) {
     if (!g->timing) return;
     g->tnames.clear();
     g->tms.clear();
-    for (auto& e : g->tev) {
-        hipEventSynchronize(e.second.second);
+    for (size_t i = 0; i < g->tused; ++i) {
+        hipEventSynchronize(g->tpool[i].second);
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e.second.first, e.second.second);
-        g->tnames.push_back(e.first);
+        hipEventElapsedTime(&ms, g->tpool[i].first, g->tpool[i].second);
+        g->tnames.push_back(g->tlabel[i]);
         g->tms.push_back(ms);
     }
     t_reset(g);
@@ -710,7 +713,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dgrad) hipFree(g->dgrad);
     if (g->dthompson) hipFree(g->dthompson);
     if (g->dinfo) hipFree(g->dinfo);
-    t_reset(g);
+    for (auto& e : g->tpool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (g->side_stream) { hipStreamSynchronize(g->side_stream); hipStreamDestroy(g->side_stream); }
     if (g->ev_panels) hipEventDestroy(g->ev_panels);
     if (g->ev_bulk) hipEventDestroy(g->ev_bulk);
