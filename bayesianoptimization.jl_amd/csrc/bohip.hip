@@ -187,7 +187,11 @@ static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hip
 }
 
 static int one_time_kernel_setup() {
-    static bool done = false;
+    // the >64 KB dynamic-LDS opt-in is a per-device function attribute
+    static bool done_dev[64] = {false};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    bool& done = done_dev[dev & 63];
     if (done) return 0;
     HIPCHK(hipFuncSetAttribute((const void*)k_potf2_inv, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
