@@ -420,7 +420,7 @@ static int ensure_score_scratch(bohip_gp* g, int64_t R) {
     const int64_t Rpad = round_up(std::max<int64_t>(R, 1), TILE);
     const int64_t T = g->ld / TILE;
     const int64_t rc = std::min(chunk_rows(g), Rpad);
-    const int64_t SLACK = TILE;  // 96-wide candidate tiles may overrun a 128-rounded count by < 128 columns
+    const int64_t SLACK = TILE;  // head-room so tile-granular writes past the last candidate stay inside the buffers
     if (g->kst_rows < rc || g->dKsT == nullptr) {
         if (g->dKsT) hipFree(g->dKsT);
         g->dKsT = nullptr;
@@ -542,7 +542,7 @@ static int small_posterior(bohip_gp* g, const double* dXs, int64_t R, bool want_
 static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
     CHK(one_time_kernel_setup());
     if (R <= SMALL_R) return small_posterior(g, dXs, R, false);
-    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: 96-wide tile overrun
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: head-room for tile-granular writes
     const int T = (int)(Npad / TILE);
     g->q_tiles = T;
     const KernelHyper hp = make_hyper(g);
@@ -617,7 +617,7 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
         return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
     }
-    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: 96-wide tile overrun
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: head-room for tile-granular writes
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
     if (R <= SMALL_R) {  // the reference's default: a handful of L-BFGS restarts per call
