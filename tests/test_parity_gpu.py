@@ -157,6 +157,34 @@ def test_empty_and_ragged_inputs(bohip):
         m.append_(np.zeros((3, 2)), np.zeros(3))             # x / y length mismatch
 
 
+def test_c_abi_error_codes_on_device(bohip):
+    """Every misuse returns a status code and a message; nothing aborts, the handle stays usable."""
+    from bohip import _lib
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.bohip_gp_create(2, 16, 0, 99, C.byref(h)) == _lib.E_ARG                 # device ordinal out of range
+    assert lib.bohip_gp_create(2, 16, 0, 0, C.byref(h)) == _lib.OK
+    X = (C.c_double * 4)(0.1, 0.2, 0.7, 0.9); y = (C.c_double * 2)(1.0, 2.0)
+    mu = (C.c_double * 2)(); var = (C.c_double * 2)(); best = _lib.Best()
+    assert lib.bohip_gp_predict(h, X, 2, mu, var) == _lib.E_STATE                      # no observations yet
+    assert b"no observations" in lib.bohip_last_error()
+    assert lib.bohip_gp_append(h, None, None, 2) == _lib.E_ARG
+    assert lib.bohip_gp_append(h, X, y, 2) == _lib.OK
+    assert lib.bohip_gp_score(h, 7, None, X, 2, None, C.byref(best)) == _lib.E_ARG      # unknown acquisition id
+    assert lib.bohip_gp_score(h, _lib.ACQ["EI"], None, X, 2, None, C.byref(best)) == _lib.E_ARG   # EI needs tau
+    assert lib.bohip_gp_predict(h, X, -1, mu, var) == _lib.E_ARG
+    assert lib.bohip_gp_predict(h, X, 2, mu, var) == _lib.OK and var[0] >= 0
+    n = C.c_int64(); d = C.c_int64(); m = C.c_double()
+    assert lib.bohip_gp_dims(h, C.byref(d), C.byref(n)) == _lib.OK and (d.value, n.value) == (2, 2)
+    assert lib.bohip_gp_maxy(h, C.byref(m)) == _lib.OK and m.value == 2.0
+    v = C.c_int64()
+    assert lib.bohip_gp_info(h, 42, C.byref(v)) == _lib.E_ARG
+    assert lib.bohip_gp_info(h, _lib.INFO_CAPACITY, C.byref(v)) == _lib.OK and v.value >= 16
+    lib.bohip_gp_destroy(h)
+    lib.bohip_gp_destroy(None)                                                           # destroy(NULL) is a no-op
+
+
 def test_nan_and_inf_never_win(bohip):
     X, y, Xs = synth(40, 2, 20, seed=4)
     m = make_model(bohip, X, y, [-0.5, -0.5], 0.0, -2.0, 0.0)
