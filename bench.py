@@ -98,11 +98,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
+    if args.gpus > 1 and world != args.gpus and os.environ.get("BOHIP_SHARE_GPU") != "1":
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libbohip has no CPU path")
+    # BOHIP_SHARE_GPU=1 + BOHIP_DIST_BACKEND=gloo: a TEST mode that runs all ranks on GPU 0 and exchanges the records
+    # through gloo, so the sharded N > 1 code path can be checked end-to-end on a single-GPU box.
+    share_gpu = os.environ.get("BOHIP_SHARE_GPU") == "1"
+    backend = os.environ.get("BOHIP_DIST_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("BOHIP_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on 1 GPU
     if use_dist:
@@ -110,7 +116,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import bohip
     from bohip import _lib
@@ -165,7 +174,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
