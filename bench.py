@@ -56,7 +56,11 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
 
     orc = COracle()
     ll = np.full(DIM, np.log(0.5))
-    L, alpha = orc.fit(X, y, ll, 0.0, -2.0, 0.0)
+    cK = orc.build_cK(X, ll, 0.0, -2.0)
+    t0 = time.perf_counter()
+    L = orc.cholesky(cK)                                   # cpu-chol: row-by-row restatement, one thread
+    t_chol = time.perf_counter() - t0
+    alpha = orc.alpha(L, y, 0.0)
     sample = Xs[:budget_candidates]
     t0 = time.perf_counter()
     orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], sample, nthreads=1)
@@ -66,6 +70,10 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
     t0 = time.perf_counter()
     orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], big, nthreads=ncores)
     tn = time.perf_counter() - t0
+    gsample = Xs[:192]
+    t0 = time.perf_counter()
+    orc.score_grad(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], gsample)   # cpu-ref-grad-1t: value + analytic gradient
+    tg = time.perf_counter() - t0
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -80,6 +88,9 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
         "sample": f"first {len(sample)} of the {len(Xs)} candidates of this workload, oracle/gp_oracle.c "
                   f"(restatement of the reference path; the Julia package cannot run here), {t1:.1f} s",
         "allcores": {"value": len(big) / tn, "cores": ncores, "sample": f"{len(big)} candidates, {tn:.1f} s"},
+        "with_gradient": {"value": len(gsample) / tg, "cores": 1, "sample": f"{len(gsample)} candidates, {tg:.1f} s "
+                          "(the reference's default :LD_LBFGS path evaluates value and gradient)"},
+        "cholesky": {"gflops": (N_OBS ** 3 / 3.0) / t_chol / 1e9, "cores": 1, "sample": f"N={N_OBS}, {t_chol:.1f} s"},
         "cpu_model": cpu_model, "host_cores": os.cpu_count(),
     }
 
