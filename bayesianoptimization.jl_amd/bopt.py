@@ -39,8 +39,9 @@ class NoModelOptimizer(ModelOptimizer):                       # :48-49
 
 class MAPGPOptimizer(ModelOptimizer):
     """src/models/gp.jl:20-52: MAP hyper-parameter fit every ``every`` calls.  Each objective evaluation is a
-    full device rebuild (kernel matrix + Cholesky + alpha -> bohip_gp_mll); the search itself stays on the host
-    (bounded L-BFGS-B on central differences -- the reference's analytic dmll is out of scope)."""
+    full device rebuild (kernel matrix + Cholesky + alpha) plus the analytic gradient 1/2 tr((aa' - cK^-1) dcK)
+    formed on the device (bohip_gp_mll_grad); the bounded L-BFGS search itself stays on the host, like the
+    reference's NLopt :LD_LBFGS driving GP.update_target_and_dtarget!."""
 
     def __init__(self, every=10, **kwargs):
         self.i = 0
@@ -95,15 +96,23 @@ def _map_fit(model, opt):                                     # :54-77
             kw["ll"] = x[i:i + nk - 1]; kw["lsigma"] = x[i + nk - 1]
         model.set_params_(**kw)
 
-    def negmll(x):
+    def negmll(x):                                            # f = (x, g) -> ... gp.target, gp.dtarget  (:59-64)
         apply(x)
         try:
-            return -model.mll()
+            m, dn, dm, dk = model.mll_grad()
         except Exception:                                     # not positive definite for these parameters
-            return 1e300
+            return 1e300, np.zeros_like(x)
+        g = []
+        if opt["noise"]:
+            g.append(dn)
+        if opt["domean"] and isinstance(model.mean, MeanConst):
+            g.append(dm)
+        if opt["kern"]:
+            g += dk.tolist()
+        return -m, -np.asarray(g, dtype=float)
 
-    res = minimize(negmll, x0, method="L-BFGS-B", bounds=list(zip(lo, hi)),
-                   options=dict(maxfun=int(opt["maxeval"]), eps=1e-5))
+    res = minimize(negmll, x0, jac=True, method="L-BFGS-B", bounds=list(zip(lo, hi)),
+                   options=dict(maxfun=int(opt["maxeval"])))
     best = res.x if np.isfinite(res.fun) and res.fun < 1e299 else x0
     apply(best)
     model.fit_()

@@ -81,6 +81,8 @@ struct bohip_gp {
     double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
     int64_t grad_cap = 0;
     Best* dthompson = nullptr; // S arg-max records
+    double* ddmll_parts = nullptr;  // per-block partial sums of the marginal-likelihood gradient
+    int64_t dmll_cap = 0;
     int64_t thompson_cap = 0;
     // bookkeeping
     int64_t pivot = 0, refits = 0, appends = 0;
@@ -694,7 +696,7 @@ int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohi
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_bulk, hipEventDisableTiming);
     if (e != hipSuccess) { delete g; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
     g->stream = g->own_stream;
-    if (hipMalloc(&g->dinfo, sizeof(int)) != hipSuccess || hipMalloc(&g->dmll, 8) != hipSuccess ||
+    if (hipMalloc(&g->dinfo, sizeof(int)) != hipSuccess || hipMalloc(&g->dmll, 8 * (DMAX + 4)) != hipSuccess ||
         hipMalloc(&g->dbest, 4096 * sizeof(Best)) != hipSuccess) {
         delete g;
         return fail(BOHIP_E_HIP, "hipMalloc failed");
@@ -716,6 +718,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dbest) hipFree(g->dbest);
     if (g->dgrad) hipFree(g->dgrad);
     if (g->dthompson) hipFree(g->dthompson);
+    if (g->ddmll_parts) hipFree(g->ddmll_parts);
     if (g->dinfo) hipFree(g->dinfo);
     for (auto& e : g->tpool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (g->side_stream) { hipStreamSynchronize(g->side_stream); hipStreamDestroy(g->side_stream); }
@@ -808,6 +811,57 @@ int bohip_gp_mll(bohip_gp* g, double* mll) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(mll, g->dmll, 8, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
+    return 0;
+}
+
+int bohip_gp_mll_grad(bohip_gp* g, double* mll, double* d_lognoise, double* d_mean, double* d_kern) {
+    if (!g || !mll || !d_lognoise || !d_mean || !d_kern) return fail(BOHIP_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(g->device));
+    const int iso = g->kern == KERN_SEISO, nl = iso ? 1 : g->d;
+    if (g->n == 0) {
+        *mll = 0.0; *d_lognoise = 0.0; *d_mean = 0.0;
+        for (int k = 0; k <= nl; ++k) d_kern[k] = 0.0;
+        return 0;
+    }
+    CHK(ensure_fresh(g));
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), ld = g->ld;
+    const int T = (int)(Npad / TILE), NP = g->d + 3;
+    hipLaunchKernelGGL(k_mll, dim3(1), dim3(256), 0, g->stream, g->dL, ld, N, g->dr, g->dalpha, g->dmll);
+    t_begin(g, "kinv");
+    {
+        GemmNTParams p{};  // cK^-1 = W'W, lower 128-tiles only:  (W'W)_ij = sum_{k >= max(i,j)} W'[i][k] W'[j][k]
+        p.A = g->dWT; p.lda = ld; p.B = g->dWT; p.ldb = ld; p.C = g->dS; p.ldc = ld;
+        p.mt = T; p.nt64 = 2 * T; p.kc = T * (TILE / KC); p.alpha = 1.0; p.beta = 0.0;
+        p.klo_from_m = 1; p.klo_from_n = 1; p.diag_skip = 1; p.row0 = 0; p.col0 = 0;
+        CHK(launch_gemm_nt(g, p));
+    }
+    t_end(g);
+    t_begin(g, "dmll_reduce");
+    const int rpb = 32;
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)((N + rpb - 1) / rpb));
+    const int64_t nblocks = (int64_t)grid.x * grid.y;
+    if (g->dmll_cap < nblocks * NP) {
+        if (g->ddmll_parts) HIPCHK(hipFree(g->ddmll_parts));
+        g->ddmll_parts = nullptr; g->dmll_cap = 0;
+        HIPCHK(hipMalloc(&g->ddmll_parts, (size_t)nblocks * NP * 8));
+        g->dmll_cap = nblocks * NP;
+    }
+    const KernelHyper hp = make_hyper(g);
+    const double noise_var = std::exp(2.0 * g->lognoise);
+#define DM(DTV) hipLaunchKernelGGL(k_dmll_parts<DTV>, grid, dim3(256), 0, g->stream, g->dX, N, hp, noise_var, g->dS, ld, \
+                                   g->dalpha, rpb, g->ddmll_parts)
+    if (g->d <= 2) DM(2); else if (g->d <= 4) DM(4); else if (g->d <= 8) DM(8); else if (g->d <= 16) DM(16);
+    else if (g->d <= 32) DM(32); else DM(64);
+#undef DM
+    const int nout = nl + 3;
+    hipLaunchKernelGGL(k_dmll_final, dim3(nout), dim3(256), 0, g->stream, g->ddmll_parts, nblocks, NP, g->d, iso, g->dmll + 1);
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    double h[DMAX + 4];
+    HIPCHK(hipMemcpyAsync(h, g->dmll, 8 * (size_t)(nout + 1), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    *mll = h[0]; *d_lognoise = h[1]; *d_mean = h[2];
+    for (int k = 0; k <= nl; ++k) d_kern[k] = h[3 + k];
     return 0;
 }
 

@@ -502,6 +502,104 @@ __global__ __launch_bounds__(256) void k_mll(const double* __restrict__ L, int64
     if (threadIdx.x == 0) out[0] = red[0] - 0.5 * (double)N * log(2.0 * M_PI);
 }
 
+// ------------------------------------------------------------------------------------------------
+// N2: gradient of the marginal likelihood (role of GaussianProcesses.jl update_target_and_dtarget!, called from
+// optimizemodel!, reference src/models/gp.jl:59-64):   d mll / d theta = 1/2 tr((alpha alpha' - cK^-1) dcK/dtheta).
+// cK^-1 = W'W is one lower-triangular k_gemm_nt on the resident W' (N^3/3 flops on the MFMA engine); this kernel
+// is the single pass over it: thread = column j (coordinates in registers), the block walks rows_per_block rows,
+// entries of K and dK/dll_k are recomputed from X (cheaper than a second N x N buffer).  Per-block partial sums
+// [block][NP], NP = d + 3: {logNoise, beta, ll_0..ll_{d-1}, logsig}; k_dmll_final adds them in a fixed order.
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void k_dmll_parts(const double* __restrict__ X, int64_t N, KernelHyper hp,
+                                                    double noise_var, const double* __restrict__ Kinv, int64_t ld,
+                                                    const double* __restrict__ alpha, int rows_per_block,
+                                                    double* __restrict__ parts) {
+    const int d = hp.d, NP = d + 3;
+    const int64_t j = blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t i1 = min(N, i0 + rows_per_block);
+    double* out = parts + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NP;
+    if ((int64_t)blockIdx.x * 256 > i1 - 1) {   // block entirely above the diagonal
+        for (int k = threadIdx.x; k < NP; k += 256) out[k] = 0.0;
+        return;
+    }
+    double xj[DT], acc[DT], a_sig = 0.0, a_noise = 0.0, a_mean = 0.0;
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+        xj[k] = (j < N && k < d) ? X[j * d + k] : 0.0;
+        acc[k] = 0.0;
+    }
+    const double aj = j < N ? alpha[j] : 0.0;
+    for (int64_t i = i0; i < i1; ++i) {
+        if (j > i) continue;   // (j <= i < N)
+        const double ai = alpha[i];
+        const double G = (ai * aj - Kinv[i * ld + j]) * (i == j ? 0.5 : 1.0);
+        double t[DT], r = 0.0;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+            const double dx = (k < d) ? X[i * d + k] - xj[k] : 0.0;
+            t[k] = (k < d) ? hp.il2[k] * (dx * dx) : 0.0;
+            r += t[k];
+        }
+        double Kij, fac;
+        if (hp.kern == KERN_MAT52ARD) {
+            const double sq = sqrt(5.0) * sqrt(r), e = exp(-sq);
+            Kij = hp.sigma2 * (1.0 + sq + 5.0 / 3.0 * r) * e;
+            fac = 5.0 / 3.0 * hp.sigma2 * (1.0 + sq) * e;
+        } else {
+            Kij = hp.sigma2 * exp(-0.5 * r);
+            fac = Kij;
+        }
+        const double gf = G * fac;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) acc[k] += gf * t[k];
+        a_sig += G * 2.0 * Kij;
+        if (i == j) {
+            a_noise += G * 2.0 * noise_var;   // G carries the 1/2
+            a_mean += ai;
+        }
+    }
+    // block reduction of NP accumulators: wave shuffles, then 4 wave leaders through LDS
+    __shared__ double red[4][DMAX + 3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto wsum = [](double v) {
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    a_noise = wsum(a_noise); a_mean = wsum(a_mean); a_sig = wsum(a_sig);
+#pragma unroll
+    for (int k = 0; k < DT; ++k) acc[k] = wsum(acc[k]);
+    if (lane == 0) {
+        red[wave][0] = a_noise; red[wave][1] = a_mean;
+#pragma unroll
+        for (int k = 0; k < DT; ++k) if (k < d) red[wave][2 + k] = acc[k];
+        red[wave][2 + d] = a_sig;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < NP; k += 256) out[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+// out[k] = sum over blocks of parts[b][k] in a fixed strided order + tree; SEIso folds the d length entries into one.
+// One workgroup per output parameter.
+__global__ __launch_bounds__(256) void k_dmll_final(const double* __restrict__ parts, int64_t nblocks, int NP, int d,
+                                                    int iso, double* __restrict__ out) {
+    __shared__ double red[256];
+    const int k = blockIdx.x;   // output slot
+    // iso: slots are {noise, mean, ll, logsig}: slot 2 gathers part columns 2 .. 2+d-1, slot 3 reads column 2+d
+    int c0 = k, c1 = k + 1;
+    if (iso) { if (k == 2) { c0 = 2; c1 = 2 + d; } else if (k == 3) { c0 = 2 + d; c1 = 3 + d; } }
+    double s = 0.0;
+    for (int64_t b = threadIdx.x; b < nblocks; b += 256)
+        for (int c = c0; c < c1; ++c) s += parts[b * NP + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[k] = red[0];
+}
+
 }  // namespace bohip
 
 // ================================================================================================

@@ -159,6 +159,15 @@ class ElasticGPE:
         check(self._lib.bohip_gp_mll(self._h, C.byref(out)))
         return out.value
 
+    def mll_grad(self):
+        """(mll, dlogNoise, dmean, dkern) -- gp.target / gp.dtarget after update_target_and_dtarget!
+        (reference src/models/gp.jl:61-63); dkern = [dll..., dlsigma] in the kernel's parameter order."""
+        nk = (1 if isinstance(self.kernel, SEIso) else self.dim) + 1
+        m, dn, dm = C.c_double(), C.c_double(), C.c_double()
+        dk = np.empty(nk)
+        check(self._lib.bohip_gp_mll_grad(self._h, C.byref(m), C.byref(dn), C.byref(dm), _ptr(dk)))
+        return m.value, dn.value, dm.value, dk
+
     # -- predict_f / scoring ------------------------------------------------------------------------
     def predict_f(self, xs):
         xs = _cols(xs, self.dim)

@@ -88,6 +88,11 @@ int bohip_gp_get_xy(const bohip_gp *gp, double *X /* d x n, nullable */, double 
 /* log marginal likelihood of the current factor: -0.5 (y-b)'alpha - sum log L_ii - n/2 log 2pi
  * (gp.mll, read by MAP fitting at reference src/models/gp.jl:61-63)                         */
 int bohip_gp_mll(bohip_gp *gp, double *mll);
+/* mll and its analytic gradient w.r.t. the log hyper-parameters, in the reference's get_params order
+ * [logNoise; mean; kernel (loglen..., logsig)] -- the role of GP.update_target_and_dtarget! + gp.dtarget in
+ * optimizemodel! (reference src/models/gp.jl:59-64).  d_kern has d + 1 entries (SEArd, Mat52Ard) or 2 (SEIso).
+ * d mll/d theta = 1/2 tr((alpha alpha' - cK^-1) dcK/dtheta); cK^-1 = W'W is formed on the device.          */
+int bohip_gp_mll_grad(bohip_gp *gp, double *mll, double *d_lognoise, double *d_mean, double *d_kern);
 
 /* ---- mean_var(model, X::Matrix) (reference src/models/gp.jl:8 -> GP.predict_f):
  * Xs d x R column-major; mu, var length R (latent f variance, clamped at 0).                */

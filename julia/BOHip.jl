@@ -44,12 +44,13 @@ mutable struct BOHipGPE
     dim::Int
     x::Matrix{Float64}          # d x n host mirror: the reference reads model.x / model.y directly
     y::Vector{Float64}          # (src/BayesianOptimization.jl:117-119, src/acquisitionfunctions.jl:136)
+    hyper::Vector{Float64}      # [logNoise; mean; loglen...; logsig] = GP.get_params order
     function BOHipGPE(d::Integer; loglen = zeros(d), logsig = 0.0, logNoise = -2.0, mean = 0.0,
                       kernel::Symbol = :SEArd, capacity = 3000, device = 0)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:bohip_gp_create, libbohip), Cint, (Int64, Int64, Cint, Cint, Ref{Ptr{Cvoid}}),
                     d, capacity, KERN[kernel], device, h))
-        m = new(h[], d, zeros(d, 0), Float64[])
+        m = new(h[], d, zeros(d, 0), Float64[], vcat(logNoise, mean, Float64.(loglen), logsig))
         check(ccall((:bohip_gp_set_hyper, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Float64, Float64, Float64),
                     m.handle, Float64.(loglen), logsig, logNoise, mean))
         finalizer(g -> ccall((:bohip_gp_destroy, libbohip), Cvoid, (Ptr{Cvoid},), g.handle), m)
@@ -91,6 +92,30 @@ function BO.acquire_max(a::BO.AbstractAcquisition, m::BOHipGPE, lowerbounds, upp
     starts = BO.latin_hypercube_sampling(lowerbounds, upperbounds, options.restarts)      # src/utils.jl:101-120
     _, maxf, j = score(m, a, starts)
     j == 0 ? (-Inf, lowerbounds) : (maxf, starts[:, j])
+end
+
+# ---- reference src/models/gp.jl:42-77: MAP hyper-parameter fit -------------------------------------------
+# f = (x, g) -> (set_params!; update_target_and_dtarget!; g .= gp.dtarget; gp.target) with the device doing the
+# rebuild, the marginal likelihood and its analytic gradient; parameter order [logNoise; mean; loglen...; logsig].
+function target_and_dtarget!(m::BOHipGPE, x::Vector{Float64}, g::Vector{Float64})
+    d = m.dim
+    check(ccall((:bohip_gp_set_hyper, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Float64, Float64, Float64),
+                m.handle, x[3:2+d], x[3+d], x[1], x[2]))
+    mll = Ref(0.0); dn = Ref(0.0); dm = Ref(0.0); dk = Vector{Float64}(undef, d + 1)
+    check(ccall((:bohip_gp_mll_grad, libbohip), Cint,
+                (Ptr{Cvoid}, Ref{Float64}, Ref{Float64}, Ref{Float64}, Ptr{Float64}), m.handle, mll, dn, dm, dk))
+    g[1] = dn[]; g[2] = dm[]; g[3:end] .= dk
+    m.hyper .= x
+    mll[]
+end
+function BO.optimizemodel!(m::BOHipGPE, options)                                          # :54-77
+    d = m.dim
+    lb = vcat(something(options.noisebounds, [-Inf, Inf])[1], -Inf, something(options.kernbounds, [fill(-Inf, d + 1), fill(Inf, d + 1)])[1])
+    ub = vcat(something(options.noisebounds, [-Inf, Inf])[2], Inf, something(options.kernbounds, [fill(-Inf, d + 1), fill(Inf, d + 1)])[2])
+    opt = BO.NLopt.Opt(options.method, d + 3)
+    BO.NLopt.lower_bounds!(opt, lb); BO.NLopt.upper_bounds!(opt, ub); BO.NLopt.maxeval!(opt, options.maxeval)
+    BO.NLopt.max_objective!(opt, (x, g) -> target_and_dtarget!(m, x, g))
+    BO.NLopt.optimize(opt, copy(m.hyper))
 end
 
 end # module

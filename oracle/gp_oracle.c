@@ -371,6 +371,58 @@ void oracle_thompson(int64_t S, int64_t R, const double *mu, const double *var, 
     }
 }
 
+/* N2: log marginal likelihood and its analytic gradient w.r.t. (logNoise, beta, kernel log-parameters) -- the role of
+ * GaussianProcesses.jl update_target_and_dtarget! called from optimizemodel!, reference src/models/gp.jl:59-64
+ * (the package source is absent from /root/reference; this is the textbook expression, Rasmussen & Williams eq. 5.9):
+ *     mll = -1/2 r'alpha - sum_i log L_ii - N/2 log(2 pi),  r = y - beta,  alpha = cK^-1 r
+ *     d mll / d theta = 1/2 tr((alpha alpha' - cK^-1) dcK/dtheta)
+ *     dcK/dlogNoise = 2 exp(2 logNoise) I;  d mll / d beta = sum_i alpha_i
+ *     SE:    dK_ij/dll_k = K_ij t_k,                      t_k = il2_k (x_ik - x_jk)^2   (SEIso: sum over k)
+ *     Mat52: dK_ij/dll_k = 5/3 s2 (1 + s) exp(-s) t_k,    s = sqrt(5 r);     dK_ij/dlogsig = 2 K_ij
+ * grad layout: [dlogNoise, dbeta, dll_0 .. dll_{nl-1}, dlogsig], nl = d (Ard) or 1 (Iso).  cK^-1 is formed explicitly
+ * column by column (two triangular solves per unit vector): O(N^3), small cases only.
+ * Returns 0 or the failing Cholesky pivot. */
+int64_t oracle_mll_grad(int kern, int64_t d, int64_t N, const double *X, const double *y, const double *loglen,
+                        double logsig, double lognoise, double beta, double *mll, double *grad) {
+    double *cK = (double *)malloc(sizeof(double) * N * N), *Ki = (double *)malloc(sizeof(double) * N * N);
+    double *alpha = (double *)malloc(sizeof(double) * N), *il2 = (double *)malloc(sizeof(double) * d);
+    double *e = (double *)malloc(sizeof(double) * N);
+    oracle_build_cK(kern, d, N, X, loglen, logsig, lognoise, cK);
+    int64_t info = oracle_cholesky(N, cK, N);
+    if (info == 0) {
+        oracle_alpha(N, cK, N, y, beta, alpha);
+        double m = 0.0;
+        for (int64_t i = 0; i < N; ++i) m += -0.5 * (y[i] - beta) * alpha[i] - log(cK[i * N + i]);
+        *mll = m - 0.5 * (double)N * log(2.0 * M_PI);
+        for (int64_t c = 0; c < N; ++c) {
+            for (int64_t i = 0; i < N; ++i) e[i] = (i == c) ? 1.0 : 0.0;
+            oracle_trsv_lower(N, cK, N, e);
+            oracle_trsv_lower_t(N, cK, N, e);
+            for (int64_t i = 0; i < N; ++i) Ki[i * N + c] = e[i];
+        }
+        oracle_il2(kern, d, loglen, il2);
+        const int64_t nl = (kern == KERN_SEISO) ? 1 : d;
+        const double s2 = exp(2.0 * logsig);
+        for (int64_t k = 0; k < nl + 3; ++k) grad[k] = 0.0;
+        for (int64_t i = 0; i < N; ++i) {
+            grad[1] += alpha[i];
+            grad[0] += 0.5 * (alpha[i] * alpha[i] - Ki[i * N + i]) * 2.0 * exp(2.0 * lognoise);
+            for (int64_t j = 0; j <= i; ++j) {
+                const double G = (alpha[i] * alpha[j] - Ki[i * N + j]) * (i == j ? 0.5 : 1.0);
+                const double r = wsqdist(d, X + d * i, X + d * j, il2);
+                const double Kij = cov_from_r(kern, s2, r), fac = -cov_grad_fac(kern, s2, r);
+                for (int64_t k = 0; k < d; ++k) {
+                    const double t = X[d * i + k] - X[d * j + k];
+                    grad[2 + (kern == KERN_SEISO ? 0 : k)] += G * fac * (il2[k] * (t * t));
+                }
+                grad[2 + nl] += G * 2.0 * Kij;
+            }
+        }
+    }
+    free(cK); free(Ki); free(alpha); free(il2); free(e);
+    return info;
+}
+
 int oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -109,6 +109,22 @@ class COracle:
         self.lib.oracle_alpha(C.c_int64(N), _p(L), C.c_int64(L.shape[1]), _p(y), C.c_double(beta), _p(a))
         return a
 
+    def mll_grad(self, X, y, loglen, logsig, lognoise, beta, kern="SEArd"):
+        """(mll, grad) with grad = [dlogNoise, dbeta, dll..., dlogsig] (O(N^3) explicit inverse: small N only)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        N, d = X.shape
+        ll = np.ascontiguousarray(np.broadcast_to(np.asarray(loglen, dtype=np.float64), (d,)))
+        nl = 1 if kern == "SEIso" else d
+        grad = np.empty(nl + 3)
+        mll = C.c_double(0.0)
+        self.lib.oracle_mll_grad.restype = C.c_int64
+        info = self.lib.oracle_mll_grad(C.c_int(KERN[kern]), C.c_int64(d), C.c_int64(N), _p(X), _p(y), _p(ll),
+                                        C.c_double(logsig), C.c_double(lognoise), C.c_double(beta), C.byref(mll), _p(grad))
+        if info != 0:
+            raise np.linalg.LinAlgError(f"not positive definite at pivot {info}")
+        return mll.value, grad
+
     def fit(self, X, y, loglen, logsig, lognoise, beta, kern="SEArd"):
         cK = self.build_cK(X, loglen, logsig, lognoise, kern)
         L = self.cholesky(cK)

@@ -189,3 +189,28 @@ def test_multithreaded_oracle_is_bit_identical(orc):
     b = orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [y.max()], Xs, nthreads=4)
     np.testing.assert_array_equal(a[0], b[0])
     assert a[1:] == b[1:]
+
+
+@pytest.mark.parametrize("kern", ["SEArd", "SEIso", "Mat52Ard"])
+def test_oracle_mll_gradient_matches_central_differences(kern):
+    """oracle_mll_grad (the checker for bohip_gp_mll_grad) against central differences of its own mll."""
+    from oracle.oracle import COracle
+
+    o = COracle()
+    rng = np.random.default_rng(3)
+    N, d = 60, 3
+    X = rng.random((N, d))
+    y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
+    nl = 1 if kern == "SEIso" else d
+    th = np.concatenate([[-1.2, 0.2], rng.normal(-0.5, 0.3, nl), [0.3]])
+
+    def f(t):
+        return o.mll_grad(X, y, t[2:2 + nl] if nl > 1 else t[2], t[2 + nl], t[0], t[1], kern)
+
+    m, g = f(th)
+    fd = np.array([(f(th + 1e-6 * e)[0] - f(th - 1e-6 * e)[0]) / 2e-6 for e in np.eye(len(th))])
+    np.testing.assert_allclose(g, fd, rtol=1e-6, atol=1e-6)
+    # textbook mll from the oracle factor
+    L, alpha = o.fit(X, y, th[2:2 + nl] if nl > 1 else th[2], th[2 + nl], th[0], th[1], kern)
+    ref = -0.5 * (y - th[1]) @ alpha - np.log(np.diag(L)).sum() - 0.5 * N * np.log(2 * np.pi)
+    assert m == pytest.approx(ref, rel=1e-12)
