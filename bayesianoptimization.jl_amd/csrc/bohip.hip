@@ -82,6 +82,8 @@ struct bohip_gp {
     int64_t grad_cap = 0;
     Best* dthompson = nullptr; // S arg-max records
     double* ddmll_parts = nullptr;  // per-block partial sums of the marginal-likelihood gradient
+    double *dVV = nullptr, *dcov = nullptr;  // [Rp][Rp] V'V (lower tiles) and the full posterior covariance
+    int64_t cov_cap = 0;
     int64_t dmll_cap = 0;
     int64_t thompson_cap = 0;
     // bookkeeping
@@ -719,6 +721,8 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dgrad) hipFree(g->dgrad);
     if (g->dthompson) hipFree(g->dthompson);
     if (g->ddmll_parts) hipFree(g->ddmll_parts);
+    if (g->dVV) hipFree(g->dVV);
+    if (g->dcov) hipFree(g->dcov);
     if (g->dinfo) hipFree(g->dinfo);
     for (auto& e : g->tpool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (g->side_stream) { hipStreamSynchronize(g->side_stream); hipStreamDestroy(g->side_stream); }
@@ -900,6 +904,62 @@ int bohip_gp_predict(bohip_gp* g, const double* Xs, int64_t R, double* mu, doubl
     CHK(score_core(g, BOHIP_ACQ_MAXMEAN, nullptr, g->dXs, R, g->dmu, g->dvar, nullptr, nullptr));
     HIPCHK(hipMemcpyAsync(mu, g->dmu, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipMemcpyAsync(var, g->dvar, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    t_collect(g);
+    return 0;
+}
+
+int bohip_gp_predict_cov(bohip_gp* g, const double* Xs, int64_t R, double* mu, double* cov) {
+    if (!g || R < 0 || (R > 0 && (!Xs || !mu || !cov))) return fail(BOHIP_E_ARG, "bad arguments");
+    if (R == 0) return 0;
+    if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    CHK(ensure_fresh(g));
+    CHK(ensure_xs(g, R));
+    CHK(ensure_score_scratch(g, R));
+    if (R > g->kst_rows)
+        return fail(BOHIP_E_UNSUPPORTED, "predict_cov: R exceeds one candidate chunk (" + std::to_string(g->kst_rows) + ")");
+    CHK(ensure_grad_scratch(g));
+    CHK(one_time_kernel_setup());
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE, Rp = round_up(R, TILE);
+    const int T = (int)(Npad / TILE), CT = (int)(Rp / TILE);
+    if (g->cov_cap < Rp) {
+        for (double** p : {&g->dVV, &g->dcov})
+            if (*p) { HIPCHK(hipFree(*p)); *p = nullptr; }
+        g->cov_cap = 0;
+        HIPCHK(hipMalloc(&g->dVV, (size_t)Rp * Rp * 8));
+        HIPCHK(hipMalloc(&g->dcov, (size_t)Rp * Rp * 8));
+        g->cov_cap = Rp;
+    }
+    const KernelHyper hp = make_hyper(g);
+    HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
+    g->q_tiles = T;
+    t_begin(g, "kstar");
+    CHK(launch_kstar_any(g, g->dXs, 0, R, Npad, hp));
+    t_end(g);
+    t_begin(g, "trigemm_sq+V");
+    CHK(launch_trigemm(g, T, R, N, Rpad, 0, g->dVT));
+    t_end(g);
+    t_begin(g, "gemm_VV");
+    GemmNTParams p{};  // (V'V)[r][s] = sum_i V'[r][i] V'[s][i], lower 128-tiles
+    p.A = g->dVT; p.lda = g->ld; p.B = g->dVT; p.ldb = g->ld; p.C = g->dVV; p.ldc = g->cov_cap;
+    p.mt = CT; p.nt64 = 2 * CT; p.kc = T * (TILE / KC); p.alpha = 1.0; p.beta = 0.0; p.diag_skip = 1;
+    CHK(launch_gemm_nt(g, p));
+    t_end(g);
+    t_begin(g, "post_cov");
+    AcqParams ap{BOHIP_ACQ_MAXMEAN, 0.0, 0.0};
+    hipLaunchKernelGGL(k_score, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, g->stream, g->dq, Rpad, T, g->dmu_raw, R,
+                       std::exp(2.0 * g->logsig), g->beta, ap, g->dmu, g->dvar, (double*)nullptr, (Best*)nullptr);
+    dim3 grid((unsigned)((R + 255) / 256), (unsigned)((R + 15) / 16));
+#define PC(DTV) hipLaunchKernelGGL(k_post_cov<DTV>, grid, dim3(256), 0, g->stream, g->dXs, R, hp, g->dVV, g->cov_cap, g->dcov, R)
+    if (g->d <= 2) PC(2); else if (g->d <= 4) PC(4); else if (g->d <= 8) PC(8); else if (g->d <= 16) PC(16);
+    else if (g->d <= 32) PC(32); else PC(64);
+#undef PC
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    HIPCHK(hipMemcpyAsync(mu, g->dmu, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipMemcpyAsync(cov, g->dcov, (size_t)R * R * 8, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
     t_collect(g);
     return 0;

@@ -52,6 +52,36 @@ __global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ X, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// Full posterior covariance of R candidates (predict_f(gp, X; full_cov = true), the input of the reference's joint
+// draw myrand(model, X::Matrix), src/models/gp.jl:7):  cov[r][s] = k(x*_r, x*_s) - (V'V)[r][s].
+// VV holds the LOWER triangle of V'V (k_gemm_nt on the stored V'); both halves of cov are written from it so the
+// result is exactly symmetric.  Thread = column s, block walks 16 rows.
+// ------------------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void k_post_cov(const double* __restrict__ Xs, int64_t R, KernelHyper hp,
+                                                  const double* __restrict__ VV, int64_t ldv,
+                                                  double* __restrict__ cov, int64_t ldc) {
+    const int d = hp.d;
+    const int64_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= R) return;
+    double xs[DT];
+#pragma unroll
+    for (int k = 0; k < DT; ++k) xs[k] = (k < d) ? Xs[s * d + k] : 0.0;
+    const int64_t r0 = (int64_t)blockIdx.y * 16, r1 = min(R, r0 + 16);
+    for (int64_t r = r0; r < r1; ++r) {
+        double rr = 0.0;
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+            if (k < d) {
+                const double t = Xs[r * d + k] - xs[k];
+                rr += hp.il2[k] * (t * t);
+            }
+        const double vv = (r >= s) ? VV[r * ldv + s] : VV[s * ldv + r];
+        cov[r * ldc + s] = cov_from_r_fast(hp.kern, hp.sigma2, rr) - vv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // V = W K*, fused epilogue.  Tile (rt, ct): rows [128 rt, 128 rt + 128) of W against candidates
 // [64 ct, 64 ct + 64) of the chunk; W is lower-triangular so the contraction stops at k = 128 (rt + 1).
 // Job length is set by that K extent, so the candidate tile is only 64 wide: with 128-wide tiles the longest

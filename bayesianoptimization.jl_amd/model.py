@@ -177,6 +177,15 @@ class ElasticGPE:
         check(self._lib.bohip_gp_predict(self._h, _ptr(xs), R, _ptr(mu), _ptr(var)))
         return mu, var
 
+    def predict_cov(self, xs):
+        """predict_f(gp, X; full_cov = true): (mu, R x R posterior covariance of the latent f)."""
+        xs = _cols(xs, self.dim)
+        R = xs.shape[1]
+        mu = np.empty(R)
+        cov = np.empty((R, R))
+        check(self._lib.bohip_gp_predict_cov(self._h, _ptr(xs), R, _ptr(mu), _ptr(cov)))
+        return mu, cov
+
     def score(self, acq, params, xs, want_scores=True):
         """Fused predict + acquisition + arg-max.  Returns (scores or None, best_val, best_idx)."""
         xs = _cols(xs, self.dim)
@@ -250,14 +259,26 @@ def mean_var(model, x):
 
 
 def myrand(model, x, rng=None):
-    """gp.jl:6-7.  Vector: one draw from N(mu, sigma^2).  Matrix: independent draws per column
-    (the reference draws jointly for matrices; only its length is pinned, test/acquisitionfunctions.jl:8)."""
+    """gp.jl:6-7.  Vector: one draw from N(mu, sigma^2).  Matrix: ONE JOINT draw from N(mu, Sigma_post) over the columns
+    (rand(gp, X) = mu + chol(Sigma)·z with jitter added until the factorisation succeeds -- GaussianProcesses.jl
+    make_posdef!, UPSTREAM-UNVERIFIED; only the length is pinned by test/acquisitionfunctions.jl:8)."""
     rng = rng if rng is not None else np.random.default_rng()
     x = np.asarray(x, dtype=np.float64)
-    mu, var = model.predict_f(x)
+    if x.ndim == 1:
+        mu, var = model.predict_f(x)
+        return float(mu[0] + math.sqrt(var[0]) * rng.standard_normal())
+    if model.nobs == 0:
+        raise RuntimeError("myrand on an empty model")
+    mu, cov = model.predict_cov(x)
     z = rng.standard_normal(mu.shape)
-    out = mu + np.sqrt(var) * z
-    return float(out[0]) if x.ndim == 1 else out
+    jitter, scale = 0.0, max(float(np.max(np.diag(cov))), np.finfo(float).tiny)
+    for _ in range(40):
+        try:
+            Lc = np.linalg.cholesky(cov + jitter * np.eye(len(mu)))
+            return mu + Lc @ z
+        except np.linalg.LinAlgError:
+            jitter = max(10.0 * jitter, 1e-12 * scale)
+    raise np.linalg.LinAlgError("posterior covariance could not be made positive definite")
 
 
 def dims(model):

@@ -97,6 +97,10 @@ int bohip_gp_mll_grad(bohip_gp *gp, double *mll, double *d_lognoise, double *d_m
 /* ---- mean_var(model, X::Matrix) (reference src/models/gp.jl:8 -> GP.predict_f):
  * Xs d x R column-major; mu, var length R (latent f variance, clamped at 0).                */
 int bohip_gp_predict(bohip_gp *gp, const double *Xs, int64_t R, double *mu, double *var);
+/* Full posterior covariance (predict_f(gp, X; full_cov = true)): the input of the reference's JOINT draw
+ * myrand(model, X::Matrix) = rand(gp, X), src/models/gp.jl:7.  cov is R x R (symmetric, both halves written, diagonal
+ * NOT clamped); R is limited to one candidate chunk (>= 1024).  cov = K** - V'V with V'V on the MFMA engine.   */
+int bohip_gp_predict_cov(bohip_gp *gp, const double *Xs, int64_t R, double *mu, double *cov);
 
 /* ---- acquisitionfunction(a, model)(X) + the arg-max of acquire_max (reference
  * src/acquisitionfunctions.jl:4-9, src/acquisition.jl:54-68) fused: score all R columns, return

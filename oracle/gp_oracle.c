@@ -237,6 +237,36 @@ void oracle_predict(int kern, int64_t d, int64_t N, const double *X, const doubl
     free(il2);
 }
 
+/* Full posterior covariance: predict_f(gp, X; full_cov = true), the input of the reference's joint draw
+ * myrand(model, X::Matrix) = rand(gp, X) (src/models/gp.jl:7):  cov = K** - V'V, V = L^-1 K*, no clamp. */
+void oracle_predict_cov(int kern, int64_t d, int64_t N, const double *X, const double *loglen, double logsig,
+                        double beta, const double *L, int64_t ld, const double *alpha, const double *Xs,
+                        int64_t R, double *mu, double *cov) {
+    double *il2 = (double *)malloc(sizeof(double) * d);
+    double *V = (double *)malloc(sizeof(double) * (N > 0 ? N : 1) * (R > 0 ? R : 1));
+    oracle_il2(kern, d, loglen, il2);
+    const double s2f = exp(2.0 * logsig);
+    for (int64_t r = 0; r < R; ++r) {
+        double *v = V + r * N, m = 0.0;
+        for (int64_t i = 0; i < N; ++i) {
+            v[i] = cov_from_r(kern, s2f, wsqdist(d, X + d * i, Xs + d * r, il2));
+            m += v[i] * alpha[i];
+        }
+        mu[r] = beta + m;
+        oracle_trsv_lower(N, L, ld, v);
+    }
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t s = 0; s <= r; ++s) {
+            double q = 0.0;
+            for (int64_t i = 0; i < N; ++i) q += V[r * N + i] * V[s * N + i];
+            const double c = cov_from_r(kern, s2f, wsqdist(d, Xs + d * r, Xs + d * s, il2)) - q;
+            cov[r * R + s] = c;
+            cov[s * R + r] = c;
+        }
+    free(il2);
+    free(V);
+}
+
 /* A4-A7 fused the way acquire_max would see it if every start point were scored as-is:
  * score every column, keep the best with strict '>' starting from -Inf (src/acquisition.jl:55,62-65)
  * => first maximum wins ties, NaN never wins.  best_idx = -1 if nothing beat -Inf. */

@@ -144,6 +144,21 @@ class COracle:
                                 _p(alpha), _p(Xs), C.c_int64(R), _p(mu), _p(var), C.c_int(nthreads))
         return mu, var
 
+    def predict_cov(self, X, loglen, logsig, beta, L, alpha, Xs, kern="SEArd"):
+        """(mu, cov) with the full R x R posterior covariance (the joint-draw input of myrand(model, X::Matrix))."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+        N, d = X.shape
+        R = Xs.shape[0]
+        ll = np.ascontiguousarray(np.broadcast_to(np.asarray(loglen, dtype=np.float64), (d,)))
+        mu = np.empty(R)
+        cov = np.empty((R, R))
+        self.lib.oracle_predict_cov.restype = None
+        self.lib.oracle_predict_cov(C.c_int(KERN[kern]), C.c_int64(d), C.c_int64(N), _p(X), _p(ll), C.c_double(logsig),
+                                    C.c_double(beta), _p(L), C.c_int64(L.shape[1]), _p(alpha), _p(Xs), C.c_int64(R),
+                                    _p(mu), _p(cov))
+        return mu, cov
+
     def score(self, X, loglen, logsig, beta, L, alpha, acq, params, Xs, kern="SEArd", nthreads=1):
         X = np.ascontiguousarray(X, dtype=np.float64)
         Xs = np.ascontiguousarray(Xs, dtype=np.float64)

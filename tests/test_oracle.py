@@ -214,3 +214,23 @@ def test_oracle_mll_gradient_matches_central_differences(kern):
     L, alpha = o.fit(X, y, th[2:2 + nl] if nl > 1 else th[2], th[2 + nl], th[0], th[1], kern)
     ref = -0.5 * (y - th[1]) @ alpha - np.log(np.diag(L)).sum() - 0.5 * N * np.log(2 * np.pi)
     assert m == pytest.approx(ref, rel=1e-12)
+
+
+def test_oracle_full_covariance_consistent_with_variance_path():
+    """oracle_predict_cov (checker of bohip_gp_predict_cov): diagonal == the per-candidate variance, symmetric, and
+    equal to the NumPy restatement K** - K*' cK^-1 K*."""
+    from oracle.oracle import COracle, np_cov
+
+    o = COracle()
+    X, y, Xs = synth(80, 3, 17, seed=8)
+    ll = np.array([-0.3, -0.6, 0.1])
+    L, alpha = o.fit(X, y, ll, 0.2, -1.0, 0.1)
+    mu, cov = o.predict_cov(X, ll, 0.2, 0.1, L, alpha, Xs)
+    mu1, var1 = o.predict(X, ll, 0.2, 0.1, L, alpha, Xs)
+    np.testing.assert_array_equal(mu, mu1)
+    np.testing.assert_allclose(np.diag(cov), var1, rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(cov, cov.T)
+    cK = L @ L.T
+    Ks = np_cov("SEArd", X, Xs, ll, 0.2)
+    ref = np_cov("SEArd", Xs, Xs, ll, 0.2) - Ks.T @ np.linalg.solve(cK, Ks)
+    np.testing.assert_allclose(cov, ref, rtol=1e-8, atol=1e-10)

@@ -336,6 +336,43 @@ def test_mll_gradient_full_size_matches_central_differences(bohip):
         assert abs(a - b) <= 1e-5 * scale, (a, b)
 
 
+@pytest.mark.parametrize("kern,N,d,R", [("SEArd", 300, 4, 70), ("Mat52Ard", 200, 3, 5), ("SEIso", 129, 2, 257)])
+def test_full_posterior_covariance_vs_oracle(bohip, orc, kern, N, d, R):
+    """bohip_gp_predict_cov (K** - V'V, V'V on the MFMA engine) against the oracle; the diagonal must agree with the
+    variance path wherever that one is not clamped, and the matrix must be exactly symmetric."""
+    X, y, Xs = synth(N, d, R, seed=31)
+    nl = 1 if kern == "SEIso" else d
+    ll = np.full(nl, -0.4) if nl > 1 else -0.4
+    lsig, lnoise, beta = 0.2, -1.0, 0.1
+    m = make_model(bohip, X, y, ll, lsig, lnoise, beta, kern=kern)
+    L, alpha = orc.fit(X, y, ll, lsig, lnoise, beta, kern=kern)
+    mu_o, cov_o = orc.predict_cov(X, ll, lsig, beta, L, alpha, Xs, kern=kern)
+    mu, cov = m.predict_cov(Xs.T)
+    s2f = math.exp(2 * lsig)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=mu_floor(alpha, s2f))
+    assert np.all(np.abs(cov - cov_o) <= var_tol(cov_o, N, s2f)), np.abs(cov - cov_o).max()
+    np.testing.assert_array_equal(cov, cov.T)
+    _, var = m.predict_f(Xs.T)
+    pos = np.diag(cov) > 0
+    assert np.all(np.abs(np.diag(cov)[pos] - var[pos]) <= var_tol(var[pos], N, s2f))
+
+
+def test_joint_draw_has_posterior_moments(bohip):
+    """myrand(model, X::Matrix) = one joint draw (reference src/models/gp.jl:7): length pinned by
+    test/acquisitionfunctions.jl:8; here also the empirical mean and covariance of many draws."""
+    X, y, Xs = synth(120, 2, 6, seed=4)
+    m = make_model(bohip, X, y, np.array([-0.5, -0.5]), 0.0, -1.0, 0.0)
+    rng = np.random.default_rng(0)
+    draws = np.stack([bohip.myrand(m, Xs.T, rng) for _ in range(4000)])
+    assert draws.shape == (4000, 6)
+    mu, cov = m.predict_cov(Xs.T)
+    sd = np.sqrt(np.diag(cov))
+    assert np.all(np.abs(draws.mean(0) - mu) <= 5 * sd / math.sqrt(4000))
+    emp = np.cov(draws.T)
+    assert np.all(np.abs(emp - cov) <= 0.15 * np.outer(sd, sd) + 1e-12)
+    assert isinstance(bohip.myrand(m, Xs[0], rng), float)
+
+
 def test_thompson_draws_match_oracle(bohip, orc):
     from bohip import _lib
 
