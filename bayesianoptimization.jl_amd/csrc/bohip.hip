@@ -1098,4 +1098,12 @@ int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {
     return (int)g->tnames.size();
 }
 
+#if BOHIP_TRACE
+int bohip_debug_trace_read(unsigned long long* out, int64_t n_words) {   // tools only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -3;
+}
+int bohip_debug_phase_read(unsigned long long* out, int64_t n_words) {   // tools only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_phase), (size_t)n_words * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 }  // extern "C"

@@ -14,6 +14,12 @@
 // -> 32 accumulator doubles per lane.  Both operand tiles are K-major ([rows][16 contraction indices]),
 // brought into LDS by global_load_lds (LDS-DMA), three buffers deep.
 #pragma once
+#ifndef BOHIP_TRACE
+#define BOHIP_TRACE 0
+#endif
+#ifndef BOHIP_ABL
+#define BOHIP_ABL 0   // ablation of k_trigemm_sq's loop (tools only, see gemm_tile_loop_glds3_ks)
+#endif
 #include "common.h"
 
 namespace bohip {
@@ -69,6 +75,22 @@ __device__ __forceinline__ void mma_pair(const d2 (&av)[8], const d2 (&bv)[NJ], 
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma444(av[i].y, bv[j].y, acc[i][j]);
+}
+
+// LDS fragment read whose completion is tracked by hand (see gemm_tile_loop_glds3_ks)
+template <int OFF>
+__device__ __forceinline__ d2 ds_read128(uint32_t lds_byte_addr) {
+    d2 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(OFF));
+    return r;
+}
+template <int NJ>
+__device__ __forceinline__ void mma_row(const d2& a, const d2 (&bv)[NJ], double (&acc)[NJ]) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = mfma444(a.x, bv[j].x, acc[j]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = mfma444(a.y, bv[j].y, acc[j]);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int NJ>
@@ -163,7 +185,10 @@ __device__ __forceinline__ void gemm_tile_loop_glds3(const double* __restrict__ 
 // Measured on k_trigemm_sq (C2): 0.69 ms vs 0.71 ms for the 4-wave loop; a 16-wave 4-way split drops to one
 // workgroup per CU (102 VGPRs x 16 waves) and is slower (0.77 ms).
 constexpr int GEMM_THREADS_8 = 512;
-template <int NJ>
+#if BOHIP_TRACE
+__device__ unsigned long long g_phase[8192 * 8 * 4];   // [block][wave]{issue+mfma, vmcnt wait, barrier wait, iterations}
+#endif
+template <int NJ, int ABL = 0>  // ABL: ablation switches (tools only): 1 no DMA, 2 no LDS reads, 4 no barriers
 __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict__ A, int64_t lda,
                                                         const double* __restrict__ B, int64_t ldb, int kc_begin,
                                                         int kc_end, double* smem, double (&acc)[8][NJ],
@@ -202,29 +227,78 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
     }
     __builtin_amdgcn_s_barrier();
     int cur = 0;
+#if BOHIP_TRACE
+    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, phn = 0;
+#endif
     for (int kc = kc_begin; kc < kc_end; ++kc) {
+#if BOHIP_TRACE
+        const unsigned long long tA = __builtin_amdgcn_s_memtime();
+#endif
         const int nxt2 = cur == 0 ? 2 : cur - 1;
         const bool more2 = kc + 2 < kc_end;
-        if (more2) issue(kc + 2, nxt2);
+        if (more2 && !(ABL & 1)) issue(kc + 2, nxt2);
         if (wave_active) {
             d2 av[8], bv[NJ];
             const double* ap = As + cur * AT + a_frag;
             const double* bp = Bs + cur * BT + b_frag;
+            // B fragments first, then A row by row, issued as inline asm so that the waits are OURS: hipcc answers an
+            // LDS read that follows an LDS-DMA with s_waitcnt lgkmcnt(0) (all 12 reads) before the first MFMA; here
+            // row i starts as soon as its own fragment has landed (LDS returns in order): lgkmcnt(7 - i).
+            const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const double*)ap;
+            const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const double*)bp;
+            if constexpr ((ABL & 2) != 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const d2*>(ap + i * 8 * GL_ROW);
+            for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bv[j]) : "v"(pb));
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) bv[j] = *reinterpret_cast<const d2*>(bp + j * 8 * GL_ROW);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_pair<NJ>(av, bv, acc);
+            for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(av[i]) : "v"(pa));
+            } else {
+            bv[0] = ds_read128<0>(pb); bv[1] = ds_read128<1024>(pb); bv[2] = ds_read128<2048>(pb); bv[3] = ds_read128<3072>(pb);
+            av[0] = ds_read128<0>(pa); av[1] = ds_read128<1024>(pa); av[2] = ds_read128<2048>(pa); av[3] = ds_read128<3072>(pa);
+            av[4] = ds_read128<4096>(pa); av[5] = ds_read128<5120>(pa); av[6] = ds_read128<6144>(pa); av[7] = ds_read128<7168>(pa);
+            }
+            asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(av[0]));
+            mma_row<NJ>(av[0], bv, acc[0]);
+            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(av[1]));
+            mma_row<NJ>(av[1], bv, acc[1]);
+            asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(av[2]));
+            mma_row<NJ>(av[2], bv, acc[2]);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(av[3]));
+            mma_row<NJ>(av[3], bv, acc[3]);
+            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(av[4]));
+            mma_row<NJ>(av[4], bv, acc[4]);
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(av[5]));
+            mma_row<NJ>(av[5], bv, acc[5]);
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(av[6]));
+            mma_row<NJ>(av[6], bv, acc[6]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[7]));
+            mma_row<NJ>(av[7], bv, acc[7]);
         }
         __builtin_amdgcn_sched_barrier(0);
+#if BOHIP_TRACE
+        const unsigned long long tB = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         if (more2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+#if BOHIP_TRACE
+        const unsigned long long tC = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_sched_barrier(0);
+#endif
+        if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#if BOHIP_TRACE
+        const unsigned long long tD = __builtin_amdgcn_s_memtime();
+        ph0 += tB - tA; ph1 += tC - tB; ph2 += tD - tC; phn += 1;
+#endif
         cur = cur == 2 ? 0 : cur + 1;
     }
+#if BOHIP_TRACE
+    if (lane == 0 && blockIdx.x < 8192) {
+        unsigned long long* o = g_phase + ((size_t)blockIdx.x * 8 + wave) * 4;
+        o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = phn;
+    }
+#endif
     // add the second half's partial accumulators into the first half's (through LDS: 32 doubles per lane)
     double* xch = smem;  // 256 lanes x 32 doubles = 64 KB <= staging area
     if (khalf == 1) {

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(256) void k_post_cov(const double* __restrict__ Xs,
 // Output: q_part[rt][r] = sum over the tile's rows of v^2 (fixed summation order -> deterministic),
 //         mu_raw[r] = alpha' k*_r taken from the row of W that stores alpha (alpha_row).
 // ------------------------------------------------------------------------------------------------
+// BOHIP_TRACE (tools only, default 0 in gemm_core.h): per-workgroup start/end clocks of k_trigemm_sq (tools/trace_trigemm.py)
+#if BOHIP_TRACE
+__device__ unsigned long long g_trace[4 * 8192];
+#endif
 template <int KS>  // 1: 4 waves; 2: 8 waves, contraction index halved inside the workgroup (default)
 __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
                                                                 const double* __restrict__ KsT, int64_t ldk,
@@ -101,6 +105,21 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
                                                                 double* __restrict__ VT, int64_t ldv) {
     constexpr int NJ = 4, CW = CTILE;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#if BOHIP_TRACE
+    const unsigned long long t_start = wall_clock64();
+    struct TraceEnd {
+        unsigned long long t0;
+        __device__ ~TraceEnd() {
+            if (threadIdx.x == 0) {
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                unsigned long long* t = g_trace + 4 * (size_t)blockIdx.x;
+                t[0] = t0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;
+            }
+        }
+    } trace_end{t_start};
+#endif
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int n_local = (CT + 7) >> 3;
     const int rt = T - 1 - slot / n_local;
@@ -113,7 +132,7 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
         for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0;
     const int active_rows = (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE);  // rows past alpha' are padding
     if constexpr (KS == 2)
-        gemm_tile_loop_glds3_ks<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+        gemm_tile_loop_glds3_ks<NJ, BOHIP_ABL>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
                                     (rt + 1) * (TILE / KC), smem, acc, active_rows);
     else
         gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
