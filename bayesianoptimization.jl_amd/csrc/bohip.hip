@@ -79,6 +79,11 @@ struct bohip_gp {
     Best *dblock_best = nullptr, *dbest = nullptr;
     int64_t bb_cap = 0;
     double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
+    double* dgparts = nullptr;   // [SMALL_R][16][2 DMAX] split partial sums of k_grad_finish (small batches)
+    unsigned* dgcount = nullptr; // per-candidate arrival counters (left at zero by the kernel)
+    // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
+    // 2-3 device-to-host copies of a call cost more than its kernels (each ~8 us of API + DMA set-up)
+    double* hpin = nullptr;      // [score 32 | mu 32 | var 32 | best 2 | grad 32 DMAX]
     int64_t grad_cap = 0;
     Best* dthompson = nullptr; // S arg-max records
     double* ddmll_parts = nullptr;  // per-block partial sums of the marginal-likelihood gradient
@@ -182,6 +187,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 }
 
 // ---- GEMM launcher --------------------------------------------------------------------------------
+static int g_small_r = SMALL_R;  // batches up to this size take the row-wise path (BOHIP_SMALL_R, <= SMALL_R)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
@@ -202,6 +208,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
+    if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_R, std::max(0, atoi(e)));
     done = true;
     return 0;
 }
@@ -363,6 +370,16 @@ static int refit(bohip_gp* g) {
     return 0;
 }
 
+// out[r][j] = (W rows[r])[j] for r < P <= 32: one launch, workgroups of 8 rows of W x 8 right-hand sides
+static int launch_rows_trimv(bohip_gp* g, const double* W, int64_t N0, const double* rows, int P, double* out, int upper) {
+    if (N0 <= 0 || P <= 0) return 0;
+    const int64_t tiles = (N0 + RT_ROWS - 1) / RT_ROWS, G = (P + APPEND_CHUNK - 1) / APPEND_CHUNK;
+    hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)(8 * ((tiles + 7) / 8) * G)), dim3(RT_THREADS), 0, g->stream, W, g->ld, N0, rows,
+                       g->ld, P, out, g->ld, upper);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- A2': incremental extension by p new observations (already in dX/dy and the host mirror) ----------
 static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
     CHK(one_time_kernel_setup());
@@ -375,14 +392,8 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
                        hp, noise, g->dL, g->dW, g->dWT, ld);
     HIPCHK(hipGetLastError());
     t_end(g);
-    const int nch = (int)((p + APPEND_CHUNK - 1) / APPEND_CHUNK);
     t_begin(g, "append_L21");
-    for (int ch = 0; ch < nch; ++ch) {
-        const int P = (int)std::min<int64_t>(APPEND_CHUNK, p - ch * APPEND_CHUNK);
-        hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)N0), dim3(256), 0, g->stream, g->dW, ld, N0,
-                           g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, g->dApp + (int64_t)ch * APPEND_CHUNK * ld, ld, 0);
-    }
-    HIPCHK(hipGetLastError());
+    CHK(launch_rows_trimv(g, g->dW, N0, g->dL + N0 * ld, (int)p, g->dApp, 0));
     HIPCHK(hipMemcpy2DAsync(g->dL + N0 * ld, ld * 8, g->dApp, ld * 8, N0 * 8, p, hipMemcpyDeviceToDevice, g->stream));
     t_end(g);
     t_begin(g, "append_schur_chol");
@@ -391,11 +402,7 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
     t_end(g);
     t_begin(g, "append_W21");
     double* Tm = g->dApp + (int64_t)APP_UT_ROW0 * ld;   // T = L21 W11, row-wise on W' (k >= c)
-    for (int ch = 0; ch < nch; ++ch) {
-        const int P = (int)std::min<int64_t>(APPEND_CHUNK, p - ch * APPEND_CHUNK);
-        hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)N0), dim3(256), 0, g->stream, g->dWT, ld, N0,
-                           g->dL + (N0 + ch * APPEND_CHUNK) * ld, ld, P, Tm + (int64_t)ch * APPEND_CHUNK * ld, ld, 1);
-    }
+    CHK(launch_rows_trimv(g, g->dWT, N0, g->dL + N0 * ld, (int)p, Tm, 1));
     hipLaunchKernelGGL(k_apply_w22, dim3((N0 + 255) / 256), dim3(256), 0, g->stream, g->dW, g->dWT, ld, N0, (int)p, Tm, ld);
     HIPCHK(hipGetLastError());
     t_end(g);
@@ -511,33 +518,33 @@ static int launch_kstar_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t 
 }
 
 // Small-batch posterior (R <= SMALL_R): V' rows into dApp[0..R), q and mu_raw; optionally U' = V' W into dApp[APP_UT_ROW0..).
-static int small_posterior(bohip_gp* g, const double* dXs, int64_t R, bool want_u) {
+static int ensure_small_counters(bohip_gp* g) {
+    if (g->dgparts) return 0;
+    HIPCHK(hipMalloc(&g->dgparts, (size_t)SMALL_R * 16 * 2 * DMAX * 8));
+    HIPCHK(hipMalloc(&g->dgcount, (SMALL_R + 1) * sizeof(unsigned)));   // [0, SMALL_R): k_grad_finish, [SMALL_R]: k_small_finish
+    HIPCHK(hipMemsetAsync(g->dgcount, 0, (SMALL_R + 1) * sizeof(unsigned), g->stream));
+    return 0;
+}
+static int small_posterior(bohip_gp* g, const double* dXs, int64_t R, bool want_u, const AcqParams& ap, double* d_mu,
+                           double* d_var, double* d_score, Best* d_best) {
+    CHK(ensure_small_counters(g));
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), ld = g->ld;
     const KernelHyper hp = make_hyper(g);
     t_begin(g, "kstar");
     CHK(launch_kstar_any(g, dXs, 0, R, Npad, hp));
     t_end(g);
     t_begin(g, "small_V");
-    const int nch = (int)((R + APPEND_CHUNK - 1) / APPEND_CHUNK);
-    for (int ch = 0; ch < nch; ++ch) {
-        const int P = (int)std::min<int64_t>(APPEND_CHUNK, R - ch * APPEND_CHUNK);
-        // rows 0..N of W (row N carries alpha'): V'[r][j] = sum_{k<=j} W[j][k] K*'[r][k]
-        hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)(N + 1)), dim3(256), 0, g->stream, g->dW, ld, N + 1,
-                           g->dKsT + (int64_t)ch * APPEND_CHUNK * ld, ld, P, g->dApp + (int64_t)ch * APPEND_CHUNK * ld, ld, 0);
-    }
-    hipLaunchKernelGGL(k_small_finish, dim3((unsigned)R), dim3(256), 0, g->stream, g->dApp, ld, N, g->dq, g->dmu_raw);
+    // rows 0..N of W (row N carries alpha'): V'[r][j] = sum_{k<=j} W[j][k] K*'[r][k]
+    CHK(launch_rows_trimv(g, g->dW, N + 1, g->dKsT, (int)R, g->dApp, 0));
+    hipLaunchKernelGGL(k_small_finish, dim3((unsigned)R), dim3(256), 0, g->stream, g->dApp, ld, N, (int)R, g->dq, g->dmu_raw,
+                       g->dgcount + SMALL_R, std::exp(2.0 * g->logsig), g->beta, ap, d_mu, d_var, d_score, d_best);
     HIPCHK(hipGetLastError());
     t_end(g);
     g->q_tiles = 1;
     if (want_u) {
         t_begin(g, "small_U");
-        for (int ch = 0; ch < nch; ++ch) {  // U'[r][c] = sum_{k>=c} W'[c][k] V'[r][k]
-            const int P = (int)std::min<int64_t>(APPEND_CHUNK, R - ch * APPEND_CHUNK);
-            hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)N), dim3(256), 0, g->stream, g->dWT, ld, N,
-                               g->dApp + (int64_t)ch * APPEND_CHUNK * ld, ld, P,
-                               g->dApp + (int64_t)(APP_UT_ROW0 + ch * APPEND_CHUNK) * ld, ld, 1);
-        }
-        HIPCHK(hipGetLastError());
+        // U'[r][c] = sum_{k>=c} W'[c][k] V'[r][k]
+        CHK(launch_rows_trimv(g, g->dWT, N, g->dApp, (int)R, g->dApp + (int64_t)APP_UT_ROW0 * ld, 1));
         t_end(g);
     }
     return 0;
@@ -545,7 +552,6 @@ static int small_posterior(bohip_gp* g, const double* dXs, int64_t R, bool want_
 
 static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
     CHK(one_time_kernel_setup());
-    if (R <= SMALL_R) return small_posterior(g, dXs, R, false);
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: head-room for tile-granular writes
     const int T = (int)(Npad / TILE);
     g->q_tiles = T;
@@ -568,7 +574,6 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
     CHK(ensure_fresh(g));
     CHK(ensure_score_scratch(g, R));
-    CHK(posterior_pass(g, dXs, R));
     AcqParams ap{acq_id, 0.0, 0.0};
     if (acq_params) {
         if (acq_id != BOHIP_ACQ_MAXMEAN) ap.p0 = acq_params[0];
@@ -576,6 +581,11 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
         return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
     }
+    if (R <= g_small_r) {   // row-wise posterior, scoring and arg-max fused into its finish kernel
+        CHK(one_time_kernel_setup());
+        return small_posterior(g, dXs, R, false, ap, d_mu, d_var, d_score, d_best);
+    }
+    CHK(posterior_pass(g, dXs, R));
     const int64_t Npad = round_up(g->n + 1, TILE), Rpad = round_up(R, TILE) + TILE;
     const int T = (int)(Npad / TILE);
     const int nb = (int)((R + 255) / 256);
@@ -590,18 +600,22 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
 
 template <int DT>
 static void launch_grad(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, const KernelHyper& hp, const AcqParams& ap,
-                        double* d_grad, const double* UT) {
-    hipLaunchKernelGGL(k_grad_finish<DT>, dim3((unsigned)(r1 - r0)), dim3(256), 0, g->stream, g->dX, g->n, dXs, r0, r1, hp,
-                       g->dalpha, UT, g->ld, g->dmu, g->dvar, ap, d_grad);
+                        double* d_grad, const double* UT, int S) {
+    hipLaunchKernelGGL(k_grad_finish<DT>, dim3((unsigned)(r1 - r0), (unsigned)S), dim3(256), 0, g->stream, g->dX, g->n, dXs, r0, r1,
+                       hp, g->dalpha, UT, g->ld, g->dmu, g->dvar, ap, d_grad, g->dgparts, g->dgcount);
 }
 static int launch_grad_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, const KernelHyper& hp, const AcqParams& ap,
                            double* d_grad, const double* UT) {
-    if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad, UT);
-    else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad, UT);
-    else if (g->d <= 8) launch_grad<8>(g, dXs, r0, r1, hp, ap, d_grad, UT);
-    else if (g->d <= 16) launch_grad<16>(g, dXs, r0, r1, hp, ap, d_grad, UT);
-    else if (g->d <= 32) launch_grad<32>(g, dXs, r0, r1, hp, ap, d_grad, UT);
-    else launch_grad<64>(g, dXs, r0, r1, hp, ap, d_grad, UT);
+    // small batches: split the observations over S workgroups per candidate (see k_grad_finish)
+    int S = 1;
+    if (r1 - r0 <= SMALL_R) S = (int)std::min<int64_t>(16, std::max<int64_t>(1, g->n / 768));
+    if (S > 1) CHK(ensure_small_counters(g));
+    if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
+    else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
+    else if (g->d <= 8) launch_grad<8>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
+    else if (g->d <= 16) launch_grad<16>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
+    else if (g->d <= 32) launch_grad<32>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
+    else launch_grad<64>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -624,11 +638,9 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: head-room for tile-granular writes
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
-    if (R <= SMALL_R) {  // the reference's default: a handful of L-BFGS restarts per call
-        CHK(small_posterior(g, dXs, R, true));
-        t_begin(g, "score+grad");
-        hipLaunchKernelGGL(k_score, dim3(1), dim3(256), 0, g->stream, g->dq, Rpad, 1, g->dmu_raw, R, std::exp(2.0 * g->logsig),
-                           g->beta, ap, g->dmu, g->dvar, d_score, (Best*)nullptr);
+    if (R <= g_small_r) {  // the reference's default: a handful of L-BFGS restarts per call
+        CHK(small_posterior(g, dXs, R, true, ap, g->dmu, g->dvar, d_score, nullptr));
+        t_begin(g, "grad");
         CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld));
         t_end(g);
         return 0;
@@ -698,6 +710,7 @@ int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohi
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_bulk, hipEventDisableTiming);
     if (e != hipSuccess) { delete g; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
     g->stream = g->own_stream;
+    if (hipHostMalloc((void**)&g->hpin, (size_t)(3 * SMALL_R + 2 + SMALL_R * DMAX) * 8, hipHostMallocDefault) != hipSuccess) g->hpin = nullptr;
     if (hipMalloc(&g->dinfo, sizeof(int)) != hipSuccess || hipMalloc(&g->dmll, 8 * (DMAX + 4)) != hipSuccess ||
         hipMalloc(&g->dbest, 4096 * sizeof(Best)) != hipSuccess) {
         delete g;
@@ -719,6 +732,9 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dblock_best) hipFree(g->dblock_best);
     if (g->dbest) hipFree(g->dbest);
     if (g->dgrad) hipFree(g->dgrad);
+    if (g->dgparts) hipFree(g->dgparts);
+    if (g->dgcount) hipFree(g->dgcount);
+    if (g->hpin) hipHostFree(g->hpin);
     if (g->dthompson) hipFree(g->dthompson);
     if (g->ddmll_parts) hipFree(g->ddmll_parts);
     if (g->dVV) hipFree(g->dVV);
@@ -901,6 +917,15 @@ int bohip_gp_predict(bohip_gp* g, const double* Xs, int64_t R, double* mu, doubl
     CHK(ensure_xs(g, R));
     CHK(ensure_score_scratch(g, R));
     HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
+    if (R <= SMALL_R && g->hpin) {   // results land in pinned host memory, no copy commands
+        double *pmu = g->hpin + SMALL_R, *pvar = g->hpin + 2 * SMALL_R;
+        CHK(score_core(g, BOHIP_ACQ_MAXMEAN, nullptr, g->dXs, R, pmu, pvar, nullptr, nullptr));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        std::memcpy(mu, pmu, (size_t)R * 8);
+        std::memcpy(var, pvar, (size_t)R * 8);
+        t_collect(g);
+        return 0;
+    }
     CHK(score_core(g, BOHIP_ACQ_MAXMEAN, nullptr, g->dXs, R, g->dmu, g->dvar, nullptr, nullptr));
     HIPCHK(hipMemcpyAsync(mu, g->dmu, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipMemcpyAsync(var, g->dvar, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
@@ -978,6 +1003,16 @@ int bohip_gp_score(bohip_gp* g, int acq_id, const double* acq_params, const doub
     CHK(ensure_xs(g, R));
     CHK(ensure_score_scratch(g, R));
     HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
+    if (R <= SMALL_R && g->hpin) {
+        double* pscore = g->hpin;
+        Best* pbest = reinterpret_cast<Best*>(g->hpin + 3 * SMALL_R);
+        CHK(score_core(g, acq_id, acq_params, g->dXs, R, nullptr, nullptr, score ? pscore : nullptr, best ? pbest : nullptr));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        if (score) std::memcpy(score, pscore, (size_t)R * 8);
+        if (best) std::memcpy(best, pbest, sizeof(Best));
+        t_collect(g);
+        return 0;
+    }
     CHK(score_core(g, acq_id, acq_params, g->dXs, R, nullptr, nullptr, score ? g->dscore : nullptr,
                    best ? g->dbest : nullptr));
     if (score) HIPCHK(hipMemcpyAsync(score, g->dscore, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
@@ -1004,6 +1039,20 @@ int bohip_gp_score_grad(bohip_gp* g, int acq_id, const double* acq_params, const
     double* dgrad = g->dgrad;
     HIPCHK(hipMemcpyAsync(g->dXs, Xs, (size_t)R * g->d * 8, hipMemcpyHostToDevice, g->stream));
     int rc = ensure_score_scratch(g, R);
+    if (rc == 0 && R <= SMALL_R && g->hpin) {
+        double *pscore = g->hpin, *pgrad = g->hpin + 3 * SMALL_R + 2;
+        rc = score_grad_core(g, acq_id, acq_params, g->dXs, R, pscore, pgrad);
+        if (rc == 0) {
+            const hipError_t e = hipStreamSynchronize(g->stream);
+            if (e != hipSuccess) rc = fail(BOHIP_E_HIP, hipGetErrorString(e));
+        }
+        if (rc == 0) {
+            std::memcpy(score, pscore, (size_t)R * 8);
+            std::memcpy(grad, pgrad, (size_t)R * g->d * 8);
+        }
+        t_collect(g);
+        return rc;
+    }
     if (rc == 0) rc = score_grad_core(g, acq_id, acq_params, g->dXs, R, g->dscore, dgrad);
     if (rc == 0) {
         hipError_t e = hipMemcpyAsync(score, g->dscore, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream);

@@ -642,37 +642,74 @@ __global__ __launch_bounds__(256) void k_cov_rows(const double* __restrict__ X, 
     }
 }
 
-// out[r][j] = sum_{k<=j} W[j][k] * rows[r][k]   for j < N0, r < P (P <= APPEND_CHUNK).
-// One workgroup per row j: 256 threads stride k (coalesced), P running sums each, fixed-order reduction
-// (wave butterfly, then the four waves in index order) -> bit-deterministic and independent of P.
+// out[r][j] = sum_{k<=j} W[j][k] * rows[r][k]   for j < N0, r < P  (P <= APPEND_PMAX = SMALL_R).
+// One workgroup: 8 rows of W against 8 right-hand sides: 256 threads stride k (coalesced), 8 x 8
+// running sums each, so a W element is loaded once per 8 right-hand sides and a right-hand-side element once per 8
+// rows (one workgroup per row re-read every right-hand side N times: L2-bound at ~1.5 TB/s of W).  Reduction in a
+// fixed order -- lane-strided partial sums, recursive halving over the wave (63 shuffles for the 64 sums; lane l ends
+// up with sum number l), then the four waves in index order -- so a result is bit-identical whatever else is in the
+// batch (reference property test/acquisitionfunctions.jl:8-11: batch == single).
 // upper != 0: W is an UPPER-triangular K-major matrix (rows of W'), the sum runs over k in [j, N0) instead:
 //     out[r][j] = sum_{k>=j} W'[j][k] * rows[r][k]  ( = (rows W)[r][j] for the lower-triangular W ).
-__global__ __launch_bounds__(256) void k_rows_trimv(const double* __restrict__ W, int64_t ld, int64_t N0,
-                                                    const double* __restrict__ rows, int64_t ldr, int P,
+constexpr int RT_ROWS = 8;
+constexpr int RT_THREADS = 256;   // 512 measured slower (31 -> 39 us at N=3000, R=10)
+__global__ __launch_bounds__(RT_THREADS) void k_rows_trimv(const double* __restrict__ W, int64_t ld, int64_t N0,
+                                                    const double* __restrict__ rows, int64_t ldr, int P_total,
                                                     double* __restrict__ out, int64_t ldo, int upper) {
-    __shared__ double red[4][APPEND_CHUNK];
+    __shared__ double red[RT_THREADS / 64][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t j = blockIdx.x;
-    if (j >= N0) return;
-    double s[APPEND_CHUNK];
+    // block b runs on XCD b % 8; the G = ceil(P_total / 8) workgroups that share a row tile of W are consecutive on
+    // ONE XCD, so W comes from HBM once and the other G - 1 reads hit that XCD's L2
+    const int G = (P_total + APPEND_CHUNK - 1) / APPEND_CHUNK;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    // longest rows first: the row of W that needs k in [0, j] (lower) or [j, N0) (upper) costs its length
+    const int64_t tiles = (N0 + RT_ROWS - 1) / RT_ROWS;
+    const int64_t tsel = (int64_t)(idx / G) * 8 + xcd;
+    const int64_t j0 = (upper ? tsel : tiles - 1 - tsel) * RT_ROWS;
+    const int r0 = (idx % G) * APPEND_CHUNK;
+    const int P = min(APPEND_CHUNK, P_total - r0);
+    if (j0 < 0 || j0 >= N0 || P <= 0) return;
+    rows += (int64_t)r0 * ldr;
+    out += (int64_t)r0 * ldo;
+    double a[64];   // a[8 i + r]: row j0 + i, right-hand side r
 #pragma unroll
-    for (int r = 0; r < APPEND_CHUNK; ++r) s[r] = 0.0;
-    const int64_t k_lo = upper ? j : 0, k_hi = upper ? N0 : j + 1;
+    for (int t = 0; t < 64; ++t) a[t] = 0.0;
+    const int64_t k_lo = upper ? j0 : 0, k_hi = upper ? N0 : min(N0, j0 + RT_ROWS);
 #pragma unroll 2
-    for (int64_t k = k_lo + threadIdx.x; k < k_hi; k += 256) {
-        const double w = W[j * ld + k];
+    for (int64_t k = k_lo + threadIdx.x; k < k_hi; k += RT_THREADS) {
+        double w[RT_ROWS], v[APPEND_CHUNK];
 #pragma unroll
-        for (int r = 0; r < APPEND_CHUNK; ++r)
-            if (r < P) s[r] += w * rows[r * ldr + k];
-    }
+        for (int i = 0; i < RT_ROWS; ++i) {
+            const int64_t j = j0 + i;
+            const bool valid = j < N0 && (upper ? k >= j : k <= j);
+            w[i] = valid ? W[j * ld + k] : 0.0;
+        }
 #pragma unroll
-    for (int r = 0; r < APPEND_CHUNK; ++r) {
-        double v = s[r];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) red[wave][r] = v;
+        for (int r = 0; r < APPEND_CHUNK; ++r) v[r] = r < P ? rows[r * ldr + k] : 0.0;
+#pragma unroll
+        for (int i = 0; i < RT_ROWS; ++i)
+#pragma unroll
+            for (int r = 0; r < APPEND_CHUNK; ++r) a[8 * i + r] += w[i] * v[r];
     }
+    // recursive halving: after the step with offset o the lane keeps the half of its sums selected by bit o of its id
+#pragma unroll
+    for (int o = 32, n = 64; o >= 1; o >>= 1, n >>= 1) {
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int t = 0; t < n / 2; ++t) {
+            const double send = up ? a[t] : a[t + n / 2];
+            const double keep = up ? a[t + n / 2] : a[t];
+            a[t] = keep + __shfl_xor(send, o);
+        }
+    }
+    red[wave][lane] = a[0];
     __syncthreads();
-    if (threadIdx.x < P) out[threadIdx.x * ldo + j] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x >> 3, r = threadIdx.x & 7;
+        const int t = threadIdx.x;
+        const double sum = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+        if (r < P && j0 + i < N0) out[(int64_t)r * ldo + j0 + i] = sum;
+    }
 }
 
 // One workgroup: S = K22 - L21 L21' (p x p), L22 = chol(S), W22 = L22^-1.
@@ -747,24 +784,8 @@ __global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, doubl
 // ---- small-batch posterior (R <= SMALL_R): the default use of the reference (10 L-BFGS restarts) scores a handful
 // of candidates per call.  A 128 x 64 MFMA tile would be almost empty and the call latency-bound by the longest K
 // loop; instead V' = K*' W' is computed row-wise like the incremental append (one pass over W per 8 candidates,
-// HBM-bound), k_small_finish turns V' into (sum v^2, mu - beta), and U' = V' W is the same row-wise kernel on W'.
+// HBM-bound), k_small_finish (kernels_score.hip) turns V' into (sum v^2, mu - beta) and scores, and U' = V' W is the
+// same row-wise kernel on W'.
 constexpr int SMALL_R = 32;
-
-// one block per candidate r:  q[r] = sum_{j<N} V'[r][j]^2,  mu_raw[r] = V'[r][N] (the alpha row)
-__global__ __launch_bounds__(256) void k_small_finish(const double* __restrict__ VT, int64_t ldv, int64_t N,
-                                                      double* __restrict__ q, double* __restrict__ mu_raw) {
-    __shared__ double red[256];
-    const int r = blockIdx.x;
-    const double* v = VT + (int64_t)r * ldv;
-    double s = 0.0;
-    for (int64_t j = threadIdx.x; j < N; j += 256) s += v[j] * v[j];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { q[r] = red[0]; mu_raw[r] = v[N]; }
-}
 
 }  // namespace bohip
