@@ -247,11 +247,18 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None):
         starts = latin_hypercube_sampling(lb, ub, restarts, rng)
         iters = max(2, min(maxeval, 200))
 
-        def fg(X):
+        ftol, xtol = float(opts.get("ftol_rel", 1e-10)), float(opts.get("xtol_abs", 1e-10))
+        if hasattr(model, "ascend"):                              # device model: the whole search runs in libbohip
+            f, X, bf, bi, bx, _ = model.ascend(acq, p, lb, ub, starts, iters, ftol, xtol)
+            if bi >= 0:
+                return float(bf), np.array(bx)
+            warnings.warn("acquisition returned no finite value; keeping the lower bounds as maximiser")
+            return maxf, maxx
+
+        def fg(X):                                                # host restatement of the same search (test models)
             return model.score_grad(acq, p, X)
 
-        f, X = _batched_lbfgs_ascent(fg, starts, lb, ub, iters,
-                                     ftol_rel=float(opts.get("ftol_rel", 1e-10)), xtol_abs=float(opts.get("xtol_abs", 1e-10)))
+        f, X = _batched_lbfgs_ascent(fg, starts, lb, ub, iters, ftol_rel=ftol, xtol_abs=xtol)
     else:
         n = max(restarts, min(maxeval * restarts, 1 << 20))
         X = latin_hypercube_sampling(lb, ub, n, rng)

@@ -16,6 +16,7 @@
 #include "../../include/bohip.h"
 #include "kernels_linalg.hip"
 #include "kernels_score.hip"
+#include "kernels_ascent.hip"
 
 #include <algorithm>
 #include <cmath>
@@ -84,6 +85,14 @@ struct bohip_gp {
     // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
     // 2-3 device-to-host copies of a call cost more than its kernels (each ~8 us of API + DMA set-up)
     double* hpin = nullptr;      // [score 32 | mu 32 | var 32 | best 2 | grad 32 DMAX]
+    // lock-step L-BFGS ascent of acquire_max (kernels_ascent.hip)
+    AscentState asc{};
+    double* asc_block = nullptr;   // one allocation behind all double arrays of asc
+    int* asc_ints = nullptr;       // active, accepted
+    int* asc_hints = nullptr;      // pinned: h_accepted, h_active
+    double* asc_bounds = nullptr;  // lb, ub, best_x (3 d doubles) + starts staging is dXs
+    Best* asc_best = nullptr;
+    int64_t asc_cap = 0;
     int64_t grad_cap = 0;
     Best* dthompson = nullptr; // S arg-max records
     double* ddmll_parts = nullptr;  // per-block partial sums of the marginal-likelihood gradient
@@ -187,7 +196,8 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 }
 
 // ---- GEMM launcher --------------------------------------------------------------------------------
-static int g_small_r = SMALL_R;  // batches up to this size take the row-wise path (BOHIP_SMALL_R, <= SMALL_R)
+static int g_small_r = 96;  // batches up to this size take the row-wise path in chunks of SMALL_R (BOHIP_SMALL_R): below ~100
+                            // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
@@ -208,7 +218,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
-    if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_R, std::max(0, atoi(e)));
+    if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(1024, std::max(0, atoi(e)));
     done = true;
     return 0;
 }
@@ -525,26 +535,29 @@ static int ensure_small_counters(bohip_gp* g) {
     HIPCHK(hipMemsetAsync(g->dgcount, 0, (SMALL_R + 1) * sizeof(unsigned), g->stream));
     return 0;
 }
-static int small_posterior(bohip_gp* g, const double* dXs, int64_t R, bool want_u, const AcqParams& ap, double* d_mu,
-                           double* d_var, double* d_score, Best* d_best) {
+// one chunk [r0, r1) of at most SMALL_R candidates; the output pointers are indexed by the GLOBAL candidate number
+static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, bool want_u, const AcqParams& ap,
+                           double* d_mu, double* d_var, double* d_score, Best* d_best) {
     CHK(ensure_small_counters(g));
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), ld = g->ld;
+    const int P = (int)(r1 - r0);
     const KernelHyper hp = make_hyper(g);
     t_begin(g, "kstar");
-    CHK(launch_kstar_any(g, dXs, 0, R, Npad, hp));
+    CHK(launch_kstar_any(g, dXs, r0, r1, Npad, hp));
     t_end(g);
     t_begin(g, "small_V");
     // rows 0..N of W (row N carries alpha'): V'[r][j] = sum_{k<=j} W[j][k] K*'[r][k]
-    CHK(launch_rows_trimv(g, g->dW, N + 1, g->dKsT, (int)R, g->dApp, 0));
-    hipLaunchKernelGGL(k_small_finish, dim3((unsigned)R), dim3(256), 0, g->stream, g->dApp, ld, N, (int)R, g->dq, g->dmu_raw,
-                       g->dgcount + SMALL_R, std::exp(2.0 * g->logsig), g->beta, ap, d_mu, d_var, d_score, d_best);
+    CHK(launch_rows_trimv(g, g->dW, N + 1, g->dKsT, P, g->dApp, 0));
+    hipLaunchKernelGGL(k_small_finish, dim3((unsigned)P), dim3(256), 0, g->stream, g->dApp, ld, N, P, g->dq + r0, g->dmu_raw + r0,
+                       g->dgcount + SMALL_R, std::exp(2.0 * g->logsig), g->beta, ap, d_mu ? d_mu + r0 : nullptr,
+                       d_var ? d_var + r0 : nullptr, d_score ? d_score + r0 : nullptr, d_best);
     HIPCHK(hipGetLastError());
     t_end(g);
     g->q_tiles = 1;
     if (want_u) {
         t_begin(g, "small_U");
         // U'[r][c] = sum_{k>=c} W'[c][k] V'[r][k]
-        CHK(launch_rows_trimv(g, g->dWT, N, g->dApp, (int)R, g->dApp + (int64_t)APP_UT_ROW0 * ld, 1));
+        CHK(launch_rows_trimv(g, g->dWT, N, g->dApp, P, g->dApp + (int64_t)APP_UT_ROW0 * ld, 1));
         t_end(g);
     }
     return 0;
@@ -581,9 +594,17 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
         return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
     }
-    if (R <= g_small_r) {   // row-wise posterior, scoring and arg-max fused into its finish kernel
+    if (R <= g_small_r) {   // row-wise posterior in chunks of SMALL_R, scoring fused into its finish kernel
         CHK(one_time_kernel_setup());
-        return small_posterior(g, dXs, R, false, ap, d_mu, d_var, d_score, d_best);
+        if (R <= SMALL_R) return small_posterior(g, dXs, 0, R, false, ap, d_mu, d_var, d_score, d_best);
+        double* sc = d_score ? d_score : g->dscore;
+        for (int64_t r0 = 0; r0 < R; r0 += SMALL_R)
+            CHK(small_posterior(g, dXs, r0, std::min(R, r0 + SMALL_R), false, ap, d_mu, d_var, sc, nullptr));
+        if (d_best) {
+            hipLaunchKernelGGL(k_argmax_scores, dim3(1), dim3(256), 0, g->stream, sc, (int)R, d_best);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
     }
     CHK(posterior_pass(g, dXs, R));
     const int64_t Npad = round_up(g->n + 1, TILE), Rpad = round_up(R, TILE) + TILE;
@@ -639,10 +660,13 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
     if (R <= g_small_r) {  // the reference's default: a handful of L-BFGS restarts per call
-        CHK(small_posterior(g, dXs, R, true, ap, g->dmu, g->dvar, d_score, nullptr));
-        t_begin(g, "grad");
-        CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld));
-        t_end(g);
+        for (int64_t r0 = 0; r0 < R; r0 += SMALL_R) {
+            const int64_t r1 = std::min(R, r0 + SMALL_R);
+            CHK(small_posterior(g, dXs, r0, r1, true, ap, g->dmu, g->dvar, d_score, nullptr));
+            t_begin(g, "grad");
+            CHK(launch_grad_any(g, dXs, r0, r1, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld));
+            t_end(g);
+        }
         return 0;
     }
     CHK(ensure_grad_scratch(g));
@@ -735,6 +759,11 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dgparts) hipFree(g->dgparts);
     if (g->dgcount) hipFree(g->dgcount);
     if (g->hpin) hipHostFree(g->hpin);
+    if (g->asc_block) hipFree(g->asc_block);
+    if (g->asc_ints) hipFree(g->asc_ints);
+    if (g->asc_hints) hipHostFree(g->asc_hints);
+    if (g->asc_bounds) hipFree(g->asc_bounds);
+    if (g->asc_best) hipFree(g->asc_best);
     if (g->dthompson) hipFree(g->dthompson);
     if (g->ddmll_parts) hipFree(g->ddmll_parts);
     if (g->dVV) hipFree(g->dVV);
@@ -1062,6 +1091,107 @@ int bohip_gp_score_grad(bohip_gp* g, int acq_id, const double* acq_params, const
     }
     t_collect(g);
     return rc;
+}
+
+static int ensure_ascent(bohip_gp* g, int64_t R) {
+    if (g->asc_cap >= R && g->asc_block) return 0;
+    if (g->asc_block) HIPCHK(hipFree(g->asc_block));
+    if (g->asc_ints) HIPCHK(hipFree(g->asc_ints));
+    if (g->asc_hints) HIPCHK(hipHostFree(g->asc_hints));
+    g->asc_block = nullptr; g->asc_ints = nullptr; g->asc_hints = nullptr; g->asc_cap = 0;
+    const int64_t cap = std::max<int64_t>(R, 32), d = g->d, rd = cap * d;
+    HIPCHK(hipMalloc(&g->asc_block, (size_t)((9 + 2 * ASC_M) * rd + 5 * cap) * 8));
+    HIPCHK(hipMalloc(&g->asc_ints, (size_t)2 * cap * sizeof(int)));
+    HIPCHK(hipHostMalloc((void**)&g->asc_hints, (size_t)2 * cap * sizeof(int), hipHostMallocDefault));
+    if (!g->asc_bounds) HIPCHK(hipMalloc(&g->asc_bounds, (size_t)3 * DMAX * 8));
+    if (!g->asc_best) HIPCHK(hipMalloc(&g->asc_best, sizeof(Best)));
+    double* p = g->asc_block;
+    AscentState& a = g->asc;
+    a.X = p; p += rd; a.G = p; p += rd; a.Xt = p; p += rd; a.Gt = p; p += rd; a.Xn = p; p += rd; a.Gn = p; p += rd;
+    a.D = p; p += rd; a.Gp = p; p += rd; a.best_X = p; p += rd;
+    a.S = p; p += ASC_M * rd; a.Y = p; p += ASC_M * rd;
+    a.f = p; p += cap; a.ft = p; p += cap; a.fn = p; p += cap; a.step = p; p += cap; a.best_f = p; p += cap;
+    a.active = g->asc_ints; a.accepted = g->asc_ints + cap;
+    a.h_accepted = g->asc_hints; a.h_active = g->asc_hints + cap;
+    g->asc_cap = cap;
+    return 0;
+}
+
+// acquire_max(acquisition, model, lb, ub, restarts) for the gradient-based methods (reference src/acquisition.jl:48-68 with
+// nlopt_setup :23-35): lock-step projected L-BFGS ascent from R start columns, state resident in HBM.
+int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, const double* lb, const double* ub,
+                         const double* starts, int64_t R, int64_t maxeval, double ftol_rel, double xtol_abs, double* x_out,
+                         double* f_out, bohip_best* best, double* best_x, int64_t* evals_out) {
+    if (!g || !lb || !ub || R < 0 || (R > 0 && !starts)) return fail(BOHIP_E_ARG, "bad arguments");
+    if (acq_id < 0 || acq_id > BOHIP_ACQ_MAXMEAN) return fail(BOHIP_E_ARG, "unknown acq_id");
+    if (acq_id != BOHIP_ACQ_MAXMEAN && !acq_params) return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
+    if (evals_out) *evals_out = 0;
+    if (R == 0) {
+        if (best) { best->val = -INFINITY; best->idx = -1; }
+        return 0;
+    }
+    if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
+    HIPCHK(hipSetDevice(g->device));
+    t_reset(g);
+    const int d = g->d;
+    for (int k = 0; k < d; ++k)
+        if (!(lb[k] <= ub[k])) return fail(BOHIP_E_ARG, "lowerbounds must not exceed upperbounds");
+    CHK(ensure_fresh(g));
+    CHK(ensure_xs(g, R));
+    CHK(ensure_score_scratch(g, R));
+    CHK(ensure_ascent(g, R));
+    AscentState& st = g->asc;
+    double* dlb = g->asc_bounds;
+    double* dub = dlb + DMAX;
+    double* dbx = dub + DMAX;
+    HIPCHK(hipMemcpyAsync(dlb, lb, (size_t)d * 8, hipMemcpyHostToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(dub, ub, (size_t)d * 8, hipMemcpyHostToDevice, g->stream));
+    HIPCHK(hipMemcpyAsync(g->dXs, starts, (size_t)R * d * 8, hipMemcpyHostToDevice, g->stream));
+    double span = INFINITY;
+    for (int k = 0; k < d; ++k) span = std::min(span, ub[k] - lb[k] + 1e-300);
+    const unsigned nR = (unsigned)R;
+    auto any_of = [&](const int* v, int want) {
+        for (int64_t r = 0; r < R; ++r)
+            if ((v[r] != 0) == (want != 0)) return true;
+        return false;
+    };
+    hipLaunchKernelGGL(k_asc_start, dim3(nR), dim3(64), 0, g->stream, st, d, g->dXs, dlb, dub);
+    CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
+    hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(g->stream));
+    int64_t evals = 1;
+    int nh = 0, it = 0;
+    bool any_active = any_of(st.h_active, 1);
+    while (evals < maxeval && any_active) {
+        hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, nh, (it + ASC_M - 1) % ASC_M, dlb, dub,
+                           0.1 * span);
+        for (int bt = 0; bt < 12; ++bt) {   // backtracking Armijo, all start points per device pass
+            CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
+            ++evals;
+            hipLaunchKernelGGL(k_asc_linesearch, dim3(nR), dim3(64), 0, g->stream, st, d, dlb, dub);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(g->stream));
+            if (bt == 0 && it > 0) any_active = any_of(st.h_active, 1);   // written by the previous k_asc_update
+            if (!any_of(st.h_accepted, 0) || evals >= maxeval || !any_active) break;
+        }
+        if (!any_active) { --evals; break; }   // the speculative evaluation of an already converged set is not counted
+        hipLaunchKernelGGL(k_asc_update, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, it % ASC_M, ftol_rel, xtol_abs);
+        nh = std::min(nh + 1, ASC_M);
+        ++it;
+    }
+    hipLaunchKernelGGL(k_asc_final, dim3(1), dim3(256), 0, g->stream, st, d, (int)R, g->asc_best, dbx);
+    HIPCHK(hipGetLastError());
+    if (f_out) HIPCHK(hipMemcpyAsync(f_out, st.best_f, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
+    if (x_out) HIPCHK(hipMemcpyAsync(x_out, st.best_X, (size_t)R * d * 8, hipMemcpyDeviceToHost, g->stream));
+    if (best) HIPCHK(hipMemcpyAsync(best, g->asc_best, sizeof(Best), hipMemcpyDeviceToHost, g->stream));
+    if (best_x) HIPCHK(hipMemcpyAsync(best_x, dbx, (size_t)d * 8, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (best && best_x && best->idx < 0)
+        for (int k = 0; k < d; ++k) best_x[k] = lb[k];   // :56  maxx = lowerbounds when nothing beat -Inf
+    if (evals_out) *evals_out = evals;
+    t_collect(g);
+    return 0;
 }
 
 double bohip_thompson_normal(uint64_t seed, int64_t s, int64_t j) { return thompson_normal(seed, s, j); }

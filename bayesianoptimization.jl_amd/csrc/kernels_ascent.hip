@@ -1,0 +1,210 @@
+// kernels_ascent.hip -- SURVEY.md section 8(f) N1: the local search of acquire_max (reference src/acquisition.jl:48-68,
+// NLopt :LD_LBFGS with box bounds, :23-35) as a LOCK-STEP projected L-BFGS ascent of all R start points on the device.
+// One wave per start point, lane k = coordinate k (d <= 64), inner products by wave butterflies; the expensive part of an
+// iteration -- value and gradient of the acquisition at R trial points -- is ONE score_grad pass of the model.
+// The state (X, f, G, curvature pairs, best point seen) never leaves HBM; per evaluation the host reads one
+// int per start point from pinned memory to steer the backtracking.
+//   k_asc_start      X <- clip(starts), first trial = X
+//   k_asc_adopt      after the first evaluation: f, G, active, best
+//   k_asc_direction  two-loop recursion over the (<= 8) curvature pairs, bound blocking, first trial point
+//   k_asc_linesearch Armijo test of the trial; on failure halve the step and write the next trial
+//   k_asc_update     curvature pair, convergence tests (ftol_rel, xtol_abs), best point
+//   k_asc_final      arg-max over the start points, strict '>' => first maximum wins (:58-66)
+#include "common.h"
+
+namespace bohip {
+
+constexpr int ASC_M = 8;   // curvature pairs kept
+
+struct AscentState {
+    double *X, *f, *G;          // [R][d], [R], [R][d]   current point
+    double *Xt, *ft, *Gt;       // trial point and its evaluation (Xt is the candidate block of score_grad)
+    double *Xn, *fn, *Gn;       // accepted point of this iteration
+    double *D, *Gp, *step;      // direction, projected gradient, step length
+    double *S, *Y;              // [ASC_M][R][d] curvature pairs (zero rows where s'y was not positive)
+    double *best_f, *best_X;
+    int *active, *accepted;
+    int *h_accepted, *h_active; // pinned host mirrors read by the driver loop
+};
+
+__device__ __forceinline__ double asc_wsum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double asc_clip(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+__global__ __launch_bounds__(64) void k_asc_start(AscentState st, int d, const double* __restrict__ starts,
+                                                  const double* __restrict__ lb, const double* __restrict__ ub) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    if (k >= d) return;
+    const double x = asc_clip(starts[(int64_t)r * d + k], lb[k], ub[k]);
+    st.X[(int64_t)r * d + k] = x;
+    st.Xt[(int64_t)r * d + k] = x;
+}
+
+__global__ __launch_bounds__(64) void k_asc_adopt(AscentState st, int d) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    const double f = st.ft[r];
+    if (k < d) {
+        st.G[(int64_t)r * d + k] = st.Gt[(int64_t)r * d + k];
+        st.best_X[(int64_t)r * d + k] = st.X[(int64_t)r * d + k];
+    }
+    if (k == 0) {
+        st.f[r] = f;
+        st.best_f[r] = f;
+        const int a = isfinite(f) ? 1 : 0;
+        st.active[r] = a;
+        st.h_active[r] = a;
+    }
+}
+
+// nh curvature pairs are valid; the newest sits in slot (newest), older ones in the slots before it (ring of ASC_M)
+__global__ __launch_bounds__(64) void k_asc_direction(AscentState st, int d, int R, int nh, int newest,
+                                                      const double* __restrict__ lb, const double* __restrict__ ub,
+                                                      double first_step_scale) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    const bool on = k < d;
+    const int64_t o = (int64_t)r * d + k;
+    const double x = on ? st.X[o] : 0.0, g = on ? st.G[o] : 0.0;
+    const double lo = on ? lb[k] : 0.0, hi = on ? ub[k] : 0.0;
+    double q = g;
+    double al[ASC_M], rho[ASC_M];
+#pragma unroll
+    for (int i = 0; i < ASC_M; ++i) {   // newest -> oldest
+        if (i >= nh) break;
+        const int slot = (newest - i + ASC_M) % ASC_M;
+        const int64_t ho = ((int64_t)slot * R + r) * d + k;
+        const double s = on ? st.S[ho] : 0.0, y = on ? st.Y[ho] : 0.0;
+        rho[i] = 1.0 / fmax(asc_wsum(y * s), 1e-300);
+        al[i] = rho[i] * asc_wsum(s * q);
+        q -= al[i] * y;
+    }
+    if (nh > 0) {
+        const int64_t ho = ((int64_t)newest * R + r) * d + k;
+        const double s = on ? st.S[ho] : 0.0, y = on ? st.Y[ho] : 0.0;
+        const double sy = asc_wsum(s * y), yy = fmax(asc_wsum(y * y), 1e-300);
+        q *= sy > 0.0 ? sy / yy : 1.0;
+    }
+#pragma unroll
+    for (int i = ASC_M - 1; i >= 0; --i) {   // oldest -> newest
+        if (i >= nh) continue;
+        const int slot = (newest - i + ASC_M) % ASC_M;
+        const int64_t ho = ((int64_t)slot * R + r) * d + k;
+        const double s = on ? st.S[ho] : 0.0, y = on ? st.Y[ho] : 0.0;
+        const double b = rho[i] * asc_wsum(y * q);
+        q += (al[i] - b) * s;
+    }
+    // do not push active constraints outward; fall back to the projected gradient if that is no ascent direction
+    double D = q;
+    if ((x <= lo && D < 0.0) || (x >= hi && D > 0.0)) D = 0.0;
+    const double gp = ((x <= lo && g < 0.0) || (x >= hi && g > 0.0)) ? 0.0 : g;
+    double slope = asc_wsum(on ? gp * D : 0.0);
+    if (!(slope > 0.0)) {
+        D = gp;
+        slope = asc_wsum(on ? gp * gp : 0.0);
+    }
+    const int active = st.active[r];
+    double step = 1.0;
+    if (nh == 0) step = 1.0 / fmax(sqrt(asc_wsum(on ? D * D : 0.0)), 1e-12) * first_step_scale;
+    if (!(active && slope > 0.0)) step = 0.0;
+    if (on) {
+        st.D[o] = D;
+        st.Gp[o] = gp;
+        st.Xn[o] = x;
+        st.Gn[o] = g;
+        st.Xt[o] = asc_clip(x + step * D, lo, hi);
+    }
+    if (k == 0) {
+        st.step[r] = step;
+        st.fn[r] = st.f[r];
+        const int acc = (!active || !(slope > 0.0)) ? 1 : 0;
+        st.accepted[r] = acc;
+        st.h_accepted[r] = acc;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_asc_linesearch(AscentState st, int d, const double* __restrict__ lb,
+                                                       const double* __restrict__ ub) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    if (st.accepted[r]) return;
+    const bool on = k < d;
+    const int64_t o = (int64_t)r * d + k;
+    const double x = on ? st.X[o] : 0.0, xt = on ? st.Xt[o] : 0.0, gp = on ? st.Gp[o] : 0.0;
+    const double dot = asc_wsum(on ? gp * (xt - x) : 0.0);
+    const double ft = st.ft[r], f = st.f[r];
+    const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
+    if (ok) {
+        if (on) {
+            st.Xn[o] = xt;
+            st.Gn[o] = st.Gt[o];
+        }
+        if (k == 0) {
+            st.fn[r] = ft;
+            st.accepted[r] = 1;
+            st.h_accepted[r] = 1;
+        }
+    } else {
+        const double step = st.step[r] * 0.5;
+        if (on) st.Xt[o] = asc_clip(x + step * st.D[o], lb[k], ub[k]);
+        if (k == 0) st.step[r] = step;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R, int slot, double ftol_rel, double xtol_abs) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    const bool on = k < d;
+    const int64_t o = (int64_t)r * d + k;
+    const double x = on ? st.X[o] : 0.0, xn = on ? st.Xn[o] : 0.0, g = on ? st.G[o] : 0.0, gn = on ? st.Gn[o] : 0.0;
+    const double s = xn - x, y = -(gn - g);
+    const double f = st.f[r], fn = st.fn[r], df = fn - f, best_before = st.best_f[r];
+    const double moved = sqrt(asc_wsum(s * s));
+    const bool good = asc_wsum(s * y) > 1e-14;
+    int active = st.active[r];
+    active = (active && df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs) ? 1 : 0;
+    if (on) {
+        const int64_t ho = ((int64_t)slot * R + r) * d + k;
+        st.S[ho] = good ? s : 0.0;
+        st.Y[ho] = good ? y : 0.0;
+        st.X[o] = xn;
+        st.G[o] = gn;
+        st.Xt[o] = xn;
+        if (fn > best_before) st.best_X[o] = xn;
+    }
+    if (k == 0) {
+        st.f[r] = fn;
+        if (fn > best_before) st.best_f[r] = fn;
+        st.active[r] = active;
+        st.h_active[r] = active;
+    }
+}
+
+// (value desc, index asc) over best_f; NaN never wins.  One workgroup.
+__global__ __launch_bounds__(256) void k_asc_final(AscentState st, int d, int R, Best* __restrict__ best,
+                                                   double* __restrict__ best_x) {
+    __shared__ double sv[256];
+    __shared__ long long si[256];
+    double v = -INFINITY;
+    long long idx = -1;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const double f = st.best_f[r];
+        if (f > -INFINITY && (idx < 0 || f > v)) { v = f; idx = r; }   // ascending r within a thread: first maximum wins
+    }
+    sv[threadIdx.x] = v;
+    si[threadIdx.x] = idx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const double ov = sv[threadIdx.x + o];
+            const long long oi = si[threadIdx.x + o];
+            const double mv = sv[threadIdx.x];
+            const long long mi = si[threadIdx.x];
+            if (oi >= 0 && (mi < 0 || ov > mv || (ov == mv && oi < mi))) { sv[threadIdx.x] = ov; si[threadIdx.x] = oi; }
+        }
+        __syncthreads();
+    }
+    const long long w = si[0];
+    if (threadIdx.x == 0) { best->val = w >= 0 ? sv[0] : -INFINITY; best->idx = w; }
+    if (w >= 0 && (int)threadIdx.x < d) best_x[threadIdx.x] = st.best_X[w * d + threadIdx.x];
+}
+
+}  // namespace bohip

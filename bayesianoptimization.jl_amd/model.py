@@ -210,6 +210,29 @@ class ElasticGPE:
         check(self._lib.bohip_gp_score_grad(self._h, _lib.ACQ[acq], _ptr(p), _ptr(xs), R, _ptr(sc), _ptr(grad)))
         return sc, grad
 
+    def ascend(self, acq, params, lowerbounds, upperbounds, starts, maxeval=200, ftol_rel=1e-10, xtol_abs=1e-10):
+        """Local search of acquire_max on the device (src/acquisition.jl:48-68 with :LD_LBFGS and bounds): every start
+        column is refined by a projected L-BFGS ascent, all columns in lock step.  Returns
+        (f[R], X[d, R], best_f, best_index, best_x[d], evaluations)."""
+        starts = _cols(starts, self.dim)
+        R = starts.shape[1]
+        p = np.ascontiguousarray(np.atleast_1d(np.asarray(params, dtype=np.float64)))
+        if p.size < 2:
+            p = np.concatenate([p, np.zeros(2 - p.size)])
+        lb = np.ascontiguousarray(lowerbounds, dtype=np.float64)
+        ub = np.ascontiguousarray(upperbounds, dtype=np.float64)
+        if lb.size != self.dim or ub.size != self.dim:
+            raise ValueError("bounds must have one entry per input dimension")
+        f = np.empty(R)
+        X = np.empty((self.dim, R), order="F")
+        best = Best()
+        bx = np.empty(self.dim)
+        ev = C.c_int64(0)
+        check(self._lib.bohip_gp_acquire_max(self._h, _lib.ACQ[acq], _ptr(p), _ptr(lb), _ptr(ub), _ptr(starts), R, int(maxeval),
+                                             float(ftol_rel), float(xtol_abs), _ptr(X), _ptr(f), C.byref(best), _ptr(bx),
+                                             C.byref(ev)))
+        return f, X, best.val, best.idx, bx, ev.value
+
     def thompson(self, xs, S, seed=0, j0=0):
         xs = _cols(xs, self.dim)
         out = (Best * S)()

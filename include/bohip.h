@@ -113,6 +113,19 @@ int bohip_gp_score(bohip_gp *gp, int acq_id, const double *acq_params, const dou
 int bohip_gp_score_grad(bohip_gp *gp, int acq_id, const double *acq_params, const double *Xs, int64_t R,
                         double *score, double *grad);
 
+/* ---- acquire_max(acquisition, model, lowerbounds, upperbounds, restarts) for the gradient-based methods (reference
+ * src/acquisition.jl:48-68; nlopt_setup :23-35: method :LD_LBFGS, bounds, maxeval, ftol_rel, xtol_abs).
+ * starts: d x R start columns (the reference draws them with latin_hypercube_sampling, src/utils.jl:101-120, from
+ * Julia's global RNG, so they are an input).  Every start is refined by a projected L-BFGS ascent; all starts advance in
+ * lock step, one value+gradient pass of the model per evaluation, the state stays on the device.
+ * x_out (d x R), f_out (R): best point seen per start (nullable).  best / best_x: the maximiser over the starts under
+ * strict '>' (first maximum wins, :58-66); idx = -1 and best_x = lowerbounds if nothing beat -Inf (:55-56).
+ * maxeval bounds the number of model passes (NLopt counts per start; here every start consumes one per pass).      */
+int bohip_gp_acquire_max(bohip_gp *gp, int acq_id, const double *acq_params, const double *lowerbounds,
+                         const double *upperbounds, const double *starts, int64_t R, int64_t maxeval, double ftol_rel,
+                         double xtol_abs, double *x_out, double *f_out, bohip_best *best, double *best_x,
+                         int64_t *evals_out);
+
 /* ---- ThompsonSamplingSimple (reference src/acquisitionfunctions.jl:107-108, myrand
  * src/models/gp.jl:6-7) in its batched form: S independent draws mu_j + sigma_j z_sj over the R
  * candidates, arg-max per draw.  z comes from a counter-based generator keyed (seed, s, j + j0)

@@ -90,6 +90,16 @@ end
 function BO.acquire_max(a::BO.AbstractAcquisition, m::BOHipGPE, lowerbounds, upperbounds, options)
     BO.setparams!(a, m)
     starts = BO.latin_hypercube_sampling(lowerbounds, upperbounds, options.restarts)      # src/utils.jl:101-120
+    if string(options.method)[2] == 'D'                                                   # :31  gradient-based: local search
+        best = Ref(Best(-Inf, -1)); bx = Vector{Float64}(undef, m.dim); ev = Ref{Int64}(0)
+        check(ccall((:bohip_gp_acquire_max, libbohip), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Float64,
+                     Ptr{Float64}, Ptr{Float64}, Ref{Best}, Ptr{Float64}, Ref{Int64}),
+                    m.handle, acqid(a), acqparams(a), Float64.(lowerbounds), Float64.(upperbounds), Matrix{Float64}(starts),
+                    size(starts, 2), options.maxeval, get(options, :ftol_rel, 1e-10), get(options, :xtol_abs, 1e-10),
+                    C_NULL, C_NULL, best, bx, ev))
+        return best[].idx < 0 ? (-Inf, lowerbounds) : (best[].val, bx)
+    end
     _, maxf, j = score(m, a, starts)
     j == 0 ? (-Inf, lowerbounds) : (maxf, starts[:, j])
 end

@@ -440,15 +440,15 @@ def test_full_size_c2_properties(bohip, orc):
 
 
 def test_small_batch_path_agrees_with_mfma_path(bohip, orc):
-    """R <= 32 takes the row-wise small-batch kernels (the reference's default: 10 L-BFGS restarts); larger batches
-    the MFMA engine.  Same numbers to rounding, both against the oracle, values and gradients."""
+    """R <= 96 takes the row-wise small-batch kernels in chunks of 32 (the reference's default: 10 L-BFGS restarts);
+    larger batches the MFMA engine.  Same numbers to rounding, both against the oracle, values and gradients."""
     X, y, Xs = synth(900, 5, 200, seed=23)
     ll = np.linspace(-0.7, -0.3, 5)
     L, alpha = orc.fit(X, y, ll, 0.2, -2.0, 0.1)
     m = make_model(bohip, X, y, ll, 0.2, -2.0, 0.1)
     tau = float(y.max())
     sc_big, g_big = m.score_grad("EI", [tau], Xs.T)                       # MFMA engine
-    for lo, n in [(0, 1), (3, 7), (10, 8), (40, 9), (100, 32)]:           # chunk sizes 1, 7, 8, 8+1, 4x8
+    for lo, n in [(0, 1), (3, 7), (10, 8), (40, 9), (100, 32), (50, 33), (20, 70), (100, 96)]:   # row-wise path: 1..3 chunks of 32
         sc, g = m.score_grad("EI", [tau], Xs[lo:lo + n].T)
         np.testing.assert_allclose(sc, sc_big[lo:lo + n], rtol=1e-11, atol=1e-14)
         np.testing.assert_allclose(g, g_big[:, lo:lo + n], rtol=1e-9, atol=1e-12 * np.abs(g_big).max())
@@ -541,3 +541,49 @@ def test_device_resident_entry_point_matches_host_entry_point(bohip):
     np.testing.assert_array_equal(dsc.cpu().numpy(), sc)
     assert allgather_best(rec, 0, 1) == (bv, bi)
     _lib.check(lib.bohip_gp_set_stream(m._h, None))
+
+
+def test_device_ascent_matches_host_restatement(bohip, orc):
+    """bohip_gp_acquire_max (lock-step projected L-BFGS on the device) against the NumPy restatement of the
+    same search driven by the same device score_grad: same maximisers to optimiser tolerance, never worse than the start,
+    inside the box, first-maximum-wins over the starts."""
+    from bohip.acquisition import _batched_lbfgs_ascent
+
+    X, y, _ = synth(120, 2, 4, seed=12)
+    m = make_model(bohip, X, y, np.array([-1.0, -0.7]), 0.3, -2.0, 0.0)
+    lb, ub = np.zeros(2), np.ones(2)
+    rng = np.random.default_rng(3)
+    for acq, p in [("UCB", [2.0]), ("EI", [float(y.max())]), ("MaxMean", [])]:
+        for R in (1, 7, 40):                      # row-wise path and MFMA path
+            starts = np.asfortranarray(rng.random((2, R)))
+            f0, _ = m.score_grad(acq, p, starts)
+            f, Xb, bf, bi, bx, ev = m.ascend(acq, p, lb, ub, starts, maxeval=200)
+            fh, Xh = _batched_lbfgs_ascent(lambda Z: m.score_grad(acq, p, Z), starts, lb, ub, 200)
+            assert ev >= 1 and ev <= 200
+            assert np.all(f >= f0 - 1e-12) and np.all(Xb >= lb[:, None]) and np.all(Xb <= ub[:, None])
+            # value at the returned point is the returned value
+            fchk, _ = m.score_grad(acq, p, Xb)
+            np.testing.assert_allclose(fchk, f, rtol=1e-9, atol=1e-12)
+            # both searches climb to the same local maxima (same algorithm, different reduction order)
+            np.testing.assert_allclose(f, fh, rtol=1e-5, atol=1e-8)
+            j = int(np.argmax(f))                 # numpy argmax = first maximum
+            assert bi == j and bf == f[j]
+            np.testing.assert_array_equal(bx, Xb[:, j])
+
+
+def test_device_ascent_respects_bounds_and_edge_cases(bohip):
+    X, y, _ = synth(60, 3, 4, seed=2)
+    m = make_model(bohip, X, y, np.zeros(3), 0.0, -1.0, 0.0)
+    lb, ub = np.array([0.2, 0.0, 0.5]), np.array([0.4, 1.0, 0.5])     # third coordinate pinned
+    starts = np.asfortranarray(np.random.default_rng(0).random((3, 5)) * 2 - 0.5)   # partly outside the box
+    f, Xb, bf, bi, bx, ev = m.ascend("UCB", [1.5], lb, ub, starts, maxeval=50)
+    assert np.all(Xb >= lb[:, None] - 0) and np.all(Xb <= ub[:, None] + 0) and np.all(Xb[2] == 0.5)
+    # maxeval = 1: only the clipped starts are evaluated
+    f1, X1, *_ = m.ascend("UCB", [1.5], lb, ub, starts, maxeval=1)
+    np.testing.assert_array_equal(X1, np.clip(starts, lb[:, None], ub[:, None]))
+    # a NaN start never wins and does not poison the others
+    starts[:, 1] = np.nan
+    f2, X2, bf2, bi2, bx2, _ = m.ascend("UCB", [1.5], lb, ub, starts, maxeval=50)
+    assert bi2 != 1 and np.isfinite(bf2)
+    with pytest.raises(ValueError):
+        m.ascend("UCB", [1.5], lb[:2], ub, starts)
