@@ -192,7 +192,10 @@ template <int NJ, int ABL = 0>  // ABL: ablation switches (tools only): 1 no DMA
 __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict__ A, int64_t lda,
                                                         const double* __restrict__ B, int64_t ldb, int kc_begin,
                                                         int kc_end, double* smem, double (&acc)[8][NJ],
-                                                        int active_rows = TILE) {
+                                                        int active_rows = TILE, int tri_kc = 1 << 30) {
+    // tri_kc: first chunk of a 128 x 128 block of A that is LOWER-TRIANGULAR (row r has zeros at k > r): from there on
+    // an 8-row group whose rows all lie above this wave's 8 contraction indices contributes nothing and is skipped
+    // (47 % of that block's MFMAs).
     static_assert(NJ == 4, "piece distribution below assumes 16 + 8 DMA pieces per chunk");
     constexpr int AT = TILE * GL_ROW, BT = 16 * NJ * GL_ROW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,6 +221,7 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
     const int oa = ((4 * khalf + k) ^ r7a) << 1, ob = ((4 * khalf + k) ^ r7b) << 1;
     const int a_frag = (wr * 64 + r7a) * GL_ROW + oa, b_frag = (wc * 8 * NJ + r7b) * GL_ROW + ob;
     const bool wave_active = wr * 64 < active_rows;
+    const int skip0 = __builtin_amdgcn_readfirstlane(khalf - 8 * wr);   // wave-uniform: keep it in an SGPR
     issue(kc_begin, 0);
     if (kc_begin + 1 < kc_end) {
         issue(kc_begin + 1, 1);
@@ -256,22 +260,24 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
             av[0] = ds_read128<0>(pa); av[1] = ds_read128<1024>(pa); av[2] = ds_read128<2048>(pa); av[3] = ds_read128<3072>(pa);
             av[4] = ds_read128<4096>(pa); av[5] = ds_read128<5120>(pa); av[6] = ds_read128<6144>(pa); av[7] = ds_read128<7168>(pa);
             }
+            // row groups below `skip` are all-zero in a triangular block (wave-uniform): 2 (kc - tri_kc) + khalf - 8 wr
+            const int skip = kc >= tri_kc ? 2 * (kc - tri_kc) + skip0 : 0;
             asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(av[0]));
-            mma_row<NJ>(av[0], bv, acc[0]);
+            if (skip <= 0) mma_row<NJ>(av[0], bv, acc[0]);
             asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(av[1]));
-            mma_row<NJ>(av[1], bv, acc[1]);
+            if (skip <= 1) mma_row<NJ>(av[1], bv, acc[1]);
             asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(av[2]));
-            mma_row<NJ>(av[2], bv, acc[2]);
+            if (skip <= 2) mma_row<NJ>(av[2], bv, acc[2]);
             asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(av[3]));
-            mma_row<NJ>(av[3], bv, acc[3]);
+            if (skip <= 3) mma_row<NJ>(av[3], bv, acc[3]);
             asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(av[4]));
-            mma_row<NJ>(av[4], bv, acc[4]);
+            if (skip <= 4) mma_row<NJ>(av[4], bv, acc[4]);
             asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(av[5]));
-            mma_row<NJ>(av[5], bv, acc[5]);
+            if (skip <= 5) mma_row<NJ>(av[5], bv, acc[5]);
             asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(av[6]));
-            mma_row<NJ>(av[6], bv, acc[6]);
+            if (skip <= 6) mma_row<NJ>(av[6], bv, acc[6]);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[7]));
-            mma_row<NJ>(av[7], bv, acc[7]);
+            if (skip <= 7) mma_row<NJ>(av[7], bv, acc[7]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #if BOHIP_TRACE

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
     const int active_rows = (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE);  // rows past alpha' are padding
     if constexpr (KS == 2)
         gemm_tile_loop_glds3_ks<NJ, BOHIP_ABL>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
-                                    (rt + 1) * (TILE / KC), smem, acc, active_rows);
+                                    (rt + 1) * (TILE / KC), smem, acc, active_rows, rt * (TILE / KC));
     else
         gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
                                  (rt + 1) * (TILE / KC), smem, acc, active_rows);
