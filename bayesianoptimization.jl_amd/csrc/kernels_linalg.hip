@@ -29,27 +29,39 @@ __global__ __launch_bounds__(256) void k_build_cov(const double* __restrict__ X,
                                                    KernelHyper hp, double noise, double* __restrict__ K,
                                                    int64_t ld, int rows_per_block) {
 #pragma clang fp contract(off)
-    // thread = column j (its coordinates live in registers); the block walks rows_per_block rows whose
-    // coordinates are wave-uniform (scalar loads).  Stores are coalesced along j.
+    // thread = column j (its coordinates live in registers); the block walks rows_per_block (<= 32) rows whose
+    // coordinates are staged in LDS by one coalesced load: read as wave-uniform scalars straight from memory, hipcc
+    // emits one s_load + s_waitcnt lgkmcnt(0) PER DIMENSION inside `if (k < d)` branches and the kernel is bound by
+    // that latency chain (1.0 TB/s).  Dimensions d <= k < DT carry zero weight instead of a branch.
+    __shared__ double xi_l[32 * DT];
     const int d = hp.d;
     const int64_t j = blockIdx.x * 256 + threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
     if (blockIdx.x * 256 / TILE > (i0 + rows_per_block - 1) / TILE) return;  // whole block above the diagonal tiles
-    double xj[DT];
+    for (int t = threadIdx.x; t < rows_per_block * DT; t += 256) {
+        const int64_t i = i0 + t / DT;
+        const int k = t % DT;
+        xi_l[t] = (i < N && k < d) ? X[i * d + k] : 0.0;
+    }
+    double xj[DT], w[DT];
 #pragma unroll
-    for (int k = 0; k < DT; ++k) xj[k] = (k < d && j < N) ? X[j * d + k] : 0.0;
-    for (int64_t i = i0; i < i0 + rows_per_block && i < Npad; ++i) {
+    for (int k = 0; k < DT; ++k) {
+        xj[k] = (k < d && j < N) ? X[j * d + k] : 0.0;
+        w[k] = k < d ? hp.il2[k] : 0.0;
+    }
+    __syncthreads();
+    for (int c = 0; c < rows_per_block; ++c) {
+        const int64_t i = i0 + c;
+        if (i >= Npad) break;
         if (j >= Npad || j > i) continue;  // only the lower triangle is ever written (the rest stays zero)
         double v;
         if (i < N && j < N) {
-            const double* xi = X + i * d;
             double r = 0.0;
 #pragma unroll
-            for (int k = 0; k < DT; ++k)
-                if (k < d) {
-                    const double t = xi[k] - xj[k];
-                    r += hp.il2[k] * (t * t);
-                }
+            for (int k = 0; k < DT; ++k) {
+                const double t = xi_l[c * DT + k] - xj[k];
+                r += w[k] * (t * t);
+            }
             v = cov_from_r(hp.kern, hp.sigma2, r);
             if (i == j) v += noise;
         } else {

@@ -29,25 +29,36 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ X, int64_t N, int64_t Npad,
                                                const double* __restrict__ Xs, int64_t r_begin, int64_t r_end,
                                                KernelHyper hp, double* __restrict__ KsT, int64_t ldk, int rb) {
+    // the block's rb (<= 16) candidates are staged in LDS by one coalesced load (see k_build_cov: per-dimension scalar
+    // loads behind `if (k < d)` made this kernel latency-bound); dimensions d <= k < DT carry zero weight
+    __shared__ double xs_l[16 * DT];
     const int d = hp.d;
     const int64_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= Npad) return;
-    double xj[DT];
-#pragma unroll
-    for (int k = 0; k < DT; ++k) xj[k] = (k < d && j < N) ? X[j * d + k] : 0.0;
     const int64_t r0 = r_begin + (int64_t)blockIdx.y * rb;
     const int64_t r1 = min(r0 + rb, r_end);
-    for (int64_t r = r0; r < r1; ++r) {
-        const double* xs = Xs + r * d;
+    for (int t = threadIdx.x; t < rb * DT; t += 256) {
+        const int64_t r = r0 + t / DT;
+        const int k = t % DT;
+        xs_l[t] = (r < r1 && k < d) ? Xs[r * d + k] : 0.0;
+    }
+    double xj[DT], w[DT];
+#pragma unroll
+    for (int k = 0; k < DT; ++k) {
+        xj[k] = (k < d && j < N) ? X[j * d + k] : 0.0;
+        w[k] = k < d ? hp.il2[k] : 0.0;
+    }
+    __syncthreads();
+    if (j >= Npad) return;
+    const int nc = (int)(r1 - r0);
+    for (int c = 0; c < nc; ++c) {
         double rr = 0.0;
 #pragma unroll
-        for (int k = 0; k < DT; ++k)
-            if (k < d) {
-                const double t = xj[k] - xs[k];
-                rr += hp.il2[k] * (t * t);
-            }
+        for (int k = 0; k < DT; ++k) {
+            const double t = xj[k] - xs_l[c * DT + k];
+            rr += w[k] * (t * t);
+        }
         const double v = (j < N) ? cov_from_r_fast(hp.kern, hp.sigma2, rr) : 0.0;
-        KsT[(r - r_begin) * ldk + j] = v;
+        KsT[(r0 + c - r_begin) * ldk + j] = v;
     }
 }
 
