@@ -70,6 +70,8 @@ struct bohip_gp {
     hipStream_t stream = nullptr, own_stream = nullptr;
     hipStream_t side_stream = nullptr;            // bulk trailing updates of the factorisation run here (look-ahead)
     hipEvent_t ev_panels = nullptr, ev_bulk = nullptr;
+    hipStream_t inv_stream = nullptr;             // W = L^-1 grows block by block beside the factorisation's diagonal chain
+    hipEvent_t ev_blk = nullptr, ev_inv = nullptr;
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
@@ -196,6 +198,9 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 }
 
 // ---- GEMM launcher --------------------------------------------------------------------------------
+static int g_inv_overlap = 0;  // BOHIP_INV_OVERLAP=1: grow W = L^-1 block by block beside the factorisation instead of after it.
+                               // Measured: refit 3.67 -> 3.56 ms (N=3000), 21.4 -> 19.9 ms (N=10000), but the factorisation itself slows
+                               // down under the competition (2.90 -> 3.08 ms, 13.9 -> 17.7 ms), so it stays opt-in.
 static int g_small_r = 96;  // batches up to this size take the row-wise path in chunks of SMALL_R (BOHIP_SMALL_R): below ~100
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
@@ -218,6 +223,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
+    if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
     if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(1024, std::max(0, atoi(e)));
     done = true;
     return 0;
@@ -248,6 +254,49 @@ static int check_info(bohip_gp* g) {
         return fail(BOHIP_E_NOTPD, "kernel matrix not positive definite at pivot " + std::to_string(info));
     }
     g->pivot = 0;
+    return 0;
+}
+
+// ---- W = L^-1 by blocks:  [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22].  With W' kept beside W both products are
+// K-major x K-major:   S'[c][i]  =  sum_k W11'[c][k] L21[i][k]     (A = W' block, upper-triangular: k >= c)
+//                      W21[i][c] = -sum_k W22[i][k]  S'[c][k]      (A = W22, lower-triangular: k <= i); W21' goes to W' too
+// S' lives in the (otherwise unused) upper-right part of the scratch matrix dS, whose lower part holds the solved panels
+// (= L21; dL receives them only with the final copy).
+// inverse_level: all pairs of half-size h (tiles) inside the diagonal region [t0, t0 + nt), one batched launch each.
+static int inverse_level(bohip_gp* g, hipStream_t st, int t0, int nt, int h) {
+    const int64_t ld = g->ld, base = (int64_t)t0 * TILE * (ld + 1);
+    const int pairs = (nt + 2 * h - 1) / (2 * h);
+    const int64_t zs = (int64_t)2 * h * TILE * (ld + 1);
+    const int64_t off21 = (int64_t)h * TILE * ld, off12 = (int64_t)h * TILE, off22 = (int64_t)h * TILE * (ld + 1);
+    GemmNTParams a{};
+    a.A = g->dWT + base; a.lda = ld; a.B = g->dS + base + off21; a.ldb = ld; a.C = g->dS + base + off12; a.ldc = ld;
+    a.zA = a.zB = a.zC = zs;
+    a.mt = h; a.nt64 = 2 * h; a.kc = h * (TILE / KC); a.alpha = 1.0; a.beta = 0.0; a.klo_from_m = 1;
+    a.row_t0 = 0; a.row_ts = 2 * h; a.col_t0 = h; a.col_ts = 2 * h; a.total_t = nt;
+    CHK(launch_gemm_nt(g, a, pairs, st));
+    GemmNTParams b{};
+    b.A = g->dW + base + off22; b.lda = ld; b.B = g->dS + base + off12; b.ldb = ld; b.C = g->dW + base + off21; b.ldc = ld;
+    b.CT = g->dWT + base + off12; b.ldct = ld;
+    b.zA = b.zB = b.zC = b.zCT = zs;
+    b.mt = h; b.nt64 = 2 * h; b.kc = h * (TILE / KC); b.alpha = -1.0; b.beta = 0.0; b.khi_from_m = 1;
+    b.row_t0 = h; b.row_ts = 2 * h; b.col_t0 = 0; b.col_ts = 2 * h; b.total_t = nt;
+    CHK(launch_gemm_nt(g, b, pairs, st));
+    return 0;
+}
+// inverse_join: the leading P tiles are inverted, so are the nb tiles behind them: fill W[P:P+nb, 0:P] (and its transpose).
+static int inverse_join(bohip_gp* g, hipStream_t st, int P, int nb) {
+    if (P <= 0 || nb <= 0) return 0;
+    const int64_t ld = g->ld;
+    const int64_t off21 = (int64_t)P * TILE * ld, off12 = (int64_t)P * TILE, off22 = (int64_t)P * TILE * (ld + 1);
+    GemmNTParams a{};
+    a.A = g->dWT; a.lda = ld; a.B = g->dS + off21; a.ldb = ld; a.C = g->dS + off12; a.ldc = ld;
+    a.mt = P; a.nt64 = 2 * nb; a.kc = P * (TILE / KC); a.alpha = 1.0; a.beta = 0.0; a.klo_from_m = 1;
+    CHK(launch_gemm_nt(g, a, 1, st));
+    GemmNTParams b{};
+    b.A = g->dW + off22; b.lda = ld; b.B = g->dS + off12; b.ldb = ld; b.C = g->dW + off21; b.ldc = ld;
+    b.CT = g->dWT + off12; b.ldct = ld;
+    b.mt = nb; b.nt64 = 2 * P; b.kc = nb * (TILE / KC); b.alpha = -1.0; b.beta = 0.0; b.khi_from_m = 1;
+    CHK(launch_gemm_nt(g, b, 1, st));
     return 0;
 }
 
@@ -308,6 +357,15 @@ static int refit(bohip_gp* g) {
                 CHK(launch_gemm_nt(g, u));
             }
         }
+        if (g_inv_overlap) {
+            // The block's panels are final: invert its diagonal region and join it to the leading inverse on the inverse
+            // stream, beside the next blocks' diagonal chain (which leaves most CUs idle).  Reads dS panels of columns
+            // < oe (final), W/W' of tiles < oe; writes W/W' rows/columns of THIS block and the upper-right part of dS.
+            HIPCHK(hipEventRecord(g->ev_blk, g->stream));
+            HIPCHK(hipStreamWaitEvent(g->inv_stream, g->ev_blk, 0));
+            for (int h = 1; h < oe - ob; h *= 2) CHK(inverse_level(g, g->inv_stream, ob, oe - ob, h));
+            CHK(inverse_join(g, g->inv_stream, ob, oe - ob));
+        }
         const int rem = T - oe;
         if (rem > 0) {
             // Bulk update with the OB solved panels, split for look-ahead: the columns of the NEXT outer block are
@@ -345,29 +403,12 @@ static int refit(bohip_gp* g) {
         HIPCHK(hipGetLastError());
     }
     t_end(g);
-    // W = L^-1 by recursive doubling over diagonal blocks:  [L11 0; L21 L22]^-1 = [W11 0; -W22 L21 W11, W22].
-    // With W' kept beside W both products are K-major x K-major:
-    //     S'[c][i]  =  sum_k W11'[c][k] L21[i][k]          (A = W' block, upper-triangular: k >= c)
-    //     W21[i][c] = -sum_k W22[i][k]  S'[c][k]           (A = W22, lower-triangular: k <= i); W21' goes to W' too
-    // S' lives in the (otherwise unused) upper-right block of the scratch matrix.  All pairs of a level are one launch.
     t_begin(g, "tri_inverse");
-    for (int h = 1; h < T; h *= 2) {  // h = half-block size in tiles
-        const int pairs = (T + 2 * h - 1) / (2 * h);
-        const int64_t zs = (int64_t)2 * h * TILE * (ld + 1);
-        const int64_t off21 = (int64_t)h * TILE * ld, off12 = (int64_t)h * TILE, off22 = (int64_t)h * TILE * (ld + 1);
-        GemmNTParams a{};
-        a.A = g->dWT; a.lda = ld; a.B = g->dL + off21; a.ldb = ld; a.C = g->dS + off12; a.ldc = ld;
-        a.zA = a.zB = a.zC = zs;
-        a.mt = h; a.nt64 = 2 * h; a.kc = h * (TILE / KC); a.alpha = 1.0; a.beta = 0.0; a.klo_from_m = 1;
-        a.row_t0 = 0; a.row_ts = 2 * h; a.col_t0 = h; a.col_ts = 2 * h; a.total_t = T;
-        CHK(launch_gemm_nt(g, a, pairs));
-        GemmNTParams b{};
-        b.A = g->dW + off22; b.lda = ld; b.B = g->dS + off12; b.ldb = ld; b.C = g->dW + off21; b.ldc = ld;
-        b.CT = g->dWT + off12; b.ldct = ld;
-        b.zA = b.zB = b.zC = b.zCT = zs;
-        b.mt = h; b.nt64 = 2 * h; b.kc = h * (TILE / KC); b.alpha = -1.0; b.beta = 0.0; b.khi_from_m = 1;
-        b.row_t0 = h; b.row_ts = 2 * h; b.col_t0 = 0; b.col_ts = 2 * h; b.total_t = T;
-        CHK(launch_gemm_nt(g, b, pairs));
+    if (g_inv_overlap) {   // only the tail of the last block's join is still running
+        HIPCHK(hipEventRecord(g->ev_inv, g->inv_stream));
+        HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
+    } else {               // recursive doubling over the whole matrix after the factorisation
+        for (int h = 1; h < T; h *= 2) CHK(inverse_level(g, g->stream, 0, T, h));
     }
     t_end(g);
     t_begin(g, "alpha");
@@ -732,6 +773,9 @@ int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohi
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->side_stream, hipStreamNonBlocking, prio_lo);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_panels, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_bulk, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->inv_stream, hipStreamNonBlocking, prio_lo);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_blk, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_inv, hipEventDisableTiming);
     if (e != hipSuccess) { delete g; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
     g->stream = g->own_stream;
     if (hipHostMalloc((void**)&g->hpin, (size_t)(3 * SMALL_R + 2 + SMALL_R * DMAX) * 8, hipHostMallocDefault) != hipSuccess) g->hpin = nullptr;
@@ -773,6 +817,9 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->side_stream) { hipStreamSynchronize(g->side_stream); hipStreamDestroy(g->side_stream); }
     if (g->ev_panels) hipEventDestroy(g->ev_panels);
     if (g->ev_bulk) hipEventDestroy(g->ev_bulk);
+    if (g->inv_stream) { hipStreamSynchronize(g->inv_stream); hipStreamDestroy(g->inv_stream); }
+    if (g->ev_blk) hipEventDestroy(g->ev_blk);
+    if (g->ev_inv) hipEventDestroy(g->ev_inv);
     if (g->own_stream) hipStreamDestroy(g->own_stream);
     delete g;
 }
