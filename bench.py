@@ -6,7 +6,8 @@ per GPU; at --gpus G the candidate set is R*G sharded over G ranks = configs[2] 
 One "step" = one pass of the hot path over one batch of candidates already resident in HBM:
 k_kstar (cross-covariances) -> k_trigemm_sq (V = L^-1 K*, sum v^2, mu) -> k_score (sigma^2, EI,
 block arg-max) -> k_argmax_final, then (G > 1) ONE RCCL all_gather of the 16-byte (value, index)
-record per rank and an identical local reduce, then the 16-byte result is read back by the host.
+record per rank and an identical local reduce; the 16-byte result is read by the host (G = 1: the kernel
+writes it into pinned host memory, read after the stream synchronisation).
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -158,11 +159,21 @@ def main():
     # (f64 value bits, i64 local index) written by the kernel + this rank's global column offset: the unit of the
     # single all_gather; the offset rides along so the exchange needs no other device work
     d_best = torch.tensor([0, -1, lo], dtype=torch.int64, device=dev)
+    # one GPU: the 16-byte result record is written by the arg-max kernel straight into pinned host memory and read
+    # after the stream synchronisation (no copy command); G > 1: it stays on the device for the RCCL all_gather
+    h_best = torch.tensor([0, -1, lo], dtype=torch.int64).pin_memory()
+    h_best_np = h_best.numpy()
     stream = torch.cuda.current_stream()
     _lib.check(lib.bohip_gp_set_stream(model._h, C.c_void_p(stream.cuda_stream)))
     params = (C.c_double * 2)(tau, 0.0)
 
     def step():
+        if not use_dist:
+            _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()),
+                                              R_PER_GPU, None, C.c_void_p(h_best.data_ptr())))
+            _lib.check(lib.bohip_gp_synchronize(model._h))
+            i = int(h_best_np[1])
+            return (float(h_best_np[:1].view(np.float64)[0]), i + lo) if i >= 0 else (-np.inf, -1)
         _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()),
                                           R_PER_GPU, None, C.c_void_p(d_best.data_ptr())))
         val, idx = allgather_best(d_best, lo, world, force_collective=use_dist)  # RCCL all_gather of 16 B/rank + local reduce
