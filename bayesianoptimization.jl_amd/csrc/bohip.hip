@@ -106,6 +106,8 @@ struct bohip_gp {
     int64_t pivot = 0, refits = 0, appends = 0;
     int q_tiles = 0;  // number of q_part rows the last posterior pass produced (T, or 1 on the small-batch path)
     bool timing = false;
+    bool t_open = false;
+    bool timing_dominant_only = false;   // enable_timing(2): only the dominant kernel (k_trigemm_sq) is bracketed by events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tpool;  // pooled event pairs
     size_t tused = 0;
     std::vector<const char*> tlabel;
@@ -124,8 +126,13 @@ static KernelHyper make_hyper(const bohip_gp* g) {
 }
 
 // ---- stage timing (HIP events on the handle's stream; the event pairs are pooled, not re-created per call) -------
+static bool t_skip(const bohip_gp* g, const char* name) {
+    return g->timing_dominant_only && std::strncmp(name, "trigemm_sq", 10) != 0;
+}
 static void t_begin(bohip_gp* g, const char* name) {
     if (!g->timing) return;
+    g->t_open = !t_skip(g, name);
+    if (!g->t_open) return;
     if (g->tused == g->tpool.size()) {
         hipEvent_t a, b;
         hipEventCreate(&a);
@@ -137,7 +144,8 @@ static void t_begin(bohip_gp* g, const char* name) {
     ++g->tused;
 }
 static void t_end(bohip_gp* g) {
-    if (!g->timing || g->tused == 0) return;
+    if (!g->timing || g->tused == 0 || !g->t_open) return;
+    g->t_open = false;
     hipEventRecord(g->tpool[g->tused - 1].second, g->stream);
 }
 static void t_reset(bohip_gp* g) {
@@ -1312,6 +1320,7 @@ int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
 int bohip_gp_enable_timing(bohip_gp* g, int on) {
     if (!g) return fail(BOHIP_E_ARG, "null handle");
     g->timing = on != 0;
+    g->timing_dominant_only = on == 2;
     return 0;
 }
 int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {

@@ -256,7 +256,7 @@ class ElasticGPE:
         check(self._lib.bohip_gp_info(self._h, what, C.byref(v)))
         return v.value
 
-    def enable_timing(self, on=True):
+    def enable_timing(self, on=True):                    # True/1: every stage; 2: only the dominant kernel
         check(self._lib.bohip_gp_enable_timing(self._h, int(on)))
 
     def timing(self):

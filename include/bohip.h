@@ -156,7 +156,9 @@ int bohip_gp_get_alpha(bohip_gp *gp, double *alpha);
 #define BOHIP_INFO_APPENDS 3      /* number of incremental factor extensions so far              */
 int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
 /* per-stage device times (ms, HIP events on the handle's stream) of the LAST call when timing
- * is enabled: names/values for up to `cap` stages; returns the number of stages.            */
+ * is enabled: names/values for up to `cap` stages; returns the number of stages.
+ * on = 1: every stage; on = 2: only the dominant kernel (k_trigemm_sq) is bracketed by events -- two
+ * event records per call instead of six (the records themselves cost ~4 us each on the stream).   */
 int bohip_gp_enable_timing(bohip_gp *gp, int on);
 int bohip_gp_get_timing(bohip_gp *gp, const char **names, double *ms, int cap);
 
