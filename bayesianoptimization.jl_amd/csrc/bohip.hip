@@ -238,15 +238,15 @@ static int one_time_kernel_setup() {
 }
 
 // ---- A1-A3: full rebuild --------------------------------------------------------------------------
+static int launch_rows_trimv(bohip_gp* g, const double* W, int64_t N0, const double* rows, int P, double* out, int upper);
 static int compute_alpha(bohip_gp* g) {
+    // alpha = W'(W (y - beta)): two passes of the row-wise kernel (W, then the resident W' as an upper-triangular
+    // K-major matrix) with one right-hand side
     const int64_t N = g->n;
     hipLaunchKernelGGL(k_sub_mean, dim3((N + 255) / 256), dim3(256), 0, g->stream, g->dy, g->beta, N, g->dr);
-    hipLaunchKernelGGL(k_trimv, dim3((N + 3) / 4), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dr, g->dt);
-    const int nsplit = 16;  // dApp doubles as the [nsplit][ld] partial buffer (APP_ROWS = 64 >= 16)
-    hipLaunchKernelGGL(k_trimv_t_part, dim3((N + 63) / 64, nsplit), dim3(256), 0, g->stream, g->dW, g->ld, N, g->dt, nsplit,
-                       g->dApp, g->ld);
-    hipLaunchKernelGGL(k_sum_parts, dim3((N + 255) / 256), dim3(256), 0, g->stream, g->dApp, g->ld, nsplit, N, g->dalpha);
     HIPCHK(hipGetLastError());
+    CHK(launch_rows_trimv(g, g->dW, N, g->dr, 1, g->dt, 0));
+    CHK(launch_rows_trimv(g, g->dWT, N, g->dt, 1, g->dalpha, 1));
     // alpha' into the first padding row of W (cols < N); W[N][N] = 1 meets K*[N] = 0.
     HIPCHK(hipMemcpyAsync(g->dW + N * g->ld, g->dalpha, (size_t)N * 8, hipMemcpyDeviceToDevice, g->stream));
     return 0;

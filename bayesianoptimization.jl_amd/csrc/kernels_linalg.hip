@@ -3,7 +3,7 @@
 //   k_potf2_inv      128x128 diagonal block: Cholesky + triangular inverse in LDS (latency bound)
 //   k_gemm_nt        FP64 MFMA contraction C = alpha*A*B' + beta*C, both operands K-major (panel solve,
 //                    trailing updates, recursive triangular inverse W = L^-1, U' = V'W of the gradient path)
-//   k_trimv / k_trimv_t, k_sub_mean, k_mll  -- alpha = W'(W(y - beta)) and the marginal likelihood
+//   k_sub_mean, k_rows_trimv, k_mll  -- alpha = W'(W(y - beta)) and the marginal likelihood
 // Reference call sites replaced: update!/append!/fit! in src/models/gp.jl:11-18 (GaussianProcesses.jl
 // update_cK! + ElasticPDMats Cholesky behind them).
 #include "gemm_core.h"
@@ -453,50 +453,11 @@ __global__ __launch_bounds__(256) void k_copy_offdiag_tiles(const double* __rest
 
 
 // ------------------------------------------------------------------------------------------------
-// A3: alpha = W' (W (y - beta)).  W is lower-triangular row-major.
+// A3: alpha = W' (W (y - beta)): k_sub_mean, then two passes of k_rows_trimv (below) on W and on W'.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_sub_mean(const double* __restrict__ y, double beta, int64_t N, double* __restrict__ r) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < N) r[i] = y[i] - beta;
-}
-// t[i] = sum_{j<=i} W[i][j] r[j] : one wave per row, lanes stride j (coalesced), fixed-order butterfly.
-__global__ __launch_bounds__(256) void k_trimv(const double* __restrict__ W, int64_t ld, int64_t N,
-                                               const double* __restrict__ r, double* __restrict__ t) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= N) return;
-    double s = 0.0;
-    for (int64_t j = lane; j <= i; j += 64) s += W[i * ld + j] * r[j];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) t[i] = s;
-}
-// a[j] = sum_{i>=j} W[i][j] t[i].  Stage 1: block = 64 columns x 4 row phases over one of `nsplit` row
-// slices -> part[slice][j]; stage 2 sums the slices in index order (bit-deterministic).
-__global__ __launch_bounds__(256) void k_trimv_t_part(const double* __restrict__ W, int64_t ld, int64_t N,
-                                                      const double* __restrict__ t, int nsplit,
-                                                      double* __restrict__ part, int64_t ldp) {
-    __shared__ double red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t j = blockIdx.x * 64 + tx;
-    const int64_t span = (N + nsplit - 1) / nsplit;
-    const int64_t i_lo = (int64_t)blockIdx.y * span, i_hi = min(N, i_lo + span);
-    double s = 0.0;
-    if (j < N) {
-        int64_t i = max(i_lo, j);
-        i += (ty - (i & 3) + 4) & 3;  // align the row phase so the summation order does not depend on j
-        for (; i < i_hi; i += 4) s += W[i * ld + j] * t[i];
-    }
-    red[ty][tx] = s;
-    __syncthreads();
-    if (ty == 0 && j < N) part[(int64_t)blockIdx.y * ldp + j] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
-}
-__global__ __launch_bounds__(256) void k_sum_parts(const double* __restrict__ part, int64_t ldp, int nsplit, int64_t N,
-                                                   double* __restrict__ out) {
-    const int64_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= N) return;
-    double s = 0.0;
-    for (int q = 0; q < nsplit; ++q) s += part[(int64_t)q * ldp + j];
-    out[j] = s;
 }
 // mll = -0.5 r'alpha - sum log L_ii - N/2 log(2 pi)   (single workgroup, fixed order)
 __global__ __launch_bounds__(256) void k_mll(const double* __restrict__ L, int64_t ld, int64_t N,
