@@ -432,9 +432,15 @@ static int refit(bohip_gp* g) {
 // out[r][j] = (W rows[r])[j] for r < P <= 32: one launch, workgroups of 8 rows of W x 8 right-hand sides
 static int launch_rows_trimv(bohip_gp* g, const double* W, int64_t N0, const double* rows, int P, double* out, int upper) {
     if (N0 <= 0 || P <= 0) return 0;
-    const int64_t tiles = (N0 + RT_ROWS - 1) / RT_ROWS, G = (P + APPEND_CHUNK - 1) / APPEND_CHUNK;
-    hipLaunchKernelGGL(k_rows_trimv, dim3((unsigned)(8 * ((tiles + 7) / 8) * G)), dim3(RT_THREADS), 0, g->stream, W, g->ld, N0, rows,
-                       g->ld, P, out, g->ld, upper);
+    const int64_t tiles = (N0 + RT_ROWS - 1) / RT_ROWS;
+    if (P == 1) {
+        hipLaunchKernelGGL(k_rows_trimv<1>, dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(RT_THREADS), 0, g->stream, W, g->ld, N0,
+                           rows, g->ld, P, out, g->ld, upper);
+    } else {
+        const int64_t G = (P + APPEND_CHUNK - 1) / APPEND_CHUNK;
+        hipLaunchKernelGGL(k_rows_trimv<8>, dim3((unsigned)(8 * ((tiles + 7) / 8) * G)), dim3(RT_THREADS), 0, g->stream, W, g->ld,
+                           N0, rows, g->ld, P, out, g->ld, upper);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

@@ -626,31 +626,34 @@ __global__ __launch_bounds__(256) void k_cov_rows(const double* __restrict__ X, 
 //     out[r][j] = sum_{k>=j} W'[j][k] * rows[r][k]  ( = (rows W)[r][j] for the lower-triangular W ).
 constexpr int RT_ROWS = 8;
 constexpr int RT_THREADS = 256;   // 512 measured slower (31 -> 39 us at N=3000, R=10)
+template <int PV>   // right-hand sides per workgroup: 8, or 1 (single right-hand side: alpha, mean_var(model, x::Vector),
+                    // one-point appends): 8 running sums instead of 64 leave room to keep four k-steps of loads in flight.
+                    // Both forms add a (row, right-hand side) pair in exactly the same order -> bit-identical results.
 __global__ __launch_bounds__(RT_THREADS) void k_rows_trimv(const double* __restrict__ W, int64_t ld, int64_t N0,
                                                     const double* __restrict__ rows, int64_t ldr, int P_total,
                                                     double* __restrict__ out, int64_t ldo, int upper) {
-    __shared__ double red[RT_THREADS / 64][64];
+    __shared__ double red[RT_THREADS / 64][RT_ROWS * PV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // block b runs on XCD b % 8; the G = ceil(P_total / 8) workgroups that share a row tile of W are consecutive on
+    // block b runs on XCD b % 8; the G = ceil(P_total / PV) workgroups that share a row tile of W are consecutive on
     // ONE XCD, so W comes from HBM once and the other G - 1 reads hit that XCD's L2
-    const int G = (P_total + APPEND_CHUNK - 1) / APPEND_CHUNK;
+    const int G = (P_total + PV - 1) / PV;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     // longest rows first: the row of W that needs k in [0, j] (lower) or [j, N0) (upper) costs its length
     const int64_t tiles = (N0 + RT_ROWS - 1) / RT_ROWS;
     const int64_t tsel = (int64_t)(idx / G) * 8 + xcd;
     const int64_t j0 = (upper ? tsel : tiles - 1 - tsel) * RT_ROWS;
-    const int r0 = (idx % G) * APPEND_CHUNK;
-    const int P = min(APPEND_CHUNK, P_total - r0);
+    const int r0 = (idx % G) * PV;
+    const int P = min(PV, P_total - r0);
     if (j0 < 0 || j0 >= N0 || P <= 0) return;
     rows += (int64_t)r0 * ldr;
     out += (int64_t)r0 * ldo;
-    double a[64];   // a[8 i + r]: row j0 + i, right-hand side r
+    double a[RT_ROWS * PV];   // a[PV i + r]: row j0 + i, right-hand side r
 #pragma unroll
-    for (int t = 0; t < 64; ++t) a[t] = 0.0;
+    for (int t = 0; t < RT_ROWS * PV; ++t) a[t] = 0.0;
     const int64_t k_lo = upper ? j0 : 0, k_hi = upper ? N0 : min(N0, j0 + RT_ROWS);
-#pragma unroll 2
+#pragma unroll(PV == 1 ? 4 : 2)
     for (int64_t k = k_lo + threadIdx.x; k < k_hi; k += RT_THREADS) {
-        double w[RT_ROWS], v[APPEND_CHUNK];
+        double w[RT_ROWS], v[PV];
 #pragma unroll
         for (int i = 0; i < RT_ROWS; ++i) {
             const int64_t j = j0 + i;
@@ -658,27 +661,37 @@ __global__ __launch_bounds__(RT_THREADS) void k_rows_trimv(const double* __restr
             w[i] = valid ? W[j * ld + k] : 0.0;
         }
 #pragma unroll
-        for (int r = 0; r < APPEND_CHUNK; ++r) v[r] = r < P ? rows[r * ldr + k] : 0.0;
+        for (int r = 0; r < PV; ++r) v[r] = r < P ? rows[r * ldr + k] : 0.0;
 #pragma unroll
         for (int i = 0; i < RT_ROWS; ++i)
 #pragma unroll
-            for (int r = 0; r < APPEND_CHUNK; ++r) a[8 * i + r] += w[i] * v[r];
+            for (int r = 0; r < PV; ++r) a[PV * i + r] += w[i] * v[r];
     }
-    // recursive halving: after the step with offset o the lane keeps the half of its sums selected by bit o of its id
+    if constexpr (PV == 8) {
+        // recursive halving: after the step with offset o the lane keeps the half of its sums selected by bit o of its id
 #pragma unroll
-    for (int o = 32, n = 64; o >= 1; o >>= 1, n >>= 1) {
-        const bool up = (lane & o) != 0;
+        for (int o = 32, n = 64; o >= 1; o >>= 1, n >>= 1) {
+            const bool up = (lane & o) != 0;
 #pragma unroll
-        for (int t = 0; t < n / 2; ++t) {
-            const double send = up ? a[t] : a[t + n / 2];
-            const double keep = up ? a[t + n / 2] : a[t];
-            a[t] = keep + __shfl_xor(send, o);
+            for (int t = 0; t < n / 2; ++t) {
+                const double send = up ? a[t] : a[t + n / 2];
+                const double keep = up ? a[t + n / 2] : a[t];
+                a[t] = keep + __shfl_xor(send, o);
+            }
+        }
+        red[wave][lane] = a[0];
+    } else {
+        // the same pairing tree as the halving above, as a plain butterfly on the 8 sums
+#pragma unroll
+        for (int t = 0; t < RT_ROWS; ++t) {
+            double x = a[t];
+            for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+            if (lane == 0) red[wave][t] = x;
         }
     }
-    red[wave][lane] = a[0];
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x >> 3, r = threadIdx.x & 7;
+    if (threadIdx.x < RT_ROWS * PV) {
+        const int i = threadIdx.x / PV, r = threadIdx.x % PV;
         const int t = threadIdx.x;
         const double sum = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
         if (r < P && j0 + i < N0) out[(int64_t)r * ldo + j0 + i] = sum;
