@@ -9,7 +9,8 @@
 //   dW  [ld][ld]    W = L^-1 (lower).  Row N (first padding row) carries alpha' so the scoring
 //                   contraction V = W K* also produces mu - beta.
 //   dWT [ld][ld]    W' (upper): lets every contraction run in the K-major x K-major form of the MFMA engine
-//   dS  [ld][ld]    scratch: solved panels during the factorisation, S' blocks during the recursive inverse
+//   dS  [ld][ld]    scratch: solved panels during the factorisation, S' blocks during the recursive inverse,
+//                   cK^-1 for the marginal-likelihood gradient
 //   dKsT [Rc][ld]   cross-covariance chunk, candidate-major
 // There is NO CPU fallback: every entry point that computes fails with BOHIP_E_NODEVICE / BOHIP_E_HIP
 // when the GPU is unavailable.
@@ -50,11 +51,6 @@ static_assert(sizeof(bohip_best) == sizeof(Best), "record layout");
 static constexpr int APP_UT_ROW0 = APPEND_PMAX;            // rows [0, 32): V' / L21;  rows [32, 64): U' / T = L21 W11
 static constexpr int APP_ROWS = APP_UT_ROW0 + APPEND_PMAX;
 static_assert(SMALL_R <= APPEND_PMAX, "small-batch V' rows share the append's row area");
-
-struct StageTimer {
-    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
-    std::vector<std::pair<std::string, double>> result;
-};
 
 struct bohip_gp {
     int device = 0, d = 0, kern = 0;

@@ -767,10 +767,10 @@ __global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, doubl
     }
 }
 
-// ---- small-batch posterior (R <= SMALL_R): the default use of the reference (10 L-BFGS restarts) scores a handful
-// of candidates per call.  A 128 x 64 MFMA tile would be almost empty and the call latency-bound by the longest K
-// loop; instead V' = K*' W' is computed row-wise like the incremental append (one pass over W per 8 candidates,
-// HBM-bound), k_small_finish (kernels_score.hip) turns V' into (sum v^2, mu - beta) and scores, and U' = V' W is the
+// ---- small-batch posterior (chunks of SMALL_R, up to ~100 candidates): the default use of the reference (10 L-BFGS
+// restarts) scores a handful of candidates per call.  A 128 x 64 MFMA tile would be almost empty and its single job per
+// row tile latency-bound by the longest K loop; instead V' = K*' W' is computed row-wise like the incremental append
+// (k_rows_trimv), k_small_finish (kernels_score.hip) turns V' into (sum v^2, mu - beta) and scores, and U' = V' W is the
 // same row-wise kernel on W'.
 constexpr int SMALL_R = 32;
 
