@@ -48,16 +48,17 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 static_assert(sizeof(bohip_best) == sizeof(Best), "record layout");
-static constexpr int APP_UT_ROW0 = APPEND_PMAX;            // rows [0, 32): V' / L21;  rows [32, 64): U' / T = L21 W11
-static constexpr int APP_ROWS = APP_UT_ROW0 + APPEND_PMAX;
-static_assert(SMALL_R <= APPEND_PMAX, "small-batch V' rows share the append's row area");
+static constexpr int SMALL_MAX = 256;                      // most candidates the row-wise path takes in one go
+static constexpr int APP_UT_ROW0 = SMALL_MAX;              // rows [0, 256): V' / L21;  rows [256, 512): U' / T = L21 W11
+static constexpr int APP_ROWS = 2 * SMALL_MAX;
+static_assert(APPEND_PMAX <= SMALL_MAX && SMALL_R <= SMALL_MAX, "the append shares the small-batch row area");
 
 struct bohip_gp {
     int device = 0, d = 0, kern = 0;
     int64_t n = 0, cap = 0, ld = 0;
     double *dX = nullptr, *dy = nullptr, *dL = nullptr, *dW = nullptr, *dWT = nullptr, *dS = nullptr;
     double *dalpha = nullptr, *dr = nullptr, *dt = nullptr, *dmll = nullptr;
-    double* dApp = nullptr;  // [APP_ROWS][ld] scratch of the incremental append
+    double* dApp = nullptr;  // [APP_ROWS][ld] scratch of the incremental append and of the row-wise (small-batch) posterior
     int* dinfo = nullptr;
     std::vector<double> hX, hy;
     double loglen[DMAX], logsig = 0.0, lognoise = -2.0, beta = 0.0;
@@ -78,7 +79,7 @@ struct bohip_gp {
     Best *dblock_best = nullptr, *dbest = nullptr;
     int64_t bb_cap = 0;
     double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
-    double* dgparts = nullptr;   // [SMALL_R][16][2 DMAX] split partial sums of k_grad_finish (small batches)
+    double* dgparts = nullptr;   // [SMALL_MAX][16][2 DMAX] split partial sums of k_grad_finish (small batches)
     unsigned* dgcount = nullptr; // per-candidate arrival counters (left at zero by the kernel)
     // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
     // 2-3 device-to-host copies of a call cost more than its kernels (each ~8 us of API + DMA set-up)
@@ -205,7 +206,8 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 static int g_inv_overlap = 0;  // BOHIP_INV_OVERLAP=1: grow W = L^-1 block by block beside the factorisation instead of after it.
                                // Measured: refit 3.67 -> 3.56 ms (N=3000), 21.4 -> 19.9 ms (N=10000), but the factorisation itself slows
                                // down under the competition (2.90 -> 3.08 ms, 13.9 -> 17.7 ms), so it stays opt-in.
-static int g_small_r = 96;  // batches up to this size take the row-wise path in chunks of SMALL_R (BOHIP_SMALL_R): below ~100
+static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
+                            // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
@@ -228,7 +230,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
-    if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(1024, std::max(0, atoi(e)));
+    if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_MAX, std::max(0, atoi(e)));
     done = true;
     return 0;
 }
@@ -581,12 +583,16 @@ static int launch_kstar_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t 
 // Small-batch posterior (R <= SMALL_R): V' rows into dApp[0..R), q and mu_raw; optionally U' = V' W into dApp[APP_UT_ROW0..).
 static int ensure_small_counters(bohip_gp* g) {
     if (g->dgparts) return 0;
-    HIPCHK(hipMalloc(&g->dgparts, (size_t)SMALL_R * 16 * 2 * DMAX * 8));
-    HIPCHK(hipMalloc(&g->dgcount, (SMALL_R + 1) * sizeof(unsigned)));   // [0, SMALL_R): k_grad_finish, [SMALL_R]: k_small_finish
-    HIPCHK(hipMemsetAsync(g->dgcount, 0, (SMALL_R + 1) * sizeof(unsigned), g->stream));
+    HIPCHK(hipMalloc(&g->dgparts, (size_t)SMALL_MAX * 16 * 2 * DMAX * 8));
+    HIPCHK(hipMalloc(&g->dgcount, (SMALL_MAX + 1) * sizeof(unsigned)));   // [0, SMALL_MAX): k_grad_finish, [SMALL_MAX]: k_small_finish
+    HIPCHK(hipMemsetAsync(g->dgcount, 0, (SMALL_MAX + 1) * sizeof(unsigned), g->stream));
     return 0;
 }
-// one chunk [r0, r1) of at most SMALL_R candidates; the output pointers are indexed by the GLOBAL candidate number
+static int64_t small_limit(const bohip_gp* g) {
+    if (g_small_r >= 0) return g_small_r;
+    return std::min<int64_t>(SMALL_MAX, 90 + 300000 / std::max<int64_t>(g->n, 1));
+}
+// candidates [r0, r1), at most SMALL_MAX of them; the output pointers are indexed by the GLOBAL candidate number
 static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, bool want_u, const AcqParams& ap,
                            double* d_mu, double* d_var, double* d_score, Best* d_best) {
     CHK(ensure_small_counters(g));
@@ -600,7 +606,7 @@ static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r
     // rows 0..N of W (row N carries alpha'): V'[r][j] = sum_{k<=j} W[j][k] K*'[r][k]
     CHK(launch_rows_trimv(g, g->dW, N + 1, g->dKsT, P, g->dApp, 0));
     hipLaunchKernelGGL(k_small_finish, dim3((unsigned)P), dim3(256), 0, g->stream, g->dApp, ld, N, P, g->dq + r0, g->dmu_raw + r0,
-                       g->dgcount + SMALL_R, std::exp(2.0 * g->logsig), g->beta, ap, d_mu ? d_mu + r0 : nullptr,
+                       g->dgcount + SMALL_MAX, std::exp(2.0 * g->logsig), g->beta, ap, d_mu ? d_mu + r0 : nullptr,
                        d_var ? d_var + r0 : nullptr, d_score ? d_score + r0 : nullptr, d_best);
     HIPCHK(hipGetLastError());
     t_end(g);
@@ -645,17 +651,9 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
         return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
     }
-    if (R <= g_small_r) {   // row-wise posterior in chunks of SMALL_R, scoring fused into its finish kernel
+    if (R <= small_limit(g)) {   // row-wise posterior, scoring and arg-max fused into its finish kernel
         CHK(one_time_kernel_setup());
-        if (R <= SMALL_R) return small_posterior(g, dXs, 0, R, false, ap, d_mu, d_var, d_score, d_best);
-        double* sc = d_score ? d_score : g->dscore;
-        for (int64_t r0 = 0; r0 < R; r0 += SMALL_R)
-            CHK(small_posterior(g, dXs, r0, std::min(R, r0 + SMALL_R), false, ap, d_mu, d_var, sc, nullptr));
-        if (d_best) {
-            hipLaunchKernelGGL(k_argmax_scores, dim3(1), dim3(256), 0, g->stream, sc, (int)R, d_best);
-            HIPCHK(hipGetLastError());
-        }
-        return 0;
+        return small_posterior(g, dXs, 0, R, false, ap, d_mu, d_var, d_score, d_best);
     }
     CHK(posterior_pass(g, dXs, R));
     const int64_t Npad = round_up(g->n + 1, TILE), Rpad = round_up(R, TILE) + TILE;
@@ -680,7 +678,7 @@ static int launch_grad_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t r
                            double* d_grad, const double* UT) {
     // small batches: split the observations over S workgroups per candidate (see k_grad_finish)
     int S = 1;
-    if (r1 - r0 <= SMALL_R) S = (int)std::min<int64_t>(16, std::max<int64_t>(1, g->n / 768));
+    if (r1 - r0 <= SMALL_MAX) S = (int)std::min<int64_t>(16, std::max<int64_t>(1, g->n / 768));
     if (S > 1) CHK(ensure_small_counters(g));
     if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
     else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
@@ -710,14 +708,11 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: head-room for tile-granular writes
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
-    if (R <= g_small_r) {  // the reference's default: a handful of L-BFGS restarts per call
-        for (int64_t r0 = 0; r0 < R; r0 += SMALL_R) {
-            const int64_t r1 = std::min(R, r0 + SMALL_R);
-            CHK(small_posterior(g, dXs, r0, r1, true, ap, g->dmu, g->dvar, d_score, nullptr));
-            t_begin(g, "grad");
-            CHK(launch_grad_any(g, dXs, r0, r1, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld));
-            t_end(g);
-        }
+    if (R <= small_limit(g)) {  // the reference's default: a handful of L-BFGS restarts per call
+        CHK(small_posterior(g, dXs, 0, R, true, ap, g->dmu, g->dvar, d_score, nullptr));
+        t_begin(g, "grad");
+        CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld));
+        t_end(g);
         return 0;
     }
     CHK(ensure_grad_scratch(g));

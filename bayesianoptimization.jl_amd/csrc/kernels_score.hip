@@ -262,20 +262,7 @@ __global__ __launch_bounds__(256) void k_score(const double* __restrict__ q_part
     }
 }
 
-// arg-max over a score array (value desc, index asc; NaN and -Inf never win): the row-wise path for 32 < R <= ~100
-__global__ __launch_bounds__(256) void k_argmax_scores(const double* __restrict__ score, int R, Best* __restrict__ out) {
-    __shared__ Best sh[4];
-    double v = -INFINITY;
-    long long idx = -1;
-    for (int i = threadIdx.x; i < R; i += 256) {
-        const double f = score[i];
-        if (f > -INFINITY && better(f, i, v, idx)) { v = f; idx = i; }
-    }
-    block_argmax(v, idx, sh);
-    if (threadIdx.x == 0) { out->val = idx >= 0 ? v : -INFINITY; out->idx = idx; }
-}
-
-// Small batches (R <= 32, row-wise posterior): one workgroup per candidate r adds q[r] = sum_j V'[r][j]^2 in a fixed
+// Small batches (R <= 256, row-wise posterior): one workgroup per candidate r adds q[r] = sum_j V'[r][j]^2 in a fixed
 // order and takes mu_raw[r] from the alpha row; the LAST workgroup to finish then does what k_score + k_argmax_final do
 // for a large batch (same formulas, same operation order) for all R candidates -- two launches less per call, which
 // at this size are a fifth of its latency.  The arrival counter is left at zero.
