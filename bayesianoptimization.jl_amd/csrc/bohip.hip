@@ -671,6 +671,13 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
 template <int DT>
 static void launch_grad(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, const KernelHyper& hp, const AcqParams& ap,
                         double* d_grad, const double* UT, int S) {
+    if constexpr (DT <= 16) {   // large batches: 4 candidates per workgroup share the observation stream
+        if (r1 - r0 > SMALL_MAX) {
+            hipLaunchKernelGGL(k_grad_finish_tiled<DT>, dim3((unsigned)((r1 - r0 + GC - 1) / GC)), dim3(256), 0, g->stream, g->dX, g->n,
+                               dXs, r0, r1, hp, g->dalpha, UT, g->ld, g->dmu, g->dvar, ap, d_grad);
+            return;
+        }
+    }
     hipLaunchKernelGGL(k_grad_finish<DT>, dim3((unsigned)(r1 - r0), (unsigned)S), dim3(256), 0, g->stream, g->dX, g->n, dXs, r0, r1,
                        hp, g->dalpha, UT, g->ld, g->dmu, g->dvar, ap, d_grad, g->dgparts, g->dgcount);
 }
