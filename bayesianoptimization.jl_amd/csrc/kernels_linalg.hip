@@ -191,9 +191,11 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // (An MFMA formulation was measured slower here: 96k vs 32k cycles per block -- the panels are only 16 deep, so
 // each 8x8 block is 4 dependent MFMAs behind ~10 LDS reads, while the register-tiled VALU form reuses every
 // operand NB times.)
-template <int NB>
-__device__ __forceinline__ void trailing_update(double* a, int P, int tid) {
-    const int base = P + 16, ty = tid >> 4, tx = tid & 15;
+// (ty, tx): the element of every 16 x 16 sub-block this thread owns.  SKIP00: leave out sub-block (0, 0), the next
+// diagonal block, which the look-ahead updates and factors separately.
+template <int NB, bool SKIP00, int AMOD = -1>   // AMOD >= 0: only the sub-block rows ai with ai % 3 == AMOD
+__device__ __forceinline__ void trailing_update(double* a, int P, int ty, int tx) {
+    const int base = P + 16;
     double acc[NB][NB];
 #pragma unroll
     for (int ai = 0; ai < NB; ++ai)
@@ -209,17 +211,63 @@ __device__ __forceinline__ void trailing_update(double* a, int P, int tid) {
             lk[q] = col[tx + 16 * q];
         }
 #pragma unroll
-        for (int ai = 0; ai < NB; ++ai)
+        for (int ai = 0; ai < NB; ++ai) {
+            if (AMOD >= 0 && ai % 3 != AMOD) continue;
 #pragma unroll
             for (int ki = 0; ki <= ai; ++ki) acc[ai][ki] += li[ai] * lk[ki];
+        }
     }
 #pragma unroll
     for (int ai = 0; ai < NB; ++ai)
 #pragma unroll
         for (int ki = 0; ki <= ai; ++ki) {
+            if (AMOD >= 0 && ai % 3 != AMOD) continue;
+            if (SKIP00 && ai == 0 && ki == 0) continue;
             const int i = base + ty + 16 * ai, k = base + tx + 16 * ki;
             if (k <= i) a[i * PF_LD + k] -= acc[ai][ki];
         }
+}
+template <bool SKIP00, int AMOD>
+__device__ __forceinline__ void trailing_dispatch(double* a, int P, int nb, int ty, int tx) {
+    switch (nb) {  // tile size known at compile time per panel
+        case 7: trailing_update<7, SKIP00, AMOD>(a, P, ty, tx); break;
+        case 6: trailing_update<6, SKIP00, AMOD>(a, P, ty, tx); break;
+        case 5: trailing_update<5, SKIP00, AMOD>(a, P, ty, tx); break;
+        case 4: trailing_update<4, SKIP00, AMOD>(a, P, ty, tx); break;
+        case 3: trailing_update<3, SKIP00, AMOD>(a, P, ty, tx); break;
+        case 2: trailing_update<2, SKIP00, AMOD>(a, P, ty, tx); break;
+        case 1: trailing_update<1, SKIP00, AMOD>(a, P, ty, tx); break;
+        default: break;
+    }
+}
+// A1: the 16 x 16 diagonal block at (P, P) in registers, lane r (< 16) of ONE wave holds row r.  Finished columns go to
+// the mirror position, the diagonal to dl / idl.
+__device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int P, int lane, int* info, int row0) {
+    const int r = lane & 15;
+    double row[16], dkeep[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) row[k] = a[(P + r) * PF_LD + P + k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double ajj = readlane_f64(row[j], j);
+        if (!(ajj > 0.0)) {
+            if (lane == 0) atomicCAS(info, 0, row0 + P + j + 1);
+            ajj = 1.0;
+        }
+        const double inv = fast_rsqrt(ajj);
+        const double lj = row[j] * inv;  // lane j: the pivot L_jj = ajj * inv
+        dkeep[j] = ajj * inv;
+        row[j] = (r == j) ? inv : lj;    // keep 1/L_jj on the diagonal
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) row[k] -= lj * readlane_f64(lj, k);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (r > j) a[(P + j) * PF_LD + P + r] = row[j];  // mirror
+            if (r == j) { idl[P + j] = row[j]; dl[P + j] = dkeep[j]; }
+        }
+    }
 }
 
 #ifdef BOHIP_POTF2_CLOCKS
@@ -253,37 +301,16 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
     }
     __syncthreads();
     PF_CLK(0);
+    // Look-ahead over the 8 panels of 16 columns: the pivot block of panel j+1 (wave 0, a serial chain of 16 pivots) runs
+    // beside the trailing update of panel j (waves 1-3) instead of before it:
+    //   A1(0);  for each panel:  A2 row solves | A3a: the next diagonal block only (one element per thread) |
+    //                            wave 0: A1(next)  ||  waves 1-3: the rest of the trailing update (plus, split three ways,
+    //                            the rows wave 0 would have owned)
+    if (wave == 0) factor16(a, dl, idl, 0, lane, info, row0);
+    __syncthreads();
+    PF_CLK(1);
     for (int jb = 0; jb < 8; ++jb) {
         const int P = 16 * jb;
-        if (wave == 0) {  // A1: 16 x 16 diagonal block in registers, lane r (< 16) holds row r
-            const int r = lane & 15;
-            double row[16], dkeep[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) row[k] = a[(P + r) * PF_LD + P + k];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                double ajj = readlane_f64(row[j], j);
-                if (!(ajj > 0.0)) {
-                    if (lane == 0) atomicCAS(info, 0, row0 + P + j + 1);
-                    ajj = 1.0;
-                }
-                const double inv = fast_rsqrt(ajj);
-                const double lj = row[j] * inv;  // lane j: the pivot L_jj = ajj * inv
-                dkeep[j] = ajj * inv;
-                row[j] = (r == j) ? inv : lj;    // keep 1/L_jj on the diagonal
-#pragma unroll
-                for (int k = j + 1; k < 16; ++k) row[k] -= lj * readlane_f64(lj, k);
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    if (r > j) a[(P + j) * PF_LD + P + r] = row[j];  // mirror
-                    if (r == j) { idl[P + j] = row[j]; dl[P + j] = dkeep[j]; }
-                }
-            }
-        }
-        __syncthreads();
-        PF_CLK(1);
         const int base = P + 16, m = TILE - base;
         if (tid < m) {  // A2: rows below the diagonal block
             const int i = base + tid;
@@ -300,15 +327,29 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
         }
         __syncthreads();
         PF_CLK(2);
-        switch (m >> 4) {  // A3: rank-16 trailing update, tile size known at compile time per panel
-            case 7: trailing_update<7>(a, P, tid); break;
-            case 6: trailing_update<6>(a, P, tid); break;
-            case 5: trailing_update<5>(a, P, tid); break;
-            case 4: trailing_update<4>(a, P, tid); break;
-            case 3: trailing_update<3>(a, P, tid); break;
-            case 2: trailing_update<2>(a, P, tid); break;
-            case 1: trailing_update<1>(a, P, tid); break;
-            default: break;
+        if (m == 0) break;
+        {   // A3a: rank-16 update of the next diagonal block, element (ty, tx) per thread (done by wave 0 alone, 4 elements
+            // per lane, it costs more than this extra barrier: 175k vs 163k cycles per block)
+            const int ty = tid >> 4, tx = tid & 15;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double* col = a + (P + c) * PF_LD + base;
+                acc += col[ty] * col[tx];
+            }
+            if (tx <= ty) a[(base + ty) * PF_LD + base + tx] -= acc;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            factor16(a, dl, idl, base, lane, info, row0);
+        } else {
+            const int u = tid - 64;   // 0..191: rows 4..15 of every sub-block
+            trailing_dispatch<true, -1>(a, P, m >> 4, 4 + (u >> 4), u & 15);
+            // rows 0..3 (wave 0 is busy): each of the three waves takes every third row of sub-blocks
+            const int ty0 = (u >> 4) & 3, tx0 = u & 15;
+            if (wave == 1) trailing_dispatch<true, 0>(a, P, m >> 4, ty0, tx0);
+            else if (wave == 2) trailing_dispatch<true, 1>(a, P, m >> 4, ty0, tx0);
+            else trailing_dispatch<true, 2>(a, P, m >> 4, ty0, tx0);
         }
         __syncthreads();
         PF_CLK(3);
