@@ -47,6 +47,7 @@ SIGNATURES = {
     "bohip_gp_get_xy": (C.c_int, [_gp, _dp, _dp]),
     "bohip_gp_mll": (C.c_int, [_gp, _dp]),
     "bohip_gp_mll_grad": (C.c_int, [_gp, _dp, _dp, _dp, _dp]),
+    "bohip_gp_set_batch_hint": (C.c_int, [_gp, C.c_int64]),
     "bohip_gp_predict_cov": (C.c_int, [_gp, _dp, C.c_int64, _dp, _dp]),
     "bohip_gp_acquire_max": (C.c_int, [_gp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                       _dp, _dp, C.POINTER(Best), _dp, _i64p]),

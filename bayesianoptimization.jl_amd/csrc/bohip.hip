@@ -79,6 +79,9 @@ struct bohip_gp {
     Best *dblock_best = nullptr, *dbest = nullptr;
     int64_t bb_cap = 0;
     double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
+    int64_t batch_hint = 0;      // bohip_gp_set_batch_hint: choose the scoring path as if the batch had at least this many candidates
+    double* dsplit = nullptr;    // split-K partial planes (batches of a few hundred candidates)
+    int64_t split_cap = 0;
     double* dgparts = nullptr;   // [SMALL_MAX][16][2 DMAX] split partial sums of k_grad_finish (small batches)
     unsigned* dgcount = nullptr; // per-candidate arrival counters (left at zero by the kernel)
     // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
@@ -206,6 +209,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 static int g_inv_overlap = 0;  // BOHIP_INV_OVERLAP=1: grow W = L^-1 block by block beside the factorisation instead of after it.
                                // Measured: refit 3.67 -> 3.56 ms (N=3000), 21.4 -> 19.9 ms (N=10000), but the factorisation itself slows
                                // down under the competition (2.90 -> 3.08 ms, 13.9 -> 17.7 ms), so it stays opt-in.
+static int g_split = 1;   // split-K path for batches of a few hundred candidates (BOHIP_SPLIT=0 disables)
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
@@ -229,6 +233,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
+    if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
     if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
     if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_MAX, std::max(0, atoi(e)));
     done = true;
@@ -588,10 +593,16 @@ static int ensure_small_counters(bohip_gp* g) {
     HIPCHK(hipMemsetAsync(g->dgcount, 0, (SMALL_MAX + 1) * sizeof(unsigned), g->stream));
     return 0;
 }
+static bool split_applicable(const bohip_gp* g);
 static int64_t small_limit(const bohip_gp* g) {
     if (g_small_r >= 0) return g_small_r;
+    // measured break-even with the MFMA path: whole-K jobs (N=500: > 256, N=3000: ~190, N=10000: ~110); where the split-K
+    // form applies it wins earlier (N=1500: ~150, N=3000: ~95, N=10000: ~55)
+    if (split_applicable(g)) return std::min<int64_t>(SMALL_MAX, 45 + 150000 / std::max<int64_t>(g->n, 1));
     return std::min<int64_t>(SMALL_MAX, 90 + 300000 / std::max<int64_t>(g->n, 1));
 }
+// the batch size the path decision is based on (see bohip_gp_set_batch_hint)
+static int64_t path_R(const bohip_gp* g, int64_t R) { return std::max(R, g->batch_hint); }
 // candidates [r0, r1), at most SMALL_MAX of them; the output pointers are indexed by the GLOBAL candidate number
 static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, bool want_u, const AcqParams& ap,
                            double* d_mu, double* d_var, double* d_score, Best* d_best) {
@@ -639,6 +650,74 @@ static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
     return 0;
 }
 
+// ---- split-K posterior for batches too small to fill the chip with whole-K jobs (see k_split_combine_v) -----------
+struct SplitPlan { int kz = 0, nsl = 0; };
+static bool split_applicable(const bohip_gp* g) {
+    return g_split && round_up(g->n + 1, TILE) / TILE >= 8;   // short K extents gain nothing
+}
+static SplitPlan split_plan(const bohip_gp* g, int64_t R) {
+    SplitPlan sp;
+    if (!split_applicable(g)) return sp;
+    const int64_t Npad = round_up(g->n + 1, TILE);
+    const int T = (int)(Npad / TILE);
+    const int64_t CT64 = (path_R(g, R) + CTILE - 1) / CTILE;
+    if (CT64 * T >= 512) return sp;                     // enough whole-K jobs for every workgroup slot
+    const int units = std::max(2, (T + 7) / 8);         // 128-wide K units per slice
+    int kz = units * (TILE / KC);
+    int nsl = (T * (TILE / KC) + kz - 1) / kz;
+    const int64_t Rc = round_up(R, TILE);
+    while (nsl > 1 && (double)nsl * Rc * g->ld * 8.0 > 256.0 * 1024 * 1024) {   // keep the partial planes below 256 MB
+        kz *= 2;
+        nsl = (T * (TILE / KC) + kz - 1) / kz;
+    }
+    if (nsl < 2) return sp;
+    sp.kz = kz; sp.nsl = nsl;
+    return sp;
+}
+static int split_posterior(bohip_gp* g, const double* dXs, int64_t R, const SplitPlan& sp, bool want_u) {
+    CHK(one_time_kernel_setup());
+    const int64_t N = g->n, Npad = round_up(N + 1, TILE), ld = g->ld, Rc = round_up(R, TILE);
+    const int T = (int)(Npad / TILE);
+    const KernelHyper hp = make_hyper(g);
+    const int64_t need = (int64_t)sp.nsl * Rc * ld;
+    if (g->split_cap < need) {
+        if (g->dsplit) HIPCHK(hipFree(g->dsplit));
+        g->dsplit = nullptr; g->split_cap = 0;
+        HIPCHK(hipMalloc(&g->dsplit, (size_t)need * 8));
+        g->split_cap = need;
+    }
+    if (want_u) CHK(ensure_grad_scratch(g));
+    t_begin(g, "kstar");
+    CHK(launch_kstar_any(g, dXs, 0, R, Npad, hp));
+    t_end(g);
+    t_begin(g, "split_V");
+    GemmNTParams p{};   // partial V'[r][i] = sum over the slice's k of K*'[r][k] W[i][k]  (A = W row tiles, B = K*')
+    p.A = g->dW; p.lda = ld; p.B = g->dKsT; p.ldb = ld; p.C = nullptr; p.CT = g->dsplit; p.ldct = ld;
+    p.zA = (int64_t)sp.kz * KC; p.zB = (int64_t)sp.kz * KC; p.zCT = Rc * ld;
+    p.mt = T; p.nt64 = (int)((R + CTILE - 1) / CTILE); p.kc = sp.kz; p.alpha = 1.0; p.beta = 0.0;
+    p.khi_from_m = 1; p.kz = sp.kz; p.ktot = T * (TILE / KC);
+    CHK(launch_gemm_nt(g, p, sp.nsl));
+    hipLaunchKernelGGL(k_split_combine_v, dim3((unsigned)R), dim3(256), 0, g->stream, g->dsplit, Rc * ld, ld, sp.kz, N, g->dq,
+                       g->dmu_raw, want_u ? g->dVT : nullptr, ld);
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    g->q_tiles = 1;
+    if (want_u) {
+        t_begin(g, "split_U");
+        GemmNTParams u{};   // partial U'[r][j] = sum over the slice's i of V'[r][i] W'[j][i]   (B = W' upper-triangular: i >= j)
+        u.A = g->dVT; u.lda = ld; u.B = g->dWT; u.ldb = ld; u.C = g->dsplit; u.ldc = ld;
+        u.zA = (int64_t)sp.kz * KC; u.zB = (int64_t)sp.kz * KC; u.zC = Rc * ld;
+        u.mt = (int)(Rc / TILE); u.nt64 = 2 * T; u.kc = sp.kz; u.alpha = 1.0; u.beta = 0.0;
+        u.klo_from_n = 1; u.kz = sp.kz; u.ktot = T * (TILE / KC);
+        CHK(launch_gemm_nt(g, u, sp.nsl));
+        hipLaunchKernelGGL(k_split_combine_u, dim3((unsigned)R), dim3(256), 0, g->stream, g->dsplit, Rc * ld, ld, sp.kz, sp.nsl, N,
+                           g->dUT, ld);
+        HIPCHK(hipGetLastError());
+        t_end(g);
+    }
+    return 0;
+}
+
 static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const double* dXs, int64_t R, double* d_mu,
                       double* d_var, double* d_score, Best* d_best) {
     if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
@@ -651,11 +730,13 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     } else if (acq_id != BOHIP_ACQ_MAXMEAN) {
         return fail(BOHIP_E_ARG, "acq_params required for this acquisition");
     }
-    if (R <= small_limit(g)) {   // row-wise posterior, scoring and arg-max fused into its finish kernel
+    if (path_R(g, R) <= small_limit(g) && R <= SMALL_MAX) {   // row-wise posterior, scoring and arg-max fused into its finish kernel
         CHK(one_time_kernel_setup());
         return small_posterior(g, dXs, 0, R, false, ap, d_mu, d_var, d_score, d_best);
     }
-    CHK(posterior_pass(g, dXs, R));
+    const SplitPlan sp = split_plan(g, R);
+    if (sp.nsl > 0) CHK(split_posterior(g, dXs, R, sp, false));
+    else CHK(posterior_pass(g, dXs, R));
     const int64_t Npad = round_up(g->n + 1, TILE), Rpad = round_up(R, TILE) + TILE;
     const int T = (int)(Npad / TILE);
     const int nb = (int)((R + 255) / 256);
@@ -715,10 +796,20 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: head-room for tile-granular writes
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
-    if (R <= small_limit(g)) {  // the reference's default: a handful of L-BFGS restarts per call
+    if (path_R(g, R) <= small_limit(g) && R <= SMALL_MAX) {  // the reference's default: a handful of L-BFGS restarts per call
         CHK(small_posterior(g, dXs, 0, R, true, ap, g->dmu, g->dvar, d_score, nullptr));
         t_begin(g, "grad");
         CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld));
+        t_end(g);
+        return 0;
+    }
+    const SplitPlan sp = split_plan(g, R);
+    if (sp.nsl > 0) {
+        CHK(split_posterior(g, dXs, R, sp, true));
+        t_begin(g, "score+grad");
+        hipLaunchKernelGGL(k_score, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, g->stream, g->dq, Rpad, 1, g->dmu_raw, R,
+                           std::exp(2.0 * g->logsig), g->beta, ap, g->dmu, g->dvar, d_score, (Best*)nullptr);
+        CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dUT));
         t_end(g);
         return 0;
     }
@@ -813,6 +904,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dbest) hipFree(g->dbest);
     if (g->dgrad) hipFree(g->dgrad);
     if (g->dgparts) hipFree(g->dgparts);
+    if (g->dsplit) hipFree(g->dsplit);
     if (g->dgcount) hipFree(g->dgcount);
     if (g->hpin) hipHostFree(g->hpin);
     if (g->asc_block) hipFree(g->asc_block);
@@ -1320,6 +1412,11 @@ int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
         case BOHIP_INFO_APPENDS: *value = g->appends; return 0;
         default: return fail(BOHIP_E_ARG, "unknown info id");
     }
+}
+int bohip_gp_set_batch_hint(bohip_gp* g, int64_t total_candidates) {
+    if (!g || total_candidates < 0) return fail(BOHIP_E_ARG, "bad arguments");
+    g->batch_hint = total_candidates;
+    return 0;
 }
 int bohip_gp_enable_timing(bohip_gp* g, int on) {
     if (!g) return fail(BOHIP_E_ARG, "null handle");

@@ -428,6 +428,9 @@ struct GemmNTParams {
     int khi_from_m;   // A lower-triangular: contraction ends at k = 128 (ti + 1)
     int klo_from_n;   // B upper-triangular in (n, k): contraction starts at k = 128 (tj64 / 2)
     int diag_skip;    // skip tiles strictly above the global block diagonal (row0/col0 = element offsets of C)
+    int ktot;         // with kz: total number of contraction chunks of the problem (the last slice is cut there)
+    int kz;           // split-K batches: batch z covers contraction chunks [z kz, z kz + kc) of the whole problem; the
+                      // triangular limits above are taken in those absolute chunk numbers (zA/zB carry the operand offsets)
     int64_t row0, col0;
     // ragged batches: tile (ti, tj64) of batch z exists iff  row_t0 + z row_ts + ti < total_t  and
     // col_t0 + z col_ts + tj64/2 < total_t  (all in 128-tiles); total_t <= 0 disables the check
@@ -443,9 +446,14 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
     if (p.diag_skip && p.col0 + CTILE * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) return;
     if (p.total_t > 0 && (p.row_t0 + z * p.row_ts + ti >= p.total_t || p.col_t0 + z * p.col_ts + (tj >> 1) >= p.total_t)) return;
     int kb = 0, ke = p.kc;
-    if (p.klo_from_m) kb = ti * (TILE / KC);
-    if (p.klo_from_n) kb = max(kb, (tj >> 1) * (TILE / KC));
-    if (p.khi_from_m) ke = min(ke, (ti + 1) * (TILE / KC));
+    const int koff = z * p.kz;
+    if (p.klo_from_m) kb = max(kb, ti * (TILE / KC) - koff);
+    if (p.klo_from_n) kb = max(kb, (tj >> 1) * (TILE / KC) - koff);
+    if (p.khi_from_m) ke = min(ke, (ti + 1) * (TILE / KC) - koff);
+    if (p.kz > 0) {
+        if (p.ktot > 0) ke = min(ke, p.ktot - koff);
+        if (kb >= ke) return;   // this slice does not touch the tile: its plane entry is never read
+    }
     double acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
                                p.ldb, kb, ke, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
     if (wave >= 4) return;  // waves 4-7 only contributed partial sums (already folded into waves 0-3)
-    double* C = p.C + z * p.zC + (int64_t)ti * TILE * p.ldc + (int64_t)tj * CTILE;
+    double* C = p.C ? p.C + z * p.zC + (int64_t)ti * TILE * p.ldc + (int64_t)tj * CTILE : nullptr;
     double* CT = p.CT ? p.CT + z * p.zCT + (int64_t)tj * CTILE * p.ldct + (int64_t)ti * TILE : nullptr;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
@@ -465,10 +473,12 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
             const int c = acc_col<4>(lane, wc, nj);
             // symmetric updates never touch the strict upper triangle of the global matrix (it must stay zero)
             if (p.diag_skip && p.col0 + (int64_t)tj * CTILE + c > p.row0 + (int64_t)ti * TILE + r) continue;
-            double* dst = C + (int64_t)r * p.ldc + c;
             double v = p.alpha * acc[mi][nj];
-            if (p.beta != 0.0) v += p.beta * *dst;
-            *dst = v;
+            if (C) {
+                double* dst = C + (int64_t)r * p.ldc + c;
+                if (p.beta != 0.0) v += p.beta * *dst;
+                *dst = v;
+            }
             if (CT) CT[(int64_t)c * p.ldct + r] = v;
         }
     }
@@ -692,7 +702,8 @@ __global__ __launch_bounds__(RT_THREADS) void k_rows_trimv(const double* __restr
 #pragma unroll
     for (int t = 0; t < RT_ROWS * PV; ++t) a[t] = 0.0;
     const int64_t k_lo = upper ? j0 : 0, k_hi = upper ? N0 : min(N0, j0 + RT_ROWS);
-#pragma unroll(PV == 1 ? 4 : 2)
+    constexpr int UNROLL_K = PV == 1 ? 4 : 2;
+#pragma unroll UNROLL_K
     for (int64_t k = k_lo + threadIdx.x; k < k_hi; k += RT_THREADS) {
         double w[RT_ROWS], v[PV];
 #pragma unroll

@@ -179,6 +179,51 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
         q_part[(int64_t)rt * ldq + r_off + (int64_t)ct * CW + threadIdx.x] = red[threadIdx.x] + red[CW + threadIdx.x];
 }
 
+// ---- split-K path for batches with too few candidate tiles to fill the chip (a few hundred candidates) -------------
+// With one 64-wide candidate tile column per 64 candidates the longest job (the last row tile, K = N) runs alone on one
+// CU: ~9 us per 128 of K, 215 us at N = 3000 whatever R.  Here the contraction index is cut into slices of kz chunks,
+// k_gemm_nt computes the partial V' = K*' W' tiles of every slice in one batched launch (planes PT[s][r][i]), and this
+// kernel adds the slices of a candidate in slice order, squares, and reduces: q[r], mu_raw[r], optionally V' itself.
+// One workgroup per candidate; fixed summation order -> independent of the batch.
+__global__ __launch_bounds__(256) void k_split_combine_v(const double* __restrict__ PT, int64_t plane, int64_t ldp, int kz,
+                                                         int64_t N, double* __restrict__ q, double* __restrict__ mu_raw,
+                                                         double* __restrict__ VT, int64_t ldv) {
+    __shared__ double red[256];
+    const int r = blockIdx.x;
+    const double* base = PT + (int64_t)r * ldp;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i <= N; i += 256) {
+        const int nsl = (int)(((i >> 7) + 1) * (TILE / KC) + kz - 1) / kz;   // slices that reach row tile i / 128
+        double v = 0.0;
+        for (int sl = 0; sl < nsl; ++sl) v += base[(int64_t)sl * plane + i];
+        if (i < N) {
+            s += v * v;
+            if (VT) VT[(int64_t)r * ldv + i] = v;
+        } else {
+            mu_raw[r] = v;   // the alpha row
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) q[r] = red[0];
+}
+// U'[r][j] = sum over the slices that reach column tile j / 128 (i >= j) of the partial planes
+__global__ __launch_bounds__(256) void k_split_combine_u(const double* __restrict__ PU, int64_t plane, int64_t ldp, int kz,
+                                                         int nslices, int64_t N, double* __restrict__ UT, int64_t ldu) {
+    const int r = blockIdx.x;
+    const double* base = PU + (int64_t)r * ldp;
+    for (int64_t j = threadIdx.x; j < N; j += 256) {
+        const int s0 = (int)((j >> 7) * (TILE / KC)) / kz;   // first slice whose range ends beyond the start of the column tile
+        double v = 0.0;
+        for (int sl = s0; sl < nslices; ++sl) v += base[(int64_t)sl * plane + j];
+        UT[(int64_t)r * ldu + j] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Acquisition functors -- verbatim operation order of the reference, contraction OFF (Julia never
 // fuses a*b+c).  normal_pdf / normal_cdf: src/utils.jl:48-49.

@@ -6,6 +6,9 @@ collective.  The ONE exchange step is the arg-max: RCCL has no MAXLOC, so every 
 (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests) and every rank applies the same
 (value desc, index asc) reduction -> bit-identical winner everywhere, identical to the 1-GPU result
 (reference tie rule: strict '>' keeps the first maximum, src/acquisition.jl:62).
+
+libbohip picks one of three summation schedules by batch size (row-wise, split-K, whole-K); a rank that scores a shard
+calls ``model.set_batch_hint(R_total)`` first so that every shard is summed exactly like the unsharded batch.
 """
 from __future__ import annotations
 

@@ -256,6 +256,11 @@ class ElasticGPE:
         check(self._lib.bohip_gp_info(self._h, what, C.byref(v)))
         return v.value
 
+    def set_batch_hint(self, total_candidates):
+        """Score shards of a larger candidate set with the summation schedule of the whole set (bit-identical to the
+        unsharded call); 0 clears the hint."""
+        check(self._lib.bohip_gp_set_batch_hint(self._h, int(total_candidates)))
+
     def enable_timing(self, on=True):                    # True/1: every stage; 2: only the dominant kernel
         check(self._lib.bohip_gp_enable_timing(self._h, int(on)))
 

@@ -149,6 +149,7 @@ def main():
     model = bohip.ElasticGPE(DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0,
                              capacity=N_OBS, device=local_rank)
     model.enable_timing(True)
+    model.set_batch_hint(R_total)   # every shard takes the summation schedule of the whole candidate set (bit-identical to G = 1)
     model.append_(X.T, y)  # every rank factors the same model redundantly (192 KB broadcast beats 36 MB of L)
     fit_ms = dict(model.timing())
     model.fit_()

@@ -155,6 +155,11 @@ int bohip_gp_get_alpha(bohip_gp *gp, double *alpha);
 #define BOHIP_INFO_REFITS 2       /* number of full refits so far                                */
 #define BOHIP_INFO_APPENDS 3      /* number of incremental factor extensions so far              */
 int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
+/* Sharded scoring: candidates are scored by one of three summation schedules chosen by batch size
+ * (row-wise, split-K, whole-K MFMA jobs); they agree to ~1e-11 relative but not bit for bit.  A rank that scores a
+ * shard of a larger candidate set announces the size of the WHOLE set here, so that every shard takes the schedule
+ * the unsharded call would take and the G-GPU scores equal the 1-GPU scores bit for bit.  0 (default) = no hint.  */
+int bohip_gp_set_batch_hint(bohip_gp *gp, int64_t total_candidates);
 /* per-stage device times (ms, HIP events on the handle's stream) of the LAST call when timing
  * is enabled: names/values for up to `cap` stages; returns the number of stages.
  * on = 1: every stage; on = 2: only the dominant kernel (k_trigemm_sq) is bracketed by events -- two

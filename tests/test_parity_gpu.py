@@ -415,12 +415,17 @@ def test_full_size_c2_properties(bohip, orc):
     # sharding invariance: 8 shards of 512 (the 8-GPU partition) reduce to the same winner
     from bohip.dist import reduce_best, shard_bounds
     recs = []
+    m.set_batch_hint(R)     # every rank announces the size of the WHOLE set -> the summation schedule of the unsharded call
     for g in range(8):
         lo, hi = shard_bounds(R, 8, g)
         s_g, v_g, i_g = m.score("EI", [tau], Xs[lo:hi].T)
         np.testing.assert_array_equal(s_g, sc[lo:hi])
         recs.append((v_g, i_g + lo))
     assert reduce_best(*zip(*recs)) == (bv, bi)
+    m.set_batch_hint(0)
+    # without the hint a 512-candidate shard takes the split-K schedule: same numbers to rounding, same winner here
+    s_0, v_0, i_0 = m.score("EI", [tau], Xs[:512].T)
+    np.testing.assert_allclose(s_0, sc[:512], rtol=1e-9, atol=1e-300)
     # at an observation the posterior mean interpolates within the noise level and sigma^2 collapses
     mu_x, var_x = m.predict_f(X[:64].T)
     assert np.all(var_x < 0.05)
@@ -461,6 +466,36 @@ def test_small_batch_path_agrees_with_mfma_path(bohip, orc):
         assert np.all(np.abs(var - var_o) <= var_tol(var_o, 900, math.exp(0.4)))
         _, bv, bi = m.score("EI", [tau], Xs[lo:lo + n].T)
         assert bi == int(np.argmax(sc)) and bv == sc[bi]
+
+
+@pytest.mark.parametrize("N,d,R", [(1500, 5, 300), (1100, 3, 700), (3000, 8, 257)])
+def test_split_k_path_vs_oracle_and_whole_k(bohip, orc, N, d, R):
+    """A few hundred candidates leave the whole-K MFMA jobs on a handful of CUs, so the contraction index is cut into
+    slices (k_gemm_nt batched over slices + k_split_combine_v/u).  Against the oracle, and against the whole-K schedule
+    (forced through the batch hint) to rounding; values and gradients; bit-deterministic and batch-independent."""
+    X, y, Xs = synth(N, d, R, seed=33)
+    ll = np.linspace(-0.8, -0.4, d)
+    L, alpha = orc.fit(X, y, ll, 0.1, -2.0, 0.05)
+    m = make_model(bohip, X, y, ll, 0.1, -2.0, 0.05)
+    tau = float(y.max())
+    s2f = math.exp(0.2)
+    sc, g = m.score_grad("UCB", [2.0], Xs.T)
+    sub = np.random.default_rng(1).choice(R, 120, replace=False)
+    sc_o, g_o = orc.score_grad(X, ll, 0.1, 0.05, L, alpha, "UCB", [2.0], Xs[sub])
+    _, var_o = orc.predict(X, ll, 0.1, 0.05, L, alpha, Xs[sub])
+    floor = mu_floor(alpha, s2f) + 2.0 * np.sqrt(var_tol(var_o, N, s2f, rel=0))
+    check_scores(sc[sub], sc_o, floor)
+    good = var_o > 1e3 * var_tol(var_o, N, s2f)
+    np.testing.assert_allclose(g.T[sub][good], g_o[good], rtol=1e-5, atol=1e-7 * np.abs(g_o).max())
+    sv, bv, bi = m.score("UCB", [2.0], Xs.T)
+    np.testing.assert_array_equal(sv, sc)                                  # value path == gradient path, bit for bit
+    assert bi == int(np.argmax(sv)) and bv == sv[bi]
+    np.testing.assert_array_equal(m.score("UCB", [2.0], Xs[40:R - 3].T)[0], sv[40:R - 3])   # batch-independent (same schedule)
+    m.set_batch_hint(1 << 20)                                              # whole-K schedule
+    sw, gw = m.score_grad("UCB", [2.0], Xs.T)
+    m.set_batch_hint(0)
+    np.testing.assert_allclose(sc, sw, rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(g, gw, rtol=1e-7, atol=1e-10 * np.abs(gw).max())
 
 
 def test_candidate_chunking_is_invisible(bohip, orc):

@@ -8,8 +8,8 @@ from oracle.oracle import COracle
 from conftest import synth, var_tol
 orc = COracle()
 EPS = np.finfo(float).eps
-Ns = [1, 2, 63, 127, 128, 129, 255, 256, 257, 383, 384, 385, 640, 1000]
-Rs = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 200, 513]
+Ns = [1, 2, 63, 127, 128, 129, 255, 256, 257, 383, 384, 385, 640, 1000, 1153, 1600]
+Rs = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 200, 257, 300, 513, 700]
 rng = np.random.default_rng(int(os.environ.get("SEED", 0)))
 fails = 0; cases = 0
 t0 = time.time()
