@@ -104,6 +104,10 @@ function BO.acquire_max(a::BO.AbstractAcquisition, m::BOHipGPE, lowerbounds, upp
     j == 0 ? (-Inf, lowerbounds) : (maxf, starts[:, j])
 end
 
+"Sharded scoring: announce the size of the whole candidate set so a shard is summed exactly like the unsharded batch."
+set_batch_hint!(m::BOHipGPE, total::Integer) =
+    check(ccall((:bohip_gp_set_batch_hint, libbohip), Cint, (Ptr{Cvoid}, Int64), m.handle, total))
+
 # ---- reference src/models/gp.jl:42-77: MAP hyper-parameter fit -------------------------------------------
 # f = (x, g) -> (set_params!; update_target_and_dtarget!; g .= gp.dtarget; gp.target) with the device doing the
 # rebuild, the marginal likelihood and its analytic gradient; parameter order [logNoise; mean; loglen...; logsig].
