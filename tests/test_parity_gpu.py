@@ -606,6 +606,27 @@ def test_device_ascent_matches_host_restatement(bohip, orc):
             np.testing.assert_array_equal(bx, Xb[:, j])
 
 
+def test_device_ascent_on_the_split_k_and_whole_k_schedules(bohip):
+    """Restart counts beyond the row-wise path: 300 (split-K) and 1500 (whole-K jobs) starts at N = 1100."""
+    from bohip.acquisition import _batched_lbfgs_ascent
+
+    X, y, _ = synth(1100, 3, 4, seed=14)
+    m = make_model(bohip, X, y, np.array([-1.0, -0.8, -0.6]), 0.2, -2.0, 0.0)
+    lb, ub = np.zeros(3), np.ones(3)
+    rng = np.random.default_rng(4)
+    for R in (300, 1500):
+        starts = np.asfortranarray(rng.random((3, R)))
+        f0, _ = m.score_grad("UCB", [2.0], starts)
+        f, Xb, bf, bi, bx, ev = m.ascend("UCB", [2.0], lb, ub, starts, maxeval=60)
+        fh, Xh = _batched_lbfgs_ascent(lambda Z: m.score_grad("UCB", [2.0], Z), starts, lb, ub, 60)
+        assert np.all(f >= f0 - 1e-12) and np.all(Xb >= 0) and np.all(Xb <= 1)
+        fchk, _ = m.score_grad("UCB", [2.0], Xb)
+        np.testing.assert_allclose(fchk, f, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(f, fh, rtol=1e-5, atol=1e-8)
+        j = int(np.argmax(f))
+        assert bi == j and bf == f[j]
+
+
 def test_device_ascent_respects_bounds_and_edge_cases(bohip):
     X, y, _ = synth(60, 3, 4, seed=2)
     m = make_model(bohip, X, y, np.zeros(3), 0.0, -1.0, 0.0)
