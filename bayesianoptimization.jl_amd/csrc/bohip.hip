@@ -69,6 +69,7 @@ struct bohip_gp {
     hipEvent_t ev_panels = nullptr, ev_bulk = nullptr;
     hipStream_t inv_stream = nullptr;             // W = L^-1 grows block by block beside the factorisation's diagonal chain
     hipEvent_t ev_blk = nullptr, ev_inv = nullptr;
+    hipEvent_t ev_gate = nullptr;                 // a diagonal-block kernel is about to start: release one piece of the pending bulk update
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
@@ -209,6 +210,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
 static int g_inv_overlap = 0;  // BOHIP_INV_OVERLAP=1: grow W = L^-1 block by block beside the factorisation instead of after it.
                                // Measured: refit 3.67 -> 3.56 ms (N=3000), 21.4 -> 19.9 ms (N=10000), but the factorisation itself slows
                                // down under the competition (2.90 -> 3.08 ms, 13.9 -> 17.7 ms), so it stays opt-in.
+static int g_bulk_pieces = 4;   // gated pieces of the side-stream bulk update per outer block (BOHIP_BULK_PIECES; 0/1: one launch)
 static int g_split = 1;   // split-K path for batches of a few hundred candidates (BOHIP_SPLIT=0 disables)
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
@@ -233,6 +235,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
+    if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
     if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
     if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_MAX, std::max(0, atoi(e)));
@@ -342,11 +345,40 @@ static int refit(bohip_gp* g) {
     // are therefore read-modified-written T/OB times instead of T times and the bulk contraction is OB x deeper.
     const int OB = 4;
     bool side_pending = false;
+    // The bulk update of the columns right of the NEXT block runs on the side stream.  Run as one launch it shares the chip
+    // with the next block's whole diagonal chain and slows the chain's small GEMMs 3-6x (N = 10^4: 90-120 us instead of
+    // 15-25 us each).  So it is cut into pieces of equal area, and piece j is released by an event recorded just before the
+    // j-th diagonal-block kernel of the next block starts: the pieces fill the ~70 us during which that single-workgroup
+    // kernel leaves the chip idle and are (mostly) gone when the chain's GEMMs arrive.
+    struct Pending { int ob = 0, oe = 0, c0 = 0, rest = 0, next = 0, pieces = 0; int cut[9] = {0}; } pend;
+    auto bulk_params = [&](int pob, int poe, int r0t, int c0t, int mt, int nct) {
+        GemmNTParams b{};  // A[i, j] -= L[i, pob:poe] L[j, pob:poe]'  on rows >= r0t, columns [c0t, c0t + nct)
+        b.A = g->dS + (int64_t)r0t * TILE * ld + (int64_t)pob * TILE; b.lda = ld;
+        b.B = g->dS + (int64_t)c0t * TILE * ld + (int64_t)pob * TILE; b.ldb = ld;
+        b.C = g->dL + (int64_t)r0t * TILE * ld + (int64_t)c0t * TILE; b.ldc = ld;
+        b.mt = mt; b.nt64 = 2 * nct; b.kc = (poe - pob) * (TILE / KC); b.alpha = -1.0; b.beta = 1.0;
+        b.diag_skip = 1; b.row0 = (int64_t)r0t * TILE; b.col0 = (int64_t)c0t * TILE;
+        return b;
+    };
+    auto release_piece = [&](bool gated) -> int {   // next piece of the pending bulk update -> side stream
+        if (pend.next >= pend.pieces) return 0;
+        if (gated) {
+            HIPCHK(hipEventRecord(g->ev_gate, g->stream));
+            HIPCHK(hipStreamWaitEvent(g->side_stream, g->ev_gate, 0));
+        }
+        const int a = pend.cut[pend.next], b = pend.cut[pend.next + 1];
+        ++pend.next;
+        if (b > a)   // columns [c0 + a, c0 + b) of the pending region, rows from the first of them down
+            CHK(launch_gemm_nt(g, bulk_params(pend.ob, pend.oe, pend.c0 + a, pend.c0 + a, pend.rest - a, b - a), 1, g->side_stream));
+        if (pend.next == pend.pieces) HIPCHK(hipEventRecord(g->ev_bulk, g->side_stream));
+        return 0;
+    };
     for (int ob = 0; ob < T; ob += OB) {
         const int oe = std::min(T, ob + OB);
         for (int kb = ob; kb < oe; ++kb) {
             double* Lkk = g->dL + (int64_t)kb * TILE * (ld + 1);
             double* Wkk = g->dW + (int64_t)kb * TILE * (ld + 1);
+            CHK(release_piece(true));
             hipLaunchKernelGGL(k_potf2_inv, dim3(1), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, Lkk, ld, Wkk,
                                g->dWT + (int64_t)kb * TILE * (ld + 1), ld, g->dinfo, kb * TILE);
             HIPCHK(hipGetLastError());
@@ -368,6 +400,7 @@ static int refit(bohip_gp* g) {
                 CHK(launch_gemm_nt(g, u));
             }
         }
+        while (pend.next < pend.pieces) CHK(release_piece(false));   // a short last block: whatever is left goes now
         if (g_inv_overlap) {
             // The block's panels are final: invert its diagonal region and join it to the leading inverse on the inverse
             // stream, beside the next blocks' diagonal chain (which leaves most CUs idle).  Reads dS panels of columns
@@ -379,29 +412,28 @@ static int refit(bohip_gp* g) {
         }
         const int rem = T - oe;
         if (rem > 0) {
-            // Bulk update with the OB solved panels, split for look-ahead: the columns of the NEXT outer block are
-            // updated on the critical stream; everything to their right goes to the side stream and overlaps the next
-            // block's diagonal factorisations.  Hazards: (1) the side stream needs the panels -> ev_panels;
-            // (2) next block's columns were last written by the previous side-stream update -> ev_bulk.
+            // Bulk update with the OB solved panels: the columns of the NEXT outer block on the critical stream, everything
+            // to their right in gated pieces on the side stream.  Hazards: (1) the side stream needs the panels -> ev_panels;
+            // (2) the next block's columns were last written by the previous block's pieces -> ev_bulk (after the last one).
             const int nxt = std::min(OB, rem), rest = rem - nxt;
-            auto bulk = [&](int r0t, int c0t, int mt, int nct) {
-                GemmNTParams b{};  // A[i, j] -= L[i, ob:oe] L[j, ob:oe]'  on rows >= r0t, columns [c0t, c0t + nct)
-                b.A = g->dS + (int64_t)r0t * TILE * ld + (int64_t)ob * TILE; b.lda = ld;
-                b.B = g->dS + (int64_t)c0t * TILE * ld + (int64_t)ob * TILE; b.ldb = ld;
-                b.C = g->dL + (int64_t)r0t * TILE * ld + (int64_t)c0t * TILE; b.ldc = ld;
-                b.mt = mt; b.nt64 = 2 * nct; b.kc = (oe - ob) * (TILE / KC); b.alpha = -1.0; b.beta = 1.0;
-                b.diag_skip = 1; b.row0 = (int64_t)r0t * TILE; b.col0 = (int64_t)c0t * TILE;
-                return b;
-            };
             if (rest > 0) {
                 HIPCHK(hipEventRecord(g->ev_panels, g->stream));
                 HIPCHK(hipStreamWaitEvent(g->side_stream, g->ev_panels, 0));
             }
             if (side_pending) HIPCHK(hipStreamWaitEvent(g->stream, g->ev_bulk, 0));
-            CHK(launch_gemm_nt(g, bulk(oe, oe, rem, nxt)));
+            CHK(launch_gemm_nt(g, bulk_params(ob, oe, oe, oe, rem, nxt)));
             if (rest > 0) {
-                CHK(launch_gemm_nt(g, bulk(oe + nxt, oe + nxt, rest, rest), 1, g->side_stream));
-                HIPCHK(hipEventRecord(g->ev_bulk, g->side_stream));
+                pend = Pending{};
+                pend.ob = ob; pend.oe = oe; pend.c0 = oe + nxt; pend.rest = rest; pend.next = 0;
+                pend.pieces = g_bulk_pieces > 0 ? std::min({g_bulk_pieces, nxt, rest}) : 1;
+                // equal-area cuts of the lower-triangular region: the area left of column c is c rest - c (c - 1) / 2
+                const double total = 0.5 * rest * (rest + 1.0);
+                for (int q = 0, c = 0; q <= pend.pieces; ++q) {
+                    const double want = total * q / pend.pieces;
+                    while (c < rest && c * (double)rest - 0.5 * c * (c - 1.0) < want - 1e-9) ++c;
+                    pend.cut[q] = q == pend.pieces ? rest : c;
+                }
+                if (pend.pieces == 1) CHK(release_piece(false));   // ungated single launch (small problems, BOHIP_BULK_PIECES=0)
                 side_pending = true;
             } else {
                 side_pending = false;
@@ -879,6 +911,7 @@ int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohi
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->inv_stream, hipStreamNonBlocking, prio_lo);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_blk, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_inv, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_gate, hipEventDisableTiming);
     if (e != hipSuccess) { delete g; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
     g->stream = g->own_stream;
     if (hipHostMalloc((void**)&g->hpin, (size_t)(3 * SMALL_R + 2 + SMALL_R * DMAX) * 8, hipHostMallocDefault) != hipSuccess) g->hpin = nullptr;
@@ -924,6 +957,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->inv_stream) { hipStreamSynchronize(g->inv_stream); hipStreamDestroy(g->inv_stream); }
     if (g->ev_blk) hipEventDestroy(g->ev_blk);
     if (g->ev_inv) hipEventDestroy(g->ev_inv);
+    if (g->ev_gate) hipEventDestroy(g->ev_gate);
     if (g->own_stream) hipStreamDestroy(g->own_stream);
     delete g;
 }
