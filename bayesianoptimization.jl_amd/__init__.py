@@ -7,6 +7,7 @@ libbohip.so (HIP, gfx950).  See DESIGN.md / INTEGRATION.md.
 from . import _lib
 from ._lib import BohipError, NotPositiveDefinite
 from .model import (ElasticGPE, MeanConst, MeanZero, SEArd, SEIso, Mat52Ard, mean_var, myrand, dims, maxy, update_)
+from .multigpu import MultiGPE, comm_unique_id
 from .acquisition import (ExpectedImprovement, ProbabilityOfImprovement, UpperConfidenceBound, ThompsonSamplingSimple,
                           MutualInformation, MaxMean, BrochuBetaScaling, NoBetaScaling, acquisitionfunction, setparams_,
                           acquire_max, acquire_model_max, defaultoptions)
@@ -21,4 +22,4 @@ __all__ = ["BOpt", "ExpectedImprovement", "ProbabilityOfImprovement", "UpperConf
            "MutualInformation", "boptimize_", "MAPGPOptimizer", "NoModelOptimizer", "Min", "Max", "BrochuBetaScaling",
            "NoBetaScaling", "Silent", "Timings", "Progress", "ScaledSobolIterator", "ScaledLHSIterator",
            "maxduration_", "maxiterations_", "optimize",
-           "ElasticGPE", "GPE", "MeanConst", "MeanZero", "SEArd", "SEIso", "Mat52Ard"]
+           "ElasticGPE", "MultiGPE", "GPE", "MeanConst", "MeanZero", "SEArd", "SEIso", "Mat52Ard"]

@@ -11,10 +11,12 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbohip.so")
 
-OK, E_ARG, E_NOTPD, E_HIP, E_NODEVICE, E_STATE, E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+OK, E_ARG, E_NOTPD, E_HIP, E_NODEVICE, E_STATE, E_UNSUPPORTED, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 KERN = {"SEArd": 0, "SEIso": 1, "Mat52Ard": 2}
 ACQ = {"EI": 0, "PI": 1, "UCB": 2, "MI": 3, "MaxMean": 4}
 INFO_PIVOT, INFO_CAPACITY, INFO_REFITS, INFO_APPENDS = 0, 1, 2, 3
+MGP_INFO_DEVICES, MGP_INFO_SHARDS, MGP_INFO_EXCHANGES, MGP_INFO_RCCL_VERSION = 0, 1, 2, 3
+UNIQUE_ID_BYTES = 128
 
 
 class Best(C.Structure):
@@ -34,6 +36,8 @@ class NotPositiveDefinite(BohipError):
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 _gp = C.c_void_p
+_mgp = C.c_void_p
+_ip = C.POINTER(C.c_int)
 
 # every symbol include/bohip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
@@ -51,6 +55,7 @@ SIGNATURES = {
     "bohip_gp_predict_cov": (C.c_int, [_gp, _dp, C.c_int64, _dp, _dp]),
     "bohip_gp_acquire_max": (C.c_int, [_gp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                       _dp, _dp, C.POINTER(Best), _dp, _i64p]),
+    "bohip_gp_set_maxtime": (C.c_int, [_gp, C.c_double]),
     "bohip_gp_predict": (C.c_int, [_gp, _dp, C.c_int64, _dp, _dp]),
     "bohip_gp_score": (C.c_int, [_gp, C.c_int, _dp, _dp, C.c_int64, _dp, C.POINTER(Best)]),
     "bohip_gp_score_grad": (C.c_int, [_gp, C.c_int, _dp, _dp, C.c_int64, _dp, _dp]),
@@ -65,6 +70,28 @@ SIGNATURES = {
     "bohip_gp_info": (C.c_int, [_gp, C.c_int, _i64p]),
     "bohip_gp_enable_timing": (C.c_int, [_gp, C.c_int]),
     "bohip_gp_get_timing": (C.c_int, [_gp, C.POINTER(C.c_char_p), _dp, C.c_int]),
+    # multi-GPU: one process, a device list (in-library RCCL)
+    "bohip_mgp_create": (C.c_int, [C.c_int64, C.c_int64, C.c_int, _ip, C.c_int, C.c_int, C.POINTER(_mgp)]),
+    "bohip_mgp_destroy": (None, [_mgp]),
+    "bohip_mgp_set_hyper": (C.c_int, [_mgp, _dp, C.c_double, C.c_double, C.c_double]),
+    "bohip_mgp_append": (C.c_int, [_mgp, _dp, _dp, C.c_int64]),
+    "bohip_mgp_refit": (C.c_int, [_mgp]),
+    "bohip_mgp_score": (C.c_int, [_mgp, C.c_int, _dp, _dp, C.c_int64, _dp, C.POINTER(Best)]),
+    "bohip_mgp_set_candidates": (C.c_int, [_mgp, _dp, C.c_int64]),
+    "bohip_mgp_score_resident": (C.c_int, [_mgp, C.c_int, _dp, C.POINTER(Best)]),
+    "bohip_mgp_thompson": (C.c_int, [_mgp, _dp, C.c_int64, C.c_int64, C.c_uint64, C.POINTER(Best)]),
+    "bohip_mgp_acquire_max": (C.c_int, [_mgp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                       _dp, _dp, C.POINTER(Best), _dp, _i64p]),
+    "bohip_mgp_handle": (_gp, [_mgp, C.c_int]),
+    "bohip_mgp_info": (C.c_int, [_mgp, C.c_int, _i64p]),
+    # multi-GPU: one process per device
+    "bohip_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int64]),
+    "bohip_gp_comm_init": (C.c_int, [_gp, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "bohip_gp_comm_destroy": (C.c_int, [_gp]),
+    "bohip_gp_score_sharded_dev": (C.c_int, [_gp, C.c_int, _dp, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                            C.c_void_p]),
+    "bohip_gp_thompson_sharded": (C.c_int, [_gp, _dp, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.c_int64,
+                                           C.POINTER(Best)]),
     "bohip_last_error": (C.c_char_p, []),
     "bohip_version": (C.c_char_p, []),
     "bohip_device_count": (C.c_int, []),
@@ -74,11 +101,12 @@ _lib = None
 
 
 def _one_hip_runtime():
-    """A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
-    /opt/rocm's); whichever is dlopen'ed first wins for both, and torch cannot see the GPU when the
-    system copy got there first.  So when PyTorch is installed (it is the plumbing for device memory,
-    streams and RCCL in bench.py / dist.py) and not yet imported, load its copy first.
-    BOHIP_SYSTEM_HIP=1 skips this."""
+    """A process must hold ONE HIP runtime and ONE RCCL.  PyTorch-ROCm bundles its own libamdhip64 and
+    librccl (same SONAMEs as /opt/rocm's); whichever is dlopen'ed first wins for both users, and torch
+    cannot see the GPU when the system HIP got there first.  So when PyTorch is installed (it is the
+    plumbing for device memory, streams and the process group in bench.py / dist.py) and not yet
+    imported, load its copies first; libbohip's DT_NEEDED entries then resolve to them.
+    BOHIP_SYSTEM_HIP=1 skips this (a process without torch uses /opt/rocm's through the RUNPATH)."""
     if "torch" in sys.modules or os.environ.get("BOHIP_SYSTEM_HIP") == "1":
         return
     try:
@@ -87,12 +115,13 @@ def _one_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return
-    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        try:
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-        except OSError:
-            pass
+    for name in ("libamdhip64.so", "librccl.so"):
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def load():

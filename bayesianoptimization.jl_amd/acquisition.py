@@ -218,16 +218,41 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
     return best_f, best_X
 
 
-def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None):
+# NLopt.Opt properties the reference forwards with setproperty! (src/acquisition.jl:24-27).  The device ascent
+# implements the first group; the second is accepted by NLopt but has no counterpart here (a warning says so);
+# anything else raises, as setproperty! on an NLopt.Opt does.
+_OPTS_USED = {"method", "restarts", "maxeval", "maxtime", "ftol_rel", "xtol_abs"}
+_OPTS_NLOPT_ONLY = {"ftol_abs", "xtol_rel", "stopval", "initial_step", "population", "vector_storage", "seed",
+                    "local_optimizer", "default_initial_step"}
+
+
+def _check_options(opts):
+    for k in opts:
+        if k in _OPTS_USED:
+            continue
+        if k in _OPTS_NLOPT_ONLY:
+            warnings.warn(f"acquisition option {k!r} is an NLopt setting the device ascent does not implement; ignored")
+        else:
+            raise ValueError(f"unknown acquisition option {k!r} (the reference forwards every key to NLopt.Opt, "
+                             "which rejects unknown properties)")
+
+
+def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None, setparams=True):
     """src/acquisition.jl:48-68: R Latin-hypercube starts (utils.jl:96-120), local search from each, keep the
-    best under strict '>' (first maximum wins).  Returns (maxf, maxx)."""
+    best under strict '>' (first maximum wins).  Returns (maxf, maxx).
+    setparams=True is the 5-argument method (:48-51: nlopt_setup calls setparams!, :30); the BO loop has already
+    called setparams! (src/BayesianOptimization.jl:184) and uses the 4-argument method on its prepared optimiser
+    (:185), i.e. setparams=False -- MutualInformation's update is not idempotent."""
     lb = np.asarray(lowerbounds, dtype=np.float64)
     ub = np.asarray(upperbounds, dtype=np.float64)
     opts = options if isinstance(options, dict) else dict(vars(options))
-    setparams_(a, model)                                          # nlopt_setup :30
+    _check_options(opts)
+    if setparams:
+        setparams_(a, model)                                      # nlopt_setup :30
     method = str(opts.get("method", "LD_LBFGS")).lstrip(":")
     restarts = int(opts.get("restarts", 10))
     maxeval = int(opts.get("maxeval", 2000))
+    maxtime = float(opts.get("maxtime", 0.0) or 0.0)
     maxf, maxx = -math.inf, lb.copy()                             # :55-56
     if model.nobs == 0 or restarts <= 0:
         return maxf, maxx
@@ -245,10 +270,14 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None):
     acq, p = a.acq_id, a.params()
     if derivative:
         starts = latin_hypercube_sampling(lb, ub, restarts, rng)
-        iters = max(2, min(maxeval, 200))
+        # maxeval: NLopt counts objective evaluations per start; the lock-step ascent spends one evaluation of EVERY
+        # start per device pass, so the same number bounds the passes.  No other cap.
+        iters = max(2, maxeval)
 
         ftol, xtol = float(opts.get("ftol_rel", 1e-10)), float(opts.get("xtol_abs", 1e-10))
         if hasattr(model, "ascend"):                              # device model: the whole search runs in libbohip
+            if hasattr(model, "set_maxtime"):
+                model.set_maxtime(maxtime)                        # NLopt maxtime: per optimize call = per acquire_max here
             f, X, bf, bi, bx, _ = model.ascend(acq, p, lb, ub, starts, iters, ftol, xtol)
             if bi >= 0:
                 return float(bf), np.array(bx)

@@ -10,6 +10,7 @@ import warnings
 import numpy as np
 
 from .acquisition import (AbstractAcquisition, ExpectedImprovement, MaxMean, acquire_max, defaultoptions, setparams_)
+from ._lib import NotPositiveDefinite
 from .model import ElasticGPE, Mat52Ard, MeanConst, update_
 from .utils import (DurationCounter, IterationCounter, ScaledSobolIterator, init_, isdone as _isdone, step_)
 
@@ -70,18 +71,18 @@ def _map_fit(model, opt):                                     # :54-77
     names, x0, lo, hi = [], [], [], []
     if opt["noise"]:
         names.append("noise"); x0.append(model.logNoise)
-        b = opt["noisebounds"] or [-math.inf, math.inf]
+        b = opt["noisebounds"] if opt["noisebounds"] is not None else [-math.inf, math.inf]
         lo.append(b[0]); hi.append(b[1])
     if opt["domean"] and isinstance(model.mean, MeanConst):
         names.append("mean"); x0.append(model.mean.beta)
-        b = opt["meanbounds"] or [[-math.inf], [math.inf]]
+        b = opt["meanbounds"] if opt["meanbounds"] is not None else [[-math.inf], [math.inf]]
         lo.append(np.ravel(b[0])[0]); hi.append(np.ravel(b[1])[0])
     nk = 0
     if opt["kern"]:
         kp = np.concatenate([model.kernel.ll, [model.kernel.lsigma]])
         nk = kp.size
         names += ["kern"] * nk; x0 += kp.tolist()
-        b = opt["kernbounds"] or [[-math.inf] * nk, [math.inf] * nk]
+        b = opt["kernbounds"] if opt["kernbounds"] is not None else [[-math.inf] * nk, [math.inf] * nk]
         lo += list(np.ravel(b[0]).astype(float)); hi += list(np.ravel(b[1]).astype(float))
     x0 = np.clip(np.array(x0, float), lo, hi)
 
@@ -100,8 +101,8 @@ def _map_fit(model, opt):                                     # :54-77
         apply(x)
         try:
             m, dn, dm, dk = model.mll_grad()
-        except Exception:                                     # not positive definite for these parameters
-            return 1e300, np.zeros_like(x)
+        except NotPositiveDefinite:                           # not positive definite for these parameters; device
+            return 1e300, np.zeros_like(x)                    # failures (E_HIP, E_NODEVICE, ...) propagate
         g = []
         if opt["noise"]:
             g.append(dn)
@@ -222,7 +223,8 @@ def boptimize_(o):
             print(f"{time.strftime('%Y-%m-%dT%H:%M:%S')}\titeration: {o.iterations.i}\tcurrent optimum: {o.observed_optimum}")
         setparams_(o.acquisition, o.model)                                       # :184
         with _timeit(o, "acquisition"):
-            f, x = acquire_max(o.acquisition, o.model, o.lowerbounds, o.upperbounds, o.acquisitionoptions, o.rng)
+            f, x = acquire_max(o.acquisition, o.model, o.lowerbounds, o.upperbounds, o.acquisitionoptions, o.rng,
+                               setparams=False)                                  # :185 (4-argument method: no second setparams!)
         ys = []
         step_(o.iterations)
         for _ in range(o.repetitions):

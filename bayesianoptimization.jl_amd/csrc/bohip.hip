@@ -20,6 +20,7 @@
 #include "kernels_ascent.hip"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -80,6 +81,7 @@ struct bohip_gp {
     Best *dblock_best = nullptr, *dbest = nullptr;
     int64_t bb_cap = 0;
     double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
+    double asc_maxtime = 0.0;    // bohip_gp_set_maxtime: wall-clock budget of one acquire_max call in seconds (NLopt maxtime), 0 = none
     int64_t batch_hint = 0;      // bohip_gp_set_batch_hint: choose the scoring path as if the batch had at least this many candidates
     double* dsplit = nullptr;    // split-K partial planes (batches of a few hundred candidates)
     int64_t split_cap = 0;
@@ -103,6 +105,11 @@ struct bohip_gp {
     int64_t cov_cap = 0;
     int64_t dmll_cap = 0;
     int64_t thompson_cap = 0;
+    // one-process-per-device exchange (multigpu.hip): communicator attached by bohip_gp_comm_init
+    void* comm = nullptr;
+    int comm_rank = 0, comm_n = 0;
+    Best *csend = nullptr, *crecv = nullptr, *cfinal = nullptr;
+    int64_t crec_cap = 0;
     // bookkeeping
     int64_t pivot = 0, refits = 0, appends = 0;
     int q_tiles = 0;  // number of q_part rows the last posterior pass produced (T, or 1 on the small-batch path)
@@ -516,6 +523,7 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
 }
 
 static int ensure_fresh(bohip_gp* g) {
+    if (g->dL == nullptr || g->cap < g->n) CHK(alloc_model(g, std::max<int64_t>(g->n, 1)));   // a failed growth left no buffers
     if (g->stale || g->n_factored != g->n) return refit(g);
     return 0;
 }
@@ -637,7 +645,7 @@ static int64_t small_limit(const bohip_gp* g) {
 static int64_t path_R(const bohip_gp* g, int64_t R) { return std::max(R, g->batch_hint); }
 // candidates [r0, r1), at most SMALL_MAX of them; the output pointers are indexed by the GLOBAL candidate number
 static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, bool want_u, const AcqParams& ap,
-                           double* d_mu, double* d_var, double* d_score, Best* d_best) {
+                           double* d_mu, double* d_var, double* d_score, Best* d_best, int64_t best_off = 0) {
     CHK(ensure_small_counters(g));
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), ld = g->ld;
     const int P = (int)(r1 - r0);
@@ -650,7 +658,7 @@ static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r
     CHK(launch_rows_trimv(g, g->dW, N + 1, g->dKsT, P, g->dApp, 0));
     hipLaunchKernelGGL(k_small_finish, dim3((unsigned)P), dim3(256), 0, g->stream, g->dApp, ld, N, P, g->dq + r0, g->dmu_raw + r0,
                        g->dgcount + SMALL_MAX, std::exp(2.0 * g->logsig), g->beta, ap, d_mu ? d_mu + r0 : nullptr,
-                       d_var ? d_var + r0 : nullptr, d_score ? d_score + r0 : nullptr, d_best);
+                       d_var ? d_var + r0 : nullptr, d_score ? d_score + r0 : nullptr, d_best, (long long)best_off);
     HIPCHK(hipGetLastError());
     t_end(g);
     g->q_tiles = 1;
@@ -750,8 +758,9 @@ static int split_posterior(bohip_gp* g, const double* dXs, int64_t R, const Spli
     return 0;
 }
 
+// best_off: added to the winner's index (a shard of a larger candidate set reports GLOBAL columns)
 static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const double* dXs, int64_t R, double* d_mu,
-                      double* d_var, double* d_score, Best* d_best) {
+                      double* d_var, double* d_score, Best* d_best, int64_t best_off = 0) {
     if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
     CHK(ensure_fresh(g));
     CHK(ensure_score_scratch(g, R));
@@ -764,7 +773,7 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     }
     if (path_R(g, R) <= small_limit(g) && R <= SMALL_MAX) {   // row-wise posterior, scoring and arg-max fused into its finish kernel
         CHK(one_time_kernel_setup());
-        return small_posterior(g, dXs, 0, R, false, ap, d_mu, d_var, d_score, d_best);
+        return small_posterior(g, dXs, 0, R, false, ap, d_mu, d_var, d_score, d_best, best_off);
     }
     const SplitPlan sp = split_plan(g, R);
     if (sp.nsl > 0) CHK(split_posterior(g, dXs, R, sp, false));
@@ -775,7 +784,7 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
     t_begin(g, "score");
     hipLaunchKernelGGL(k_score, dim3(nb), dim3(256), 0, g->stream, g->dq, Rpad, g->q_tiles, g->dmu_raw, R,
                        std::exp(2.0 * g->logsig), g->beta, ap, d_mu, d_var, d_score, d_best ? g->dblock_best : nullptr);
-    if (d_best) hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, g->stream, g->dblock_best, nb, d_best);
+    if (d_best) hipLaunchKernelGGL(k_argmax_final, dim3(1), dim3(256), 0, g->stream, g->dblock_best, nb, d_best, (long long)best_off);
     HIPCHK(hipGetLastError());
     t_end(g);
     return 0;
@@ -926,10 +935,12 @@ int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohi
     return 0;
 }
 
+int bohip_gp_comm_destroy(bohip_gp* g);
 void bohip_gp_destroy(bohip_gp* g) {
     if (!g) return;
     hipSetDevice(g->device);
     if (g->own_stream) hipStreamSynchronize(g->own_stream);
+    if (g->comm) bohip_gp_comm_destroy(g);
     free_model(g);
     for (double** p : {&g->dKsT, &g->dq, &g->dmu_raw, &g->dXs, &g->dmu, &g->dvar, &g->dscore, &g->dmll, &g->dVT, &g->dUT})
         if (*p) hipFree(*p);
@@ -982,16 +993,31 @@ int bohip_gp_append(bohip_gp* g, const double* X, const double* y, int64_t p) {
     int rc = 0;
     bool done = false;
     if (p > 0) {
-        g->hX.insert(g->hX.end(), X, X + p * g->d);
-        g->hy.insert(g->hy.end(), y, y + p);
         const int64_t n_old = g->n, n_new = g->n + p;
         if (n_new > g->cap) {
+            // growth: alloc_model re-uploads everything from the host mirrors, so they are extended first -- and rolled
+            // back if the allocation fails (the handle then holds its old observations and no device buffers; the next
+            // call that needs them allocates again, see ensure_fresh)
+            g->hX.insert(g->hX.end(), X, X + p * g->d);
+            g->hy.insert(g->hy.end(), y, y + p);
             g->n = n_new;
-            CHK(alloc_model(g, std::max<int64_t>(2 * g->cap, n_new)));
+            const int arc = alloc_model(g, std::max<int64_t>(2 * g->cap, n_new));
+            if (arc != 0) {
+                g->hX.resize((size_t)n_old * g->d);
+                g->hy.resize((size_t)n_old);
+                g->n = n_old;
+                free_model(g);
+                g->cap = 0;
+                g->stale = true;
+                return arc;
+            }
         } else {
-            HIPCHK(hipMemcpyAsync(g->dX + g->n * g->d, X, (size_t)p * g->d * 8, hipMemcpyHostToDevice, g->stream));
-            HIPCHK(hipMemcpyAsync(g->dy + g->n, y, (size_t)p * 8, hipMemcpyHostToDevice, g->stream));
+            // the mirrors and n advance only after the device holds the new rows: a failed copy leaves the handle unchanged
+            HIPCHK(hipMemcpyAsync(g->dX + n_old * g->d, X, (size_t)p * g->d * 8, hipMemcpyHostToDevice, g->stream));
+            HIPCHK(hipMemcpyAsync(g->dy + n_old, y, (size_t)p * 8, hipMemcpyHostToDevice, g->stream));
             HIPCHK(hipStreamSynchronize(g->stream));  // caller's buffers are only valid during the call
+            g->hX.insert(g->hX.end(), X, X + p * g->d);
+            g->hy.insert(g->hy.end(), y, y + p);
             g->n = n_new;
             if (!g->stale && g->n_factored == n_old && n_old > 0 && p <= APPEND_PMAX) {
                 rc = append_incremental(g, n_old, p);
@@ -1348,7 +1374,11 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     int64_t evals = 1;
     int nh = 0, it = 0;
     bool any_active = any_of(st.h_active, 1);
-    while (evals < maxeval && any_active) {
+    const auto t_start = std::chrono::steady_clock::now();
+    auto out_of_time = [&]() {   // NLopt's maxtime (reference src/acquisition.jl:24-27 forwards it): checked once per iteration
+        return g->asc_maxtime > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= g->asc_maxtime;
+    };
+    while (evals < maxeval && any_active && !out_of_time()) {
         hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, nh, (it + ASC_M - 1) % ASC_M, dlb, dub,
                            0.1 * span);
         for (int bt = 0; bt < 12; ++bt) {   // backtracking Armijo, all start points per device pass
@@ -1397,7 +1427,7 @@ int bohip_gp_thompson(bohip_gp* g, const double* Xs, int64_t R, int64_t S, uint6
     }
     Best* dout = g->dthompson;
     t_begin(g, "thompson");
-    hipLaunchKernelGGL(k_thompson, dim3(S), dim3(256), 0, g->stream, g->dmu, g->dvar, R, seed, j0, dout);
+    hipLaunchKernelGGL(k_thompson, dim3(S), dim3(256), 0, g->stream, g->dmu, g->dvar, R, seed, j0, dout, 0ll);
     t_end(g);
     hipError_t e = hipMemcpyAsync(best, dout, S * sizeof(Best), hipMemcpyDeviceToHost, g->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
@@ -1452,6 +1482,11 @@ int bohip_gp_set_batch_hint(bohip_gp* g, int64_t total_candidates) {
     g->batch_hint = total_candidates;
     return 0;
 }
+int bohip_gp_set_maxtime(bohip_gp* g, double seconds) {
+    if (!g || !(seconds >= 0.0)) return fail(BOHIP_E_ARG, "bad arguments");
+    g->asc_maxtime = seconds;
+    return 0;
+}
 int bohip_gp_enable_timing(bohip_gp* g, int on) {
     if (!g) return fail(BOHIP_E_ARG, "null handle");
     g->timing = on != 0;
@@ -1468,6 +1503,9 @@ int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {
     return (int)g->tnames.size();
 }
 
+}  // extern "C"
+#include "multigpu.hip"
+extern "C" {
 #if BOHIP_TRACE
 int bohip_debug_trace_read(unsigned long long* out, int64_t n_words) {   // tools only
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -3;

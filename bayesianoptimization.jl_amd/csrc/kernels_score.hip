@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_small_finish(const double* __restrict__
                                                       unsigned* __restrict__ counter, double sigma2, double beta,
                                                       AcqParams ap, double* __restrict__ mu_out,
                                                       double* __restrict__ var_out, double* __restrict__ score_out,
-                                                      Best* __restrict__ best_out) {
+                                                      Best* __restrict__ best_out, long long idx_off) {
 #pragma clang fp contract(off)
     __shared__ double red[256];
     __shared__ Best sh[4];
@@ -356,18 +356,36 @@ __global__ __launch_bounds__(256) void k_small_finish(const double* __restrict__
     }
     if (best_out) {
         block_argmax(f_best, idx, sh);
-        if (threadIdx.x == 0) { best_out->val = idx >= 0 ? f_best : -INFINITY; best_out->idx = idx; }
+        if (threadIdx.x == 0) { best_out->val = idx >= 0 ? f_best : -INFINITY; best_out->idx = idx >= 0 ? idx + idx_off : -1; }
     }
 }
 
-__global__ __launch_bounds__(256) void k_argmax_final(const Best* __restrict__ in, int n, Best* __restrict__ out) {
+// idx_off: global column of this shard's first candidate (sharded scoring: the record leaves the kernel ready for the exchange)
+__global__ __launch_bounds__(256) void k_argmax_final(const Best* __restrict__ in, int n, Best* __restrict__ out, long long idx_off) {
     __shared__ Best sh[4];
     double v = -INFINITY;
     long long idx = -1;
     for (int i = threadIdx.x; i < n; i += 256)
         if (better(in[i].val, in[i].idx, v, idx)) { v = in[i].val; idx = in[i].idx; }
     block_argmax(v, idx, sh);
-    if (threadIdx.x == 0) { out->val = idx >= 0 ? v : -INFINITY; out->idx = idx; }
+    if (threadIdx.x == 0) { out->val = idx >= 0 ? v : -INFINITY; out->idx = idx >= 0 ? idx + idx_off : -1; }
+}
+
+// The exchange step of sharded scoring: `all` holds nrec records per draw-slot layout [rec][S] gathered
+// from every shard (global indices); thread s reduces slot s over the records in (value desc, index asc) order -- the
+// same rule on every rank, so every rank holds the same winner, and it equals the unsharded arg-max (first maximum wins,
+// reference src/acquisition.jl:62).
+__global__ __launch_bounds__(256) void k_reduce_records(const Best* __restrict__ all, int nrec, int S, Best* __restrict__ out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    double v = -INFINITY;
+    long long idx = -1;
+    for (int r = 0; r < nrec; ++r) {
+        const Best b = all[(int64_t)r * S + s];
+        if (better(b.val, b.idx, v, idx)) { v = b.val; idx = b.idx; }
+    }
+    out[s].val = idx >= 0 ? v : -INFINITY;
+    out[s].idx = idx;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -592,7 +610,8 @@ __host__ __device__ inline double thompson_normal(uint64_t seed, int64_t s, int6
 
 // one workgroup per draw s; threads stride the candidates; never materialises S x R.
 __global__ __launch_bounds__(256) void k_thompson(const double* __restrict__ mu, const double* __restrict__ var,
-                                                  int64_t R, uint64_t seed, int64_t j0, Best* __restrict__ out) {
+                                                  int64_t R, uint64_t seed, int64_t j0, Best* __restrict__ out,
+                                                  long long idx_off) {
 #pragma clang fp contract(off)
     __shared__ Best sh[4];
     const int64_t s = blockIdx.x;
@@ -603,7 +622,7 @@ __global__ __launch_bounds__(256) void k_thompson(const double* __restrict__ mu,
         if (better(f, r, v, idx)) { v = f; idx = r; }
     }
     block_argmax(v, idx, sh);
-    if (threadIdx.x == 0) { out[s].val = idx >= 0 ? v : -INFINITY; out[s].idx = idx; }
+    if (threadIdx.x == 0) { out[s].val = idx >= 0 ? v : -INFINITY; out[s].idx = idx >= 0 ? idx + idx_off : -1; }
 }
 
 }  // namespace bohip

@@ -210,7 +210,11 @@ class ElasticGPE:
         check(self._lib.bohip_gp_score_grad(self._h, _lib.ACQ[acq], _ptr(p), _ptr(xs), R, _ptr(sc), _ptr(grad)))
         return sc, grad
 
-    def ascend(self, acq, params, lowerbounds, upperbounds, starts, maxeval=200, ftol_rel=1e-10, xtol_abs=1e-10):
+    def set_maxtime(self, seconds):
+        """NLopt's maxtime for the device ascent (0 = unlimited)."""
+        check(self._lib.bohip_gp_set_maxtime(self._h, float(seconds)))
+
+    def ascend(self, acq, params, lowerbounds, upperbounds, starts, maxeval=2000, ftol_rel=1e-10, xtol_abs=1e-10):
         """Local search of acquire_max on the device (src/acquisition.jl:48-68 with :LD_LBFGS and bounds): every start
         column is refined by a projected L-BFGS ascent, all columns in lock step.  Returns
         (f[R], X[d, R], best_f, best_index, best_x[d], evaluations)."""
@@ -232,6 +236,33 @@ class ElasticGPE:
                                              float(ftol_rel), float(xtol_abs), _ptr(X), _ptr(f), C.byref(best), _ptr(bx),
                                              C.byref(ev)))
         return f, X, best.val, best.idx, bx, ev.value
+
+    # -- one process per device: communicator on the handle, exchange inside libbohip (in-library RCCL) ---------
+    def comm_init(self, unique_id, rank, nranks):
+        buf = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
+        check(self._lib.bohip_gp_comm_init(self._h, buf, _lib.UNIQUE_ID_BYTES, int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        check(self._lib.bohip_gp_comm_destroy(self._h))
+
+    def score_sharded_dev(self, acq, params, d_xs_ptr, R_local, col_offset, R_total, d_best_ptr, d_score_ptr=None):
+        """Enqueue: score this rank's shard, all-gather the records over RCCL, reduce on the device; the global winner
+        lands at d_best_ptr (device or pinned-host address), identical on every rank.  No host synchronisation."""
+        p = np.ascontiguousarray(np.atleast_1d(np.asarray(params, dtype=np.float64)))
+        if p.size < 2:
+            p = np.concatenate([p, np.zeros(2 - p.size)])
+        check(self._lib.bohip_gp_score_sharded_dev(self._h, _lib.ACQ[acq], _ptr(p), C.c_void_p(d_xs_ptr), int(R_local),
+                                                   int(col_offset), int(R_total),
+                                                   C.c_void_p(d_score_ptr) if d_score_ptr else None, C.c_void_p(d_best_ptr)))
+
+    def thompson_sharded(self, xs, S, seed, col_offset, R_total):
+        xs = _cols(xs, self.dim)
+        out = (Best * S)()
+        check(self._lib.bohip_gp_thompson_sharded(self._h, _ptr(xs), xs.shape[1], S, seed, int(col_offset), int(R_total), out))
+        return np.array([b.val for b in out]), np.array([b.idx for b in out], dtype=np.int64)
+
+    def synchronize(self):
+        check(self._lib.bohip_gp_synchronize(self._h))
 
     def thompson(self, xs, S, seed=0, j0=0):
         xs = _cols(xs, self.dim)

@@ -5,12 +5,16 @@ per GPU; at --gpus G the candidate set is R*G sharded over G ranks = configs[2] 
 
 One "step" = one pass of the hot path over one batch of candidates already resident in HBM:
 k_kstar (cross-covariances) -> k_trigemm_sq (V = L^-1 K*, sum v^2, mu) -> k_score (sigma^2, EI,
-block arg-max) -> k_argmax_final, then (G > 1) ONE RCCL all_gather of the 16-byte (value, index)
-record per rank and an identical local reduce; the 16-byte result is read by the host (G = 1: the kernel
-writes it into pinned host memory, read after the stream synchronisation).
+block arg-max) -> k_argmax_final, then (G > 1) ONE RCCL all-gather of the 16-byte (value, GLOBAL index)
+record per GPU and the same reduction kernel on every GPU -- both inside libbohip, on the handle's stream;
+the 16-byte result lands in pinned host memory and is read after the stream synchronisation.
 
 Launch:  python bench.py [--gpus N --steps K --warmup W]
+             N = 1: one handle.  N > 1 without a launcher: ONE process drives N devices through the
+             in-library multi-GPU entry points (bohip_mgp_*: ncclCommInitAll, worker thread per device).
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+             one process per GPU; rank 0 makes an ncclUniqueId, torch.distributed only carries it (and the
+             barrier / max-over-ranks of the clock); the exchange itself is bohip_gp_score_sharded_dev.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -96,6 +100,185 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
     }
 
 
+def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, extra=None):
+    ms_per_step = elapsed / args.steps * 1e3
+    R_total = R_PER_GPU * world
+    value = R_total * args.steps / elapsed
+    stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
+    tg_ms = stage_ms.get("trigemm_sq", float("nan"))
+    flops_per_launch = R_PER_GPU * (N_OBS * N_OBS + 2.0 * N_OBS)  # triangular contraction + mu row
+    achieved = flops_per_launch / (tg_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_trigemm_sq.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "acquisition-candidates/sec (N=3000,d=8)", "value": value, "unit": "candidates/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: N=3000 obs, d=8, SEArd, ExpectedImprovement, R=4096 "
+                               "restarts per GPU (LHS candidates resident in HBM)",
+                   "N": N_OBS, "d": DIM, "R_per_gpu": R_PER_GPU, "R_total": R_total, "acquisition": "EI",
+                   "parallelism": f"candidates sharded x{world}, one 16-byte RCCL all-gather + device-side reduce ({mode})"},
+        "roofline": {"bound": "mfma", "kernel": "k_trigemm_sq", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_source": "profiles/traffic_trigemm_sq.json (separate rocprofv3 --pmc passes of this command; "
+                                       "NOT measured in this run)",
+                     "avg_launch_ms": tg_ms, "flops_per_launch": flops_per_launch},
+        "stage_ms": {**{k: v for k, v in info_ms.items() if k != "trigemm_sq"}, **stage_ms},
+        "model_update_ms": fit_ms,
+        "cholesky": {"N": N_OBS, "gflops": (N_OBS ** 3 / 3.0) / (fit_ms.get("cholesky", float("nan")) * 1e-3) / 1e9},
+        "best": {"value": val, "index": idx},
+    }
+    if extra:
+        out.update(extra)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(X, y, Xs_all, tau)
+    print(json.dumps(out))
+
+
+def timed(args, step, sync, barrier=None):
+    """W untimed steps were done by the caller; time exactly K steps between barrier + synchronise on both sides."""
+    if barrier:
+        barrier()
+    sync()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    sync()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0, last
+
+
+def main_single_process(args):
+    """--gpus N inside ONE process (N = 1: one handle; N > 1: the in-library multi-GPU path, bohip_mgp_*)."""
+    import torch
+
+    import bohip
+    from bohip import _lib
+
+    lib = _lib.load()
+    G = args.gpus
+    ndev = lib.bohip_device_count()
+    spd = 1
+    devices = list(range(G))
+    if G > ndev:
+        if os.environ.get("BOHIP_LOGICAL_SHARDS") == "1":    # TEST mode: G logical shards on the devices that exist
+            devices, spd = [0], G
+        else:
+            raise SystemExit(f"--gpus {G} but only {ndev} device(s) visible")
+    X, y = synth(0)
+    tau = float(y.max())
+    R_total = R_PER_GPU * G
+    Xs_all = lhs(R_total, seed=1)
+    ll = np.full(DIM, np.log(0.5))
+    params = (C.c_double * 2)(tau, 0.0)
+    if G == 1:
+        model = bohip.ElasticGPE(DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0, capacity=N_OBS)
+        model.enable_timing(True)
+        model.append_(X.T, y)
+        model.fit_()
+        fit_ms = dict(model.timing())
+        dev = torch.device("cuda", 0)
+        dXs = torch.from_numpy(np.ascontiguousarray(Xs_all)).to(dev)  # [R][d] = d x R column-major, resident in HBM
+        # the 16-byte result record is written by the arg-max kernel straight into pinned host memory and read after
+        # the stream synchronisation (no copy command)
+        h_best = torch.tensor([0, -1], dtype=torch.int64).pin_memory()
+        h_best_np = h_best.numpy()
+        _lib.check(lib.bohip_gp_set_stream(model._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+        def step():
+            _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()), R_PER_GPU, None,
+                                              C.c_void_p(h_best.data_ptr())))
+            _lib.check(lib.bohip_gp_synchronize(model._h))
+            i = int(h_best_np[1])
+            return (float(h_best_np[:1].view(np.float64)[0]), i) if i >= 0 else (-np.inf, -1)
+
+        info_ms = {}
+        for _ in range(args.warmup):
+            step()
+            info_ms = dict(model.timing())      # every stage bracketed by events: for the report only
+        # timed region: only the dominant kernel carries events (2 records per step; bracketing all stages costs ~27 us)
+        model.enable_timing(2)
+        step()
+        stage_sum = {}
+
+        def tstep():
+            r = step()
+            for name, ms in model.timing():
+                stage_sum[name] = stage_sum.get(name, 0.0) + ms
+            return r
+
+        elapsed, (val, idx) = timed(args, tstep, torch.cuda.synchronize)
+        # the same call through the host-pointer entry point: H2D of the 256 KB of candidates inside the call
+        model.enable_timing(0)
+        Xs_host = np.ascontiguousarray(Xs_all)
+        bestrec = _lib.Best()
+        xp = Xs_host.ctypes.data_as(C.POINTER(C.c_double))
+
+        def hstep():
+            _lib.check(lib.bohip_gp_score(model._h, _lib.ACQ["EI"], params, xp, R_PER_GPU, None, C.byref(bestrec)))
+            return bestrec.val, bestrec.idx
+
+        for _ in range(3):
+            hstep()
+        el_h, (hv, hi) = timed(args, hstep, torch.cuda.synchronize)
+        extra = {"value_host_buffers": R_total * args.steps / el_h, "ms_per_step_host_buffers": el_h / args.steps * 1e3,
+                 "host_buffers_note": "same workload through bohip_gp_score: host X* in (pageable, 256 KB H2D inside the "
+                                      "call), 16-byte record out; `value` is the HBM-resident rate",
+                 "host_buffers_same_winner": bool(hv == val and hi == idx)}
+        report(args, 1, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, "one handle", extra)
+        return
+    # ---- N > 1 in one process: bohip_mgp_* -------------------------------------------------------------------
+    model = bohip.MultiGPE(DIM, devices=devices, shards_per_device=spd, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0),
+                           logNoise=-2.0, capacity=N_OBS)
+    g0 = lib.bohip_mgp_handle(model._h, 0)
+    lib.bohip_gp_enable_timing(g0, 1)
+    model.append_(X.T, y)
+    model.fit_()
+    names = (C.c_char_p * 64)()
+    msb = (C.c_double * 64)()
+
+    def timing0(sync=False):
+        if sync:
+            lib.bohip_gp_synchronize(g0)        # collects the event times of device 0
+        n = lib.bohip_gp_get_timing(g0, names, msb, 64)
+        return [(names[i].decode(), msb[i]) for i in range(min(n, 64))]
+
+    fit_ms = dict(timing0())
+    model.set_candidates(Xs_all.T)
+    best = _lib.Best()
+
+    def step():
+        _lib.check(lib.bohip_mgp_score_resident(model._h, _lib.ACQ["EI"], params, C.byref(best)))
+        return best.val, best.idx
+
+    info_ms = {}
+    for _ in range(args.warmup):
+        step()
+        info_ms = {}
+        for k, v in timing0(True):              # spd > 1: several shards on device 0 -> sum per stage
+            info_ms[k] = info_ms.get(k, 0.0) + v
+    lib.bohip_gp_enable_timing(g0, 2)
+    step()
+    stage_sum = {}
+
+    def tstep():
+        r = step()
+        for name, ms in timing0(True):
+            stage_sum[name] = stage_sum.get(name, 0.0) + ms / spd   # per shard launch
+        return r
+
+    elapsed, (val, idx) = timed(args, tstep, torch.cuda.synchronize)
+    mode = f"one process, {len(devices)} device(s) x {spd} shard(s), in-library RCCL {model.info(_lib.MGP_INFO_RCCL_VERSION)}"
+    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,33 +288,35 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus and os.environ.get("BOHIP_SHARE_GPU") != "1":
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libbohip has no CPU path")
-    # BOHIP_SHARE_GPU=1 + BOHIP_DIST_BACKEND=gloo: a TEST mode that runs all ranks on GPU 0 and exchanges the records
-    # through gloo, so the sharded N > 1 code path can be checked end-to-end on a single-GPU box.
+    if "WORLD_SIZE" not in os.environ and os.environ.get("BOHIP_FORCE_DIST") != "1":
+        return main_single_process(args)
+
+    # ---- one process per GPU (torch.distributed.run) ----------------------------------------------------------
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ["RANK"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # BOHIP_SHARE_GPU=1 + BOHIP_DIST_BACKEND=gloo: a TEST mode that runs all ranks on GPU 0 (RCCL cannot place two ranks
+    # on one device, so the records travel through gloo and dist.py's host reduce instead of the in-library exchange)
     share_gpu = os.environ.get("BOHIP_SHARE_GPU") == "1"
     backend = os.environ.get("BOHIP_DIST_BACKEND", "nccl")
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or os.environ.get("BOHIP_FORCE_DIST") == "1"   # the latter: exercise the RCCL path on 1 GPU
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
 
     import bohip
     from bohip import _lib
@@ -144,104 +329,67 @@ def main():
     Xs_all = lhs(R_total, seed=1)
     lo = rank * R_PER_GPU
     Xs_local = Xs_all[lo:lo + R_PER_GPU]
-
     ll = np.full(DIM, np.log(0.5))
     model = bohip.ElasticGPE(DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0,
                              capacity=N_OBS, device=local_rank)
     model.enable_timing(True)
-    model.set_batch_hint(R_total)   # every shard takes the summation schedule of the whole candidate set (bit-identical to G = 1)
     model.append_(X.T, y)  # every rank factors the same model redundantly (192 KB broadcast beats 36 MB of L)
-    fit_ms = dict(model.timing())
     model.fit_()
     fit_ms = dict(model.timing())
+    in_library = backend == "nccl" and not share_gpu
+    if in_library:
+        ids = [bohip.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)          # torch.distributed is only the courier of the 128 bytes
+        model.comm_init(ids[0], rank, world)
+    else:
+        model.set_batch_hint(R_total)
 
     dev = torch.device("cuda", local_rank)
     dXs = torch.from_numpy(np.ascontiguousarray(Xs_local)).to(dev)  # [R][d] = d x R column-major
-    # (f64 value bits, i64 local index) written by the kernel + this rank's global column offset: the unit of the
-    # single all_gather; the offset rides along so the exchange needs no other device work
     d_best = torch.tensor([0, -1, lo], dtype=torch.int64, device=dev)
-    # one GPU: the 16-byte result record is written by the arg-max kernel straight into pinned host memory and read
-    # after the stream synchronisation (no copy command); G > 1: it stays on the device for the RCCL all_gather
-    h_best = torch.tensor([0, -1, lo], dtype=torch.int64).pin_memory()
+    h_best = torch.tensor([0, -1], dtype=torch.int64).pin_memory()
     h_best_np = h_best.numpy()
     stream = torch.cuda.current_stream()
     _lib.check(lib.bohip_gp_set_stream(model._h, C.c_void_p(stream.cuda_stream)))
     params = (C.c_double * 2)(tau, 0.0)
 
     def step():
-        if not use_dist:
-            _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()),
-                                              R_PER_GPU, None, C.c_void_p(h_best.data_ptr())))
+        if in_library:
+            model.score_sharded_dev("EI", [tau], dXs.data_ptr(), R_PER_GPU, lo, R_total, h_best.data_ptr())
             _lib.check(lib.bohip_gp_synchronize(model._h))
             i = int(h_best_np[1])
-            return (float(h_best_np[:1].view(np.float64)[0]), i + lo) if i >= 0 else (-np.inf, -1)
+            return (float(h_best_np[:1].view(np.float64)[0]), i) if i >= 0 else (-np.inf, -1)
         _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()),
                                           R_PER_GPU, None, C.c_void_p(d_best.data_ptr())))
-        val, idx = allgather_best(d_best, lo, world, force_collective=use_dist)  # RCCL all_gather of 16 B/rank + local reduce
+        val, idx = allgather_best(d_best, lo, world, force_collective=True)
         _lib.check(lib.bohip_gp_synchronize(model._h))
         return val, idx
 
     info_ms = {}
     for _ in range(args.warmup):
         step()
-        info_ms = dict(model.timing())          # every stage bracketed by events: for the report only
-    # timed region: only the dominant kernel carries events (2 records per step; bracketing all three stages costs
-    # ~27 us per step = 3.7 %)
+        info_ms = dict(model.timing())
     model.enable_timing(2)
     step()
     stage_sum = {}
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        val, idx = step()
+
+    def tstep():
+        r = step()
         for name, ms in model.timing():
             stage_sum[name] = stage_sum.get(name, 0.0) + ms
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return r
 
+    elapsed, (val, idx) = timed(args, tstep, torch.cuda.synchronize, dist.barrier)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = R_total * args.steps / elapsed
-        stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
-        tg_ms = stage_ms.get("trigemm_sq", float("nan"))
-        flops_per_launch = R_PER_GPU * (N_OBS * N_OBS + 2.0 * N_OBS)  # triangular contraction + mu row
-        achieved = flops_per_launch / (tg_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_trigemm_sq.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "acquisition-candidates/sec (N=3000,d=8)", "value": value, "unit": "candidates/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: N=3000 obs, d=8, SEArd, ExpectedImprovement, R=4096 "
-                                   "restarts per GPU (LHS candidates resident in HBM)",
-                       "N": N_OBS, "d": DIM, "R_per_gpu": R_PER_GPU, "R_total": R_total, "acquisition": "EI",
-                       "parallelism": f"candidates sharded x{world}, one 16-byte all_gather"},
-            "roofline": {"bound": "mfma", "kernel": "k_trigemm_sq", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "avg_launch_ms": tg_ms, "flops_per_launch": flops_per_launch},
-            "stage_ms": {**{k: v for k, v in info_ms.items() if k != "trigemm_sq"}, **stage_ms},
-            "model_update_ms": fit_ms,
-            "cholesky": {"N": N_OBS, "gflops": (N_OBS ** 3 / 3.0) / (fit_ms.get("cholesky", float("nan")) * 1e-3) / 1e9},
-            "best": {"value": val, "index": idx},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, y, Xs_all, tau)
-        print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+        mode = ("one process per GPU, in-library RCCL (bohip_gp_score_sharded_dev)" if in_library
+                else f"one process per GPU, TEST exchange through torch.distributed/{backend}")
+        report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode)
+    if in_library:
+        model.comm_destroy()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@
  *     *_dev entry point, which enqueues on the handle's stream and returns.
  *   - Return value: 0 = OK, negative = error (see BOHIP_E_*); bohip_last_error() gives text.
  *     Nothing throws or aborts across the ABI.  A handle is not re-entrant; distinct
- *     handles are independent.  One handle = one device.
+ *     handles are independent.  One handle = one device; bohip_mgp (below) spans a device list.
  */
 #ifndef BOHIP_H
 #define BOHIP_H
@@ -35,6 +35,7 @@ typedef struct bohip_gp bohip_gp;
 #define BOHIP_E_NODEVICE (-4) /* no gfx950 device visible -- there is NO CPU fallback             */
 #define BOHIP_E_STATE (-5)    /* call not valid in this state (e.g. predict with 0 observations) */
 #define BOHIP_E_UNSUPPORTED (-6)
+#define BOHIP_E_COMM (-7)     /* RCCL error, or the devices disagree after the exchange (multi-GPU entry points) */
 
 /* kernel_id: GaussianProcesses.jl kernels the reference's tests/defaults construct
  * (README.md:24, test/acquisition.jl:2, src/BayesianOptimization.jl:259-262) */
@@ -125,6 +126,9 @@ int bohip_gp_acquire_max(bohip_gp *gp, int acq_id, const double *acq_params, con
                          const double *upperbounds, const double *starts, int64_t R, int64_t maxeval, double ftol_rel,
                          double xtol_abs, double *x_out, double *f_out, bohip_best *best, double *best_x,
                          int64_t *evals_out);
+/* NLopt's maxtime option (forwarded by the reference at src/acquisition.jl:24-27): wall-clock budget in seconds of ONE
+ * bohip_gp_acquire_max call, checked once per ascent iteration; 0 (default) = unlimited.                          */
+int bohip_gp_set_maxtime(bohip_gp *gp, double seconds);
 
 /* ---- ThompsonSamplingSimple (reference src/acquisitionfunctions.jl:107-108, myrand
  * src/models/gp.jl:6-7) in its batched form: S independent draws mu_j + sigma_j z_sj over the R
@@ -166,6 +170,65 @@ int bohip_gp_set_batch_hint(bohip_gp *gp, int64_t total_candidates);
  * event records per call instead of six (the records themselves cost ~4 us each on the stream).   */
 int bohip_gp_enable_timing(bohip_gp *gp, int on);
 int bohip_gp_get_timing(bohip_gp *gp, const char **names, double *ms, int cap);
+
+/* ======================================================================================================
+ * Multi-GPU.  The reference runs its restarts one after the other
+ * (src/acquisition.jl:58-66); here the candidate columns are cut into contiguous shards, every GPU scores its shard
+ * against its own replica of the model, and the arg-max over the restarts (strict '>', first maximum wins, :62) is
+ * ONE RCCL all-gather of the 16-byte (value, GLOBAL column) records followed by the same (value desc, index asc)
+ * reduction on every GPU.  RCCL has no MAXLOC, hence all-gather + local reduce; 128 B at 8 GPUs.
+ * The winner is bit-identical to the one-GPU result of bohip_gp_score on the whole set.
+ * ---- one process, a device list ------------------------------------------------------------------------ */
+typedef struct bohip_mgp bohip_mgp;
+/* devices: n_devices distinct HIP ordinals (ncclCommInitAll over them).  shards_per_device >= 1 logical shards per
+ * device (1 in production; > 1 exercises the G-shard partition and exchange on fewer GPUs).  Shard s of
+ * G = n_devices * shards_per_device holds columns [s*floor(R/G) + min(s, R%G), ...) and lives on device s / spd.   */
+int bohip_mgp_create(int64_t d, int64_t capacity, int kernel_id, const int *devices, int n_devices,
+                     int shards_per_device, bohip_mgp **out);
+void bohip_mgp_destroy(bohip_mgp *mgp);
+/* replicated model: same meaning as the bohip_gp_* calls, applied to every device (each factors redundantly) */
+int bohip_mgp_set_hyper(bohip_mgp *mgp, const double *loglen, double logsig, double lognoise, double mean_const);
+int bohip_mgp_append(bohip_mgp *mgp, const double *X, const double *y, int64_t p);
+int bohip_mgp_refit(bohip_mgp *mgp);
+/* acquisitionfunction(a, model)(X) + the arg-max of acquire_max over ALL devices (src/acquisitionfunctions.jl:4-9,
+ * src/acquisition.jl:54-68).  Xs: d x R host, score: R host (nullable), best: global record.                      */
+int bohip_mgp_score(bohip_mgp *mgp, int acq_id, const double *acq_params, const double *Xs, int64_t R, double *score,
+                    bohip_best *best);
+/* the same with the candidate shards already resident in each device's HBM */
+int bohip_mgp_set_candidates(bohip_mgp *mgp, const double *Xs, int64_t R);
+int bohip_mgp_score_resident(bohip_mgp *mgp, int acq_id, const double *acq_params, bohip_best *best);
+/* ThompsonSamplingSimple batched (src/acquisitionfunctions.jl:107-108): S draws over R candidates, one all-gather of
+ * S records per shard; best: S global records.                                                                    */
+int bohip_mgp_thompson(bohip_mgp *mgp, const double *Xs, int64_t R, int64_t S, uint64_t seed, bohip_best *best);
+/* acquire_max with the start columns sharded over the devices (src/acquisition.jl:48-68); arguments as
+ * bohip_gp_acquire_max, indices global.                                                                           */
+int bohip_mgp_acquire_max(bohip_mgp *mgp, int acq_id, const double *acq_params, const double *lowerbounds,
+                          const double *upperbounds, const double *starts, int64_t R, int64_t maxeval, double ftol_rel,
+                          double xtol_abs, double *x_out, double *f_out, bohip_best *best, double *best_x,
+                          int64_t *evals_out);
+bohip_gp *bohip_mgp_handle(bohip_mgp *mgp, int i); /* replica on the i-th listed device (borrowed, for dims/maxy/get_xy/mll...) */
+#define BOHIP_MGP_INFO_DEVICES 0
+#define BOHIP_MGP_INFO_SHARDS 1
+#define BOHIP_MGP_INFO_EXCHANGES 2    /* RCCL all-gathers performed so far */
+#define BOHIP_MGP_INFO_RCCL_VERSION 3
+int bohip_mgp_info(const bohip_mgp *mgp, int what, int64_t *value);
+
+/* ---- one process per device (torch.distributed.run, Distributed.jl, MPI) ----------------------------------
+ * Rank 0 calls bohip_comm_unique_id and ships the bytes to the other ranks with the transport it has; every rank
+ * attaches a communicator to its handle (ncclCommInitRank on the handle's device: collective, blocks until all
+ * ranks arrive).                                                                                              */
+#define BOHIP_UNIQUE_ID_BYTES 128
+int bohip_comm_unique_id(void *id, int64_t nbytes);
+int bohip_gp_comm_init(bohip_gp *gp, const void *id, int64_t nbytes, int rank, int nranks);
+int bohip_gp_comm_destroy(bohip_gp *gp);
+/* Score this rank's shard (dXs: d x R_local in HBM, columns [col_offset, col_offset + R_local) of R_total), exchange
+ * and reduce on the handle's stream: `best` (device or pinned-host pointer) receives the GLOBAL winner, identical on
+ * every rank.  Enqueues only (a *_dev entry point); d_score nullable.                                           */
+int bohip_gp_score_sharded_dev(bohip_gp *gp, int acq_id, const double *acq_params, const double *dXs, int64_t R_local,
+                               int64_t col_offset, int64_t R_total, double *d_score, bohip_best *best);
+/* Thompson form: Xs host (d x R_local), best host (S global records, identical on every rank).  Blocking.       */
+int bohip_gp_thompson_sharded(bohip_gp *gp, const double *Xs, int64_t R_local, int64_t S, uint64_t seed,
+                              int64_t col_offset, int64_t R_total, bohip_best *best);
 
 const char *bohip_last_error(void); /* thread-local */
 const char *bohip_version(void);

@@ -214,3 +214,68 @@ def test_mutual_information_gamma_update(orc):                          # src/ac
     assert mi.gamma_hat == pytest.approx(float(s2_last[0]), rel=1e-12)  # gamma_hat += sigma^2(x_last)
     bohip.setparams_(mi, m)
     assert mi.gamma_hat == pytest.approx(2 * float(s2_last[0]), rel=1e-12)
+
+
+# ---- the loop calls setparams! exactly once per iteration (src/BayesianOptimization.jl:184-185) ----------------------
+class GrowingOracleModel(OracleModel):
+    """OracleModel + update!: enough of the model interface for boptimize_ to run on the CPU oracle."""
+
+    def __init__(self, orc, d, ll):
+        self.orc, self.X, self._y, self.ll, self.lsig, self.beta = orc, np.zeros((0, d)), np.zeros(0), np.asarray(ll, float), 0.0, 0.0
+        self.dim, self.calls = d, []
+
+    def append_(self, x, y):
+        x = np.asarray(x, float).reshape(self.dim, -1)
+        self.X = np.concatenate([self.X, x.T])
+        self._y = np.concatenate([self._y, np.atleast_1d(y)])
+        self.L, self.al = self.orc.fit(self.X, self._y, self.ll, self.lsig, -2.0, self.beta)
+        return self
+
+
+def test_loop_calls_setparams_once_per_iteration(orc):
+    class CountingMI(bohip.MutualInformation):
+        calls = 0
+
+        def _setparams(self, model):
+            CountingMI.calls += 1
+            return super()._setparams(model)
+
+    m = GrowingOracleModel(orc, 2, [-0.3, -0.3])
+    acq = CountingMI()
+    k = 3
+    o = bohip.BOpt(lambda x: -float(((x - 0.2) ** 2).sum()), m, acq, bohip.NoModelOptimizer(), [-1.0, -1.0], [1.0, 1.0],
+                   maxiterations=4 + k, initializer_iterations=4, verbosity=bohip.Silent,
+                   acquisitionoptions=dict(method="LD_LBFGS", restarts=3, maxeval=20), rng=np.random.default_rng(0))
+    assert CountingMI.calls == 1                                       # ctor: nlopt_setup (src/acquisition.jl:30)
+    g0 = acq.gamma_hat
+    assert g0 == 0.0                                                   # empty model: gamma_hat = 0 (:133)
+    # replay what the reference's flow accumulates: gamma_hat += sigma^2(x_last) ONCE per iteration, before the search
+    expected = []
+    orig = bohip.MutualInformation._setparams
+
+    def spy(self, model):
+        r = orig(self, model)
+        expected.append(self.gamma_hat)
+        return r
+
+    bohip.MutualInformation._setparams = spy
+    try:
+        bohip.boptimize_(o)
+    finally:
+        bohip.MutualInformation._setparams = orig
+    assert CountingMI.calls == 1 + k                                   # one per loop iteration, none inside acquire_max
+    assert len(expected) == k and acq.gamma_hat == expected[-1]
+    inc = np.diff([g0] + expected)
+    assert np.all(inc >= 0) and acq.gamma_hat == pytest.approx(float(np.sum(inc)), rel=1e-12)
+
+
+def test_acquisition_options_are_checked_like_nlopt(orc):
+    m = OracleModel(orc, np.array([[1.0]]), np.array([2.0]), [1.0])
+    with pytest.raises(ValueError):
+        bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxevil=10))
+    with pytest.warns(UserWarning):
+        bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=10, ftol_abs=1e-3))
+    # maxeval is honoured as given (no hidden cap): 300 evaluations allowed, the search stops on its own tolerance first
+    m.calls.clear()
+    bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=300))
+    assert 2 <= len(m.calls) <= 300

@@ -1,0 +1,169 @@
+"""GPU tests of the multi-GPU entry points of the C ABI (include/bohip.h: bohip_mgp_*, bohip_gp_comm_*,
+bohip_gp_*_sharded).  A gpurun box has ONE MI355X, so the G-shard partition and the RCCL exchange are exercised with a
+G = 1 communicator and G logical shards on that device (SURVEY.md 8e caveat): the records still travel through
+ncclAllGather and k_reduce_records, and every result must equal the one-handle result bit for bit."""
+import ctypes as C
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, synth
+from test_parity_gpu import bohip, make_model  # noqa: F401  (fixture + helper)
+
+pytestmark = pytest.mark.gpu
+
+
+def make_multi(bohip, X, y, ll, spd, lsig=0.0, lnoise=-2.0, beta=0.0, devices=(0,)):
+    m = bohip.MultiGPE(X.shape[1], devices=devices, shards_per_device=spd, mean=bohip.MeanConst(beta),
+                       kernel=bohip.SEArd(ll, lsig), logNoise=lnoise, capacity=len(y))
+    m.append_(X.T, y)
+    return m
+
+
+@pytest.mark.parametrize("N,d,R,spd", [(300, 3, 1000, 8), (900, 5, 4099, 8), (257, 2, 5, 8), (500, 4, 64, 3), (1500, 6, 700, 4)])
+def test_sharded_score_is_bit_identical_to_one_handle(bohip, N, d, R, spd):
+    from bohip import _lib
+
+    X, y, Xs = synth(N, d, R, seed=N + R)
+    ll = np.linspace(-0.8, -0.3, d)
+    one = make_model(bohip, X, y, ll, 0.1, -2.0, 0.05)
+    mg = make_multi(bohip, X, y, ll, spd, 0.1, -2.0, 0.05)
+    assert mg.n_shards == spd and mg.info(_lib.MGP_INFO_RCCL_VERSION) > 20000
+    np.testing.assert_array_equal(mg.replica_factor(0), one.factor())
+    tau = float(y.max())
+    for acq, p in [("EI", [tau]), ("UCB", [2.0]), ("MaxMean", [])]:
+        sc1, bv1, bi1 = one.score(acq, p, Xs.T)
+        n0 = mg.info(_lib.MGP_INFO_EXCHANGES)
+        scg, bvg, big = mg.score(acq, p, Xs.T)
+        assert mg.info(_lib.MGP_INFO_EXCHANGES) == n0 + 1               # exactly ONE all-gather per call
+        np.testing.assert_array_equal(scg, sc1)                         # R < G, R % G != 0 included
+        assert (bvg, big) == (bv1, bi1)
+    # resident candidates: same winner, no host buffers in the call
+    mg.set_candidates(Xs.T)
+    assert mg.score_resident("EI", [tau]) == one.score("EI", [tau], Xs.T)[1:]
+
+
+def test_sharded_ties_and_nan_follow_the_reference_rule(bohip):
+    """first maximum wins (src/acquisition.jl:62) across shard boundaries; NaN / -Inf records never win"""
+    X, y, _ = synth(64, 2, 1, seed=5)
+    ll = np.array([-0.5, -0.5])
+    one = make_model(bohip, X, y, ll, 0.0, -2.0, 0.0)
+    mg = make_multi(bohip, X, y, ll, 8)
+    base = np.random.default_rng(0).random((16, 2))
+    Xs = np.concatenate([base] * 8)                                     # every shard holds the same 16 candidates
+    sc, bv, bi = mg.score("UCB", [1.5], Xs.T)
+    assert bi == int(np.argmax(sc)) < 16 and (bv, bi) == one.score("UCB", [1.5], Xs.T)[1:]
+    sc, bv, bi = mg.score("EI", [float("nan")], Xs.T)                  # every score NaN -> nothing beats -Inf
+    assert np.all(np.isnan(sc)) and bv == -math.inf and bi == -1
+
+
+def test_sharded_thompson_matches_one_handle(bohip):
+    X, y, Xs = synth(400, 4, 3001, seed=12)
+    ll = np.full(4, -0.5)
+    one = make_model(bohip, X, y, ll, 0.0, -2.0, 0.0)
+    mg = make_multi(bohip, X, y, ll, 8)
+    bv1, bi1 = one.thompson(Xs.T, 64, seed=9)
+    bvg, big = mg.thompson(Xs.T, 64, seed=9)
+    np.testing.assert_array_equal(big, bi1)
+    np.testing.assert_array_equal(bvg, bv1)
+
+
+def test_sharded_acquire_max_matches_one_handle(bohip):
+    X, y, _ = synth(300, 3, 1, seed=21)
+    ll = np.full(3, -0.6)
+    one = make_model(bohip, X, y, ll, 0.0, -2.0, 0.0)
+    mg = make_multi(bohip, X, y, ll, 4)
+    starts = np.random.default_rng(3).random((3, 24))
+    lb, ub = np.zeros(3), np.ones(3)
+    f1, X1, bf1, bi1, bx1, _ = one.ascend("EI", [float(y.max())], lb, ub, starts, maxeval=400)
+    fg, Xg, bfg, big, bxg, _ = mg.ascend("EI", [float(y.max())], lb, ub, starts, maxeval=400)
+    np.testing.assert_allclose(fg, f1, rtol=1e-9, atol=1e-14)           # every start converges on its own: same optimum
+    assert big == bi1 and bfg == pytest.approx(bf1, rel=1e-9)
+    np.testing.assert_allclose(bxg, bx1, atol=1e-6)
+    np.testing.assert_array_equal(bxg, Xg[:, big])
+
+
+def test_communicator_on_a_handle_world_size_one(bohip):
+    """one-process-per-GPU form with a 1-rank communicator: ncclCommInitRank, score_sharded_dev into pinned host memory"""
+    import torch
+
+    X, y, Xs = synth(700, 5, 2048, seed=31)
+    ll = np.full(5, -0.5)
+    m = make_model(bohip, X, y, ll, 0.0, -2.0, 0.0)
+    tau = float(y.max())
+    sc, bv, bi = m.score("EI", [tau], Xs.T)
+    m.comm_init(bohip.comm_unique_id(), 0, 1)
+    with pytest.raises(bohip.BohipError):
+        m.comm_init(bohip.comm_unique_id(), 0, 1)                       # one communicator per handle
+    dXs = torch.from_numpy(np.ascontiguousarray(Xs)).to("cuda:0")
+    h_best = torch.zeros(2, dtype=torch.int64).pin_memory()
+    torch.cuda.synchronize()
+    off = 5000                                                          # this "rank" holds columns [5000, 7048) of 10000
+    m.score_sharded_dev("EI", [tau], dXs.data_ptr(), 2048, off, 10000, h_best.data_ptr())
+    m.synchronize()
+    hb = h_best.numpy()
+    assert float(hb[:1].view(np.float64)[0]) == bv and int(hb[1]) == bi + off
+    bvt, bit = m.thompson_sharded(Xs.T, 32, 4, off, 10000)
+    bv1, bi1 = m.thompson(Xs.T, 32, seed=4, j0=off)
+    np.testing.assert_array_equal(bit, bi1 + off)
+    np.testing.assert_array_equal(bvt, bv1)
+    m.comm_destroy()
+    with pytest.raises(bohip.BohipError):
+        m.score_sharded_dev("EI", [tau], dXs.data_ptr(), 2048, 0, 2048, h_best.data_ptr())
+
+
+def test_mgp_error_codes(bohip):
+    from bohip import _lib
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.bohip_mgp_create(2, 10, 0, devs, 2, 1, C.byref(h)) == _lib.E_ARG        # duplicate ordinal
+    assert b"twice" in lib.bohip_last_error()
+    assert lib.bohip_mgp_create(2, 10, 0, devs, 0, 1, C.byref(h)) == _lib.E_ARG
+    assert lib.bohip_mgp_create(2, 10, 0, devs, 1, 0, C.byref(h)) == _lib.E_ARG
+    bad = (C.c_int * 1)(63)
+    assert lib.bohip_mgp_create(2, 10, 0, bad, 1, 1, C.byref(h)) == _lib.E_ARG         # ordinal out of range
+    mg = bohip.MultiGPE(2, devices=[0], shards_per_device=2)
+    with pytest.raises(bohip.BohipError) as e:
+        mg.score("EI", [0.0], np.zeros((2, 4)))                                        # no observations yet
+    assert e.value.code == _lib.E_STATE
+
+
+def _run_bench(cmd, env=None):
+    out = subprocess.run(cmd, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_launches_the_way_the_driver_does(bohip):
+    """`python bench.py --gpus N` must run by itself (N = 1: one handle; N > 1: in-library multi-GPU path -- here with
+    logical shards, the box has one GPU), and under torch.distributed.run the exchange is the in-library RCCL one."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    one = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                      "--no-cpu-baseline"])
+    assert one["n_gpus"] == 1 and one["value_host_buffers"] > 0 and one["host_buffers_same_winner"] is True
+    assert one["value_host_buffers"] < one["value"]
+    two = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                      "--no-cpu-baseline"], env={"BOHIP_LOGICAL_SHARDS": "1"})
+    assert two["n_gpus"] == 2 and two["config"]["R_total"] == 8192 and "in-library RCCL" in two["config"]["parallelism"]
+    assert 0 < two["roofline"]["frac"] < 1
+    tr = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+                     "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+                     "--warmup", "1", "--no-cpu-baseline"])
+    assert "bohip_gp_score_sharded_dev" in tr["config"]["parallelism"] and tr["best"] == one["best"]
+    X, y = bench.synth(0)
+    ll = np.full(bench.DIM, np.log(0.5))
+    m = bohip.ElasticGPE(bench.DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0, capacity=bench.N_OBS)
+    m.append_(X.T, y)
+    _, bv, bi = m.score("EI", [float(y.max())], bench.lhs(8192, seed=1).T)
+    assert two["best"] == {"value": bv, "index": bi}
+    _, bv, bi = m.score("EI", [float(y.max())], bench.lhs(4096, seed=1).T)
+    assert one["best"] == {"value": bv, "index": bi}

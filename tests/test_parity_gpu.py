@@ -643,3 +643,46 @@ def test_device_ascent_respects_bounds_and_edge_cases(bohip):
     assert bi2 != 1 and np.isfinite(bf2)
     with pytest.raises(ValueError):
         m.ascend("UCB", [1.5], lb[:2], ub, starts)
+
+
+def test_device_ascent_against_scipy_lbfgsb_on_the_oracle(bohip, orc):
+    """Independent check of bohip_gp_acquire_max (role of NLopt :LD_LBFGS at reference src/acquisition.jl:59): SciPy's
+    L-BFGS-B (the Fortran code NLopt's LBFGS descends from) maximises the ORACLE's value + analytic gradient from the same
+    starts under the same box; nothing of the device is inside that loop.  Per start the device's end point must be a
+    KKT point of the oracle's objective with the oracle's value; over the starts the best maximum and maximiser agree."""
+    from scipy.optimize import minimize
+
+    X, y, _ = synth(220, 3, 1, seed=40)
+    ll = np.array([-0.9, -0.6, -0.75])
+    lsig, lnoise, beta = 0.1, -2.0, 0.2
+    L, alpha = orc.fit(X, y, ll, lsig, lnoise, beta)
+    m = make_model(bohip, X, y, ll, lsig, lnoise, beta)
+    R = 16
+    starts = np.random.default_rng(41).random((3, R))
+    lb, ub = np.zeros(3), np.ones(3)
+    tau = float(y.max())
+    for acq, p in [("EI", [tau]), ("UCB", [2.0]), ("MaxMean", [])]:
+        f, Xd, bf, bi, bx, ev = m.ascend(acq, p, lb, ub, starts, maxeval=2000, ftol_rel=1e-13, xtol_abs=1e-13)
+        assert 2 <= ev <= 2000 and np.all(Xd >= 0) and np.all(Xd <= 1)
+
+        def negfg(x):
+            sc, g = orc.score_grad(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], x[None, :].copy())
+            return -float(sc[0]), -g[0]
+
+        fs, xs = np.empty(R), np.empty((3, R))
+        for r in range(R):
+            res = minimize(negfg, starts[:, r], jac=True, method="L-BFGS-B", bounds=[(0.0, 1.0)] * 3,
+                           options=dict(maxiter=2000, maxfun=4000, ftol=1e-15, gtol=1e-12))
+            fs[r], xs[:, r] = -res.fun, res.x
+        sc_o, g_o = orc.score_grad(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], np.ascontiguousarray(Xd.T))
+        scale = max(np.abs(fs).max(), 1e-300)
+        np.testing.assert_allclose(f, sc_o, rtol=1e-6, atol=1e-9 * scale)           # the device reports the oracle's value there
+        pg = np.where(((Xd.T <= 0) & (g_o < 0)) | ((Xd.T >= 1) & (g_o > 0)), 0.0, g_o)   # projected gradient (maximisation)
+        g0 = orc.score_grad(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], np.ascontiguousarray(starts.T))[1]
+        assert np.abs(pg).max() <= 2e-4 * np.abs(g0).max(), (acq, np.abs(pg).max(), np.abs(g0).max())
+        assert np.all(f >= orc.score(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], np.ascontiguousarray(starts.T))[0] - 1e-12 * scale)
+        same = np.abs(f - fs) <= 1e-6 * scale                                        # same local maximum as SciPy from that start
+        assert same.mean() >= 0.75, (acq, same.mean())
+        np.testing.assert_allclose(Xd[:, same], xs[:, same], atol=2e-4)
+        assert bf == pytest.approx(fs.max(), rel=1e-6, abs=1e-9 * scale)            # acquire_max's answer: the best over the starts
+        np.testing.assert_allclose(bx, xs[:, int(np.argmax(fs))], atol=2e-4)
