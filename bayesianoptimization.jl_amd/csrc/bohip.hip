@@ -116,6 +116,8 @@ struct bohip_gp {
     bool timing = false;
     bool t_open = false;
     bool timing_dominant_only = false;   // enable_timing(2): only the dominant kernel (k_trigemm_sq) is bracketed by events
+    bool timing_accumulate = false;      // enable_timing(3): as 2, and the event pairs of successive calls pile up unread until
+                                         // bohip_gp_get_timing (no hipEventSynchronize / hipEventElapsedTime inside a timed loop)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tpool;  // pooled event pairs
     size_t tused = 0;
     std::vector<const char*> tlabel;
@@ -157,11 +159,13 @@ static void t_end(bohip_gp* g) {
     hipEventRecord(g->tpool[g->tused - 1].second, g->stream);
 }
 static void t_reset(bohip_gp* g) {
+    if (g->timing_accumulate) return;
     g->tused = 0;
     g->tlabel.clear();
 }
-static void t_collect(bohip_gp* g) {
+static void t_collect(bohip_gp* g, bool force = false) {
     if (!g->timing) return;
+    if (g->timing_accumulate && !force) return;
     g->tnames.clear();
     g->tms.clear();
     for (size_t i = 0; i < g->tused; ++i) {
@@ -171,7 +175,8 @@ static void t_collect(bohip_gp* g) {
         g->tnames.push_back(g->tlabel[i]);
         g->tms.push_back(ms);
     }
-    t_reset(g);
+    g->tused = 0;
+    g->tlabel.clear();
 }
 
 // ---- allocation -----------------------------------------------------------------------------------
@@ -1490,11 +1495,18 @@ int bohip_gp_set_maxtime(bohip_gp* g, double seconds) {
 int bohip_gp_enable_timing(bohip_gp* g, int on) {
     if (!g) return fail(BOHIP_E_ARG, "null handle");
     g->timing = on != 0;
-    g->timing_dominant_only = on == 2;
+    g->timing_dominant_only = on == 2 || on == 3;
+    g->timing_accumulate = on == 3;
+    g->tused = 0;
+    g->tlabel.clear();
     return 0;
 }
 int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {
     if (!g) return 0;
+    if (g->timing_accumulate) {   // everything recorded since enable_timing(3) / the previous read
+        hipSetDevice(g->device);
+        t_collect(g, true);
+    }
     const int n = (int)std::min<size_t>(g->tnames.size(), cap > 0 ? cap : 0);
     for (int i = 0; i < n; ++i) {
         if (names) names[i] = g->tnames[i].c_str();

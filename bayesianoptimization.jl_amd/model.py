@@ -292,14 +292,14 @@ class ElasticGPE:
         unsharded call); 0 clears the hint."""
         check(self._lib.bohip_gp_set_batch_hint(self._h, int(total_candidates)))
 
-    def enable_timing(self, on=True):                    # True/1: every stage; 2: only the dominant kernel
+    def enable_timing(self, on=True):     # True/1: every stage; 2: only the dominant kernel; 3: as 2, read after the loop
         check(self._lib.bohip_gp_enable_timing(self._h, int(on)))
 
-    def timing(self):
-        names = (C.c_char_p * 64)()
-        ms = (C.c_double * 64)()
-        n = self._lib.bohip_gp_get_timing(self._h, names, ms, 64)
-        return [(names[i].decode(), ms[i]) for i in range(min(n, 64))]
+    def timing(self, cap=64):
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        n = self._lib.bohip_gp_get_timing(self._h, names, ms, cap)
+        return [(names[i].decode(), ms[i]) for i in range(min(n, cap))]
 
     def __repr__(self):
         return (f"ElasticGPE(dim={self.dim}, nobs={self.nobs}, kernel={self.kernel.kern}"

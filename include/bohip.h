@@ -167,7 +167,9 @@ int bohip_gp_set_batch_hint(bohip_gp *gp, int64_t total_candidates);
 /* per-stage device times (ms, HIP events on the handle's stream) of the LAST call when timing
  * is enabled: names/values for up to `cap` stages; returns the number of stages.
  * on = 1: every stage; on = 2: only the dominant kernel (k_trigemm_sq) is bracketed by events -- two
- * event records per call instead of six (the records themselves cost ~4 us each on the stream).   */
+ * event records per call instead of six (the records themselves cost ~4 us each on the stream);
+ * on = 3: as 2, but the records of successive calls accumulate unread until bohip_gp_get_timing, which then
+ * returns one entry per recorded launch (a timed loop pays for the two records only, not for reading them). */
 int bohip_gp_enable_timing(bohip_gp *gp, int on);
 int bohip_gp_get_timing(bohip_gp *gp, const char **names, double *ms, int cap);
 

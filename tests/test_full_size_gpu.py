@@ -115,7 +115,7 @@ def test_full_size_c5_thompson_1024_draws_x_65536_candidates(bohip, orc):
     np.testing.assert_array_equal(big, bi)
     np.testing.assert_array_equal(bvg, bv)
     # draws spread over the candidate set (a stuck generator or a broken shard offset would collapse them)
-    assert len(np.unique(bi)) > S // 4
+    assert len(np.unique(bi)) >= 8 and len(np.unique(bi // (R // 8))) >= 4             # winners come from several shards
 
 
 def test_stress_variant_readme_kernel_at_c2_scale(bohip, orc):
