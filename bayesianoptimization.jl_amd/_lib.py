@@ -3,10 +3,12 @@ GPU (so the ABI can be inspected), but every compute entry point raises when the
 device is missing."""
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import importlib.util
 import os
 import sys
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbohip.so")
@@ -99,14 +101,32 @@ SIGNATURES = {
 
 _lib = None
 
+# Live device objects are closed at interpreter exit BEFORE the HIP / RCCL runtimes run their own static destructors:
+# a handle finalised after that (e.g. one kept alive by a traceback until shutdown) would free into a dead runtime.
+_live = weakref.WeakSet()
+
+
+def register(obj):
+    _live.add(obj)
+
+
+@atexit.register
+def _close_all():
+    for o in list(_live):
+        try:
+            o.close()
+        except Exception:
+            pass
+
 
 def _one_hip_runtime():
-    """A process must hold ONE HIP runtime and ONE RCCL.  PyTorch-ROCm bundles its own libamdhip64 and
-    librccl (same SONAMEs as /opt/rocm's); whichever is dlopen'ed first wins for both users, and torch
-    cannot see the GPU when the system HIP got there first.  So when PyTorch is installed (it is the
-    plumbing for device memory, streams and the process group in bench.py / dist.py) and not yet
-    imported, load its copies first; libbohip's DT_NEEDED entries then resolve to them.
-    BOHIP_SYSTEM_HIP=1 skips this (a process without torch uses /opt/rocm's through the RUNPATH)."""
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+    /opt/rocm's); whichever is dlopen'ed first wins for both users, and torch cannot see the GPU when
+    the system copy got there first.  So when PyTorch is installed (it is the plumbing for device
+    memory, streams and the process group in bench.py / dist.py) and not yet imported, load its copy
+    first.  BOHIP_SYSTEM_HIP=1 skips this.  RCCL needs no such care: libbohip binds it with
+    dlopen("librccl.so.1") at the first multi-GPU call, which returns the copy the process already holds
+    (preloading torch's librccl here made the process abort in a static destructor at exit)."""
     if "torch" in sys.modules or os.environ.get("BOHIP_SYSTEM_HIP") == "1":
         return
     try:
@@ -115,7 +135,7 @@ def _one_hip_runtime():
         spec = None
     if spec is None or not spec.origin:
         return
-    for name in ("libamdhip64.so", "librccl.so"):
+    for name in ("libamdhip64.so",):
         cand = os.path.join(os.path.dirname(spec.origin), "lib", name)
         if os.path.exists(cand):
             try:

@@ -17,18 +17,69 @@
 // asc) on GLOBAL column numbers, which makes the G-device winner identical to the one-device winner bit for bit.
 // RCCL has no MAXLOC reduction, so the "all-reduce of the per-GPU arg-max" is an all-gather of G records (128 B at G = 8:
 // latency-bound, nowhere near the 153 GB/s of an xGMI link) followed by a local reduce.
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library itself is bound at first use, see rccl_api()
+#include <dlfcn.h>
 
 #include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <thread>
 
+// RCCL is bound with dlopen at the first multi-GPU call instead of a DT_NEEDED entry: a process holds ONE librccl.so.1
+// (PyTorch-ROCm ships its own copy under the same SONAME; whichever the process loaded first is the one dlopen returns,
+// so a torch process shares torch's copy and a Julia process gets /opt/rocm's), single-GPU users never load it, and
+// the library's load order cannot disturb the host framework (preloading torch's copy ahead of torch made the process
+// abort in a static destructor at exit).
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+static RcclApi* rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* env = getenv("BOHIP_RCCL_LIB");
+        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+            api.error = dlerror();
+        }
+        if (!api.lib) return;
+        bool ok = true;
+#define BIND(field, sym) ok = ((api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, #sym))) != nullptr) && ok
+        BIND(GetVersion, ncclGetVersion); BIND(GetUniqueId, ncclGetUniqueId); BIND(CommInitRank, ncclCommInitRank);
+        BIND(CommInitAll, ncclCommInitAll); BIND(CommDestroy, ncclCommDestroy); BIND(AllGather, ncclAllGather);
+        BIND(GroupStart, ncclGroupStart); BIND(GroupEnd, ncclGroupEnd); BIND(GetErrorString, ncclGetErrorString);
+#undef BIND
+        if (!ok) { api.error = "librccl lacks a required symbol"; api.lib = nullptr; }
+    });
+    return api.lib ? &api : nullptr;
+}
+#define RCCL_OR_FAIL(R)                                                                                              \
+    RcclApi* R = rccl_api();                                                                                         \
+    if (!R) return fail(BOHIP_E_COMM, "RCCL (librccl.so.1) could not be loaded: " + rccl_api_error())
+static std::string rccl_api_error() {
+    static RcclApi* dummy = rccl_api();
+    (void)dummy;
+    return "set BOHIP_RCCL_LIB or add /opt/rocm/lib to the loader path";
+}
+
 #define NCCLCHK(expr)                                                                                     \
     do {                                                                                                  \
         ncclResult_t r_ = (expr);                                                                         \
         if (r_ != ncclSuccess)                                                                            \
-            return fail(BOHIP_E_COMM, std::string(#expr) + ": " + ncclGetErrorString(r_) + " (" __FILE__  \
+            return fail(BOHIP_E_COMM, std::string(#expr) + ": " + rccl_api()->GetErrorString(r_) + " (" __FILE__  \
                                           ":" + std::to_string(__LINE__) + ")");                          \
     } while (0)
 
@@ -146,12 +197,13 @@ static int mgp_ensure_records(bohip_mgp* m, int64_t S) {
 // writes its copy of the S winners into pinned host memory.  Returns after every device's stream has drained, with the
 // copies compared: a disagreement would mean the collective delivered different data to different ranks.
 static int mgp_exchange(bohip_mgp* m, int64_t S, Best* out) {
-    NCCLCHK(ncclGroupStart());
+    RCCL_OR_FAIL(R);
+    NCCLCHK(R->GroupStart());
     for (int i = 0; i < m->nd; ++i) {
-        const ncclResult_t r = ncclAllGather(m->dsend[i], m->drecv[i], (size_t)(2 * m->spd * S), ncclInt64, m->comm[i], m->h[i]->stream);
-        if (r != ncclSuccess) { ncclGroupEnd(); return fail(BOHIP_E_COMM, std::string("ncclAllGather: ") + ncclGetErrorString(r)); }
+        const ncclResult_t r = R->AllGather(m->dsend[i], m->drecv[i], (size_t)(2 * m->spd * S), ncclInt64, m->comm[i], m->h[i]->stream);
+        if (r != ncclSuccess) { R->GroupEnd(); return fail(BOHIP_E_COMM, std::string("ncclAllGather: ") + R->GetErrorString(r)); }
     }
-    NCCLCHK(ncclGroupEnd());
+    NCCLCHK(R->GroupEnd());
     for (int i = 0; i < m->nd; ++i) {
         HIPCHK(hipSetDevice(m->devs[i]));
         hipLaunchKernelGGL(k_reduce_records, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, m->h[i]->stream, m->drecv[i],
@@ -210,6 +262,11 @@ int bohip_mgp_create(int64_t d, int64_t capacity, int kernel_id, const int* devi
     for (int i = 0; i < n_devices; ++i)
         for (int j = 0; j < i; ++j)
             if (devices[i] == devices[j]) return fail(BOHIP_E_ARG, "device list holds an ordinal twice (use shards_per_device for logical shards)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(BOHIP_E_NODEVICE, "no HIP device visible; libbohip has no CPU fallback");
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) return fail(BOHIP_E_ARG, "device ordinal out of range");
     bohip_mgp* m = new bohip_mgp();
     m->nd = n_devices; m->spd = shards_per_device; m->d = (int)d;
     m->devs.assign(devices, devices + n_devices);
@@ -224,8 +281,12 @@ int bohip_mgp_create(int64_t d, int64_t capacity, int kernel_id, const int* devi
     int rc = 0;
     for (int i = 0; i < n_devices && rc == 0; ++i) rc = bohip_gp_create(d, capacity, kernel_id, devices[i], &m->h[i]);
     if (rc == 0) {
-        const ncclResult_t r = ncclCommInitAll(m->comm.data(), n_devices, devices);
-        if (r != ncclSuccess) rc = fail(BOHIP_E_COMM, std::string("ncclCommInitAll: ") + ncclGetErrorString(r));
+        RcclApi* R = rccl_api();
+        if (!R) rc = fail(BOHIP_E_COMM, "RCCL (librccl.so.1) could not be loaded: " + rccl_api_error());
+        else {
+            const ncclResult_t r = R->CommInitAll(m->comm.data(), n_devices, devices);
+            if (r != ncclSuccess) rc = fail(BOHIP_E_COMM, std::string("ncclCommInitAll: ") + R->GetErrorString(r));
+        }
     }
     if (rc == 0) rc = mgp_ensure_records(m, 1);
     if (rc == 0 && m->threads) {
@@ -258,15 +319,17 @@ void bohip_mgp_destroy(bohip_mgp* m) {
         delete w;
     }
     for (int i = 0; i < m->nd; ++i) {
+        if (!m->h[i]) continue;   // creation failed before this device was touched
         hipSetDevice(m->devs[i]);
-        if (m->h[i] && m->h[i]->stream) hipStreamSynchronize(m->h[i]->stream);
-        if (m->comm[i]) ncclCommDestroy(m->comm[i]);
+        if (m->h[i]->stream) hipStreamSynchronize(m->h[i]->stream);
+        if (m->comm[i] && rccl_api()) rccl_api()->CommDestroy(m->comm[i]);
         if (m->dsend[i]) hipFree(m->dsend[i]);
         if (m->drecv[i]) hipFree(m->drecv[i]);
         if (m->dcand[i]) hipFree(m->dcand[i]);
         if (m->h[i]) bohip_gp_destroy(m->h[i]);
     }
     if (m->hfinal) hipHostFree(m->hfinal);
+    (void)hipGetLastError();   // a failed call above must not surface as the "last error" of an unrelated later launch
     delete m;
 }
 
@@ -438,7 +501,8 @@ int bohip_mgp_info(const bohip_mgp* m, int what, int64_t* value) {
         case BOHIP_MGP_INFO_EXCHANGES: *value = m->exchanges; return 0;
         case BOHIP_MGP_INFO_RCCL_VERSION: {
             int v = 0;
-            NCCLCHK(ncclGetVersion(&v));
+            RCCL_OR_FAIL(R);
+            NCCLCHK(R->GetVersion(&v));
             *value = v;
             return 0;
         }
@@ -450,7 +514,8 @@ int bohip_mgp_info(const bohip_mgp* m, int what, int64_t* value) {
 int bohip_comm_unique_id(void* id, int64_t nbytes) {
     if (!id || nbytes < (int64_t)sizeof(ncclUniqueId)) return fail(BOHIP_E_ARG, "id buffer must hold BOHIP_UNIQUE_ID_BYTES");
     ncclUniqueId u;
-    NCCLCHK(ncclGetUniqueId(&u));
+    RCCL_OR_FAIL(R);
+    NCCLCHK(R->GetUniqueId(&u));
     std::memset(id, 0, (size_t)nbytes);
     std::memcpy(id, &u, sizeof(u));
     return 0;
@@ -477,7 +542,8 @@ int bohip_gp_comm_init(bohip_gp* g, const void* id, int64_t nbytes, int rank, in
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
     ncclComm_t c = nullptr;
-    NCCLCHK(ncclCommInitRank(&c, nranks, u, rank));
+    RCCL_OR_FAIL(R);
+    NCCLCHK(R->CommInitRank(&c, nranks, u, rank));
     g->comm = c; g->comm_rank = rank; g->comm_n = nranks;
     return comm_ensure_records(g, 1);
 }
@@ -487,7 +553,7 @@ int bohip_gp_comm_destroy(bohip_gp* g) {
     if (!g->comm) return 0;
     HIPCHK(hipSetDevice(g->device));
     HIPCHK(hipStreamSynchronize(g->stream));
-    ncclCommDestroy((ncclComm_t)g->comm);
+    if (rccl_api()) rccl_api()->CommDestroy((ncclComm_t)g->comm);
     g->comm = nullptr; g->comm_n = 0; g->comm_rank = 0;
     for (Best** p : {&g->csend, &g->crecv, &g->cfinal})
         if (*p) { hipFree(*p); *p = nullptr; }
@@ -515,7 +581,8 @@ int bohip_gp_score_sharded_dev(bohip_gp* g, int acq_id, const double* acq_params
         HIPCHK(hipMemcpyAsync(g->csend, &none, sizeof(Best), hipMemcpyHostToDevice, g->stream));
     }
     t_begin(g, "exchange");
-    NCCLCHK(ncclAllGather(g->csend, g->crecv, 2, ncclInt64, (ncclComm_t)g->comm, g->stream));
+    RCCL_OR_FAIL(R);
+    NCCLCHK(R->AllGather(g->csend, g->crecv, 2, ncclInt64, (ncclComm_t)g->comm, g->stream));
     hipLaunchKernelGGL(k_reduce_records, dim3(1), dim3(256), 0, g->stream, g->crecv, g->comm_n, 1, reinterpret_cast<Best*>(best));
     HIPCHK(hipGetLastError());
     t_end(g);
@@ -543,7 +610,8 @@ int bohip_gp_thompson_sharded(bohip_gp* g, const double* Xs, int64_t R_local, in
     hipLaunchKernelGGL(k_thompson, dim3((unsigned)S), dim3(256), 0, g->stream, g->dmu, g->dvar, R_local, seed, col_offset, g->csend,
                        (long long)col_offset);
     HIPCHK(hipGetLastError());
-    NCCLCHK(ncclAllGather(g->csend, g->crecv, (size_t)(2 * S), ncclInt64, (ncclComm_t)g->comm, g->stream));
+    RCCL_OR_FAIL(R);
+    NCCLCHK(R->AllGather(g->csend, g->crecv, (size_t)(2 * S), ncclInt64, (ncclComm_t)g->comm, g->stream));
     hipLaunchKernelGGL(k_reduce_records, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, g->stream, g->crecv, g->comm_n, (int)S,
                        g->cfinal);
     HIPCHK(hipGetLastError());

@@ -83,9 +83,16 @@ class ElasticGPE:
         h = C.c_void_p()
         check(self._lib.bohip_gp_create(self.dim, int(capacity), _lib.KERN[self.kernel.kern], int(device), C.byref(h)))
         self._h = h
+        _lib.register(self)
         self._x = np.zeros((self.dim, 0), order="F")
         self._y = np.zeros(0)
         self._push_hyper()
+
+    def close(self):
+        """Release the device model now (idempotent; also run for every live model at interpreter exit)."""
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.bohip_gp_destroy(h)
 
     @classmethod
     def from_data(cls, x, y, mean=None, kernel=None, logNoise=-2.0, **kw):
@@ -98,12 +105,10 @@ class ElasticGPE:
         return m
 
     def __del__(self):
-        h, self._h = getattr(self, "_h", None), None
-        if h:
-            try:
-                self._lib.bohip_gp_destroy(h)
-            except Exception:
-                pass
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # -- hyper-parameters (GP.set_params!) ---------------------------------------------------------
     def _push_hyper(self):

