@@ -16,6 +16,7 @@
 // when the GPU is unavailable.
 #include "../../include/bohip.h"
 #include "kernels_linalg.hip"
+#include "kernels_chol.hip"
 #include "kernels_score.hip"
 #include "kernels_ascent.hip"
 
@@ -61,6 +62,8 @@ struct bohip_gp {
     double *dalpha = nullptr, *dr = nullptr, *dt = nullptr, *dmll = nullptr;
     double* dApp = nullptr;  // [APP_ROWS][ld] scratch of the incremental append and of the row-wise (small-batch) posterior
     int* dinfo = nullptr;
+    unsigned* dchol_flags = nullptr;   // dataflow factorisation (kernels_chol.hip): panel[T*8] | solved[T] | crit[T] | abort[1]
+    double* dchol_idl = nullptr;       // [T*128] published 1 / L_ii
     std::vector<double> hX, hy;
     double loglen[DMAX], logsig = 0.0, lognoise = -2.0, beta = 0.0;
     bool stale = true;
@@ -181,8 +184,9 @@ static void t_collect(bohip_gp* g, bool force = false) {
 
 // ---- allocation -----------------------------------------------------------------------------------
 static int free_model(bohip_gp* g) {
-    for (double** p : {&g->dX, &g->dy, &g->dL, &g->dW, &g->dWT, &g->dS, &g->dalpha, &g->dr, &g->dt, &g->dApp})
+    for (double** p : {&g->dX, &g->dy, &g->dL, &g->dW, &g->dWT, &g->dS, &g->dalpha, &g->dr, &g->dt, &g->dApp, &g->dchol_idl})
         if (*p) { hipFree(*p); *p = nullptr; }
+    if (g->dchol_flags) { hipFree(g->dchol_flags); g->dchol_flags = nullptr; }
     return 0;
 }
 static int alloc_model(bohip_gp* g, int64_t cap) {
@@ -206,6 +210,11 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
     HIPCHK(hipMalloc(&g->dr, g->ld * 8));
     HIPCHK(hipMalloc(&g->dt, g->ld * 8));
     HIPCHK(hipMalloc(&g->dApp, (size_t)APP_ROWS * g->ld * 8));
+    {
+        const size_t Tm = (size_t)(g->ld / TILE) + 1;
+        HIPCHK(hipMalloc(&g->dchol_flags, (Tm * (CH_PANELS + 2) + 4) * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&g->dchol_idl, Tm * TILE * 8));
+    }
     HIPCHK(hipMemsetAsync(g->dL, 0, mat, g->stream));
     HIPCHK(hipMemsetAsync(g->dW, 0, mat, g->stream));
     HIPCHK(hipMemsetAsync(g->dWT, 0, mat, g->stream));
@@ -227,6 +236,8 @@ static int g_split = 1;   // split-K path for batches of a few hundred candidate
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
+static int g_chol_df = 0;  // BOHIP_CHOL_DATAFLOW=1: dataflow factorisation (kernels_chol.hip).  Correct (same tests), but measured slower than
+                            // the launch-chained form (N=3000: 3.08 vs 2.77 ms; N=10^4: 21 vs 13.3 ms), see DESIGN.md section 6: opt-in
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
@@ -246,6 +257,9 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_inv128, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
+    if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
@@ -326,6 +340,51 @@ static int inverse_join(bohip_gp* g, hipStream_t st, int P, int nb) {
     return 0;
 }
 
+// ---- A2, dataflow form (kernels_chol.hip): ONE persistent chain launch on the critical stream; the panel followers and the
+// flag-gated trailing updates of every block are enqueued up front on the side stream.  No host events inside the factorisation.
+static int cholesky_dataflow(bohip_gp* g, int T) {
+    const int64_t ld = g->ld;
+    CholFlags fl{};
+    fl.panel = g->dchol_flags;
+    fl.solved = fl.panel + (size_t)T * CH_PANELS;
+    fl.crit = fl.solved + T;
+    fl.abort = fl.crit + T;
+    fl.idl_g = g->dchol_idl;
+    fl.crit_want = 16u;   // the row-(k+2) launch: 4 workgroups x 4 storing waves
+    fl.panel_want = 4u;   // four publishing waves per panel
+    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, ((size_t)T * (CH_PANELS + 2) + 4) * sizeof(unsigned), g->stream));
+    HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
+    HIPCHK(hipStreamWaitEvent(g->side_stream, g->ev_panels, 0));
+    hipLaunchKernelGGL(k_chol_chain, dim3(T > 1 ? 2 : 1), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo);
+    HIPCHK(hipGetLastError());
+    for (int k = 0; k + 2 < T; ++k) {
+        const int nfollow = T - (k + 2);
+        hipLaunchKernelGGL(k_chol_follow, dim3(nfollow), dim3(CH_THREADS), WK_LDS_DOUBLES * 8, g->side_stream, g->dL, ld, g->dS, k, fl);
+        HIPCHK(hipGetLastError());
+        // trailing update with block k's panel L(:, k) (rows >= k+1 of dS): row k+1's diagonal tile lives in the chain
+        // owner's registers, row k+2 is what the chain needs next (its own launch, counted in crit[k]), the rest follows
+        auto upd = [&](int r0t, int mt, unsigned* signal) {
+            GemmNTParams u{};
+            u.A = g->dS + (int64_t)r0t * TILE * ld + (int64_t)k * TILE; u.lda = ld;
+            u.B = g->dS + (int64_t)(k + 1) * TILE * ld + (int64_t)k * TILE; u.ldb = ld;
+            u.C = g->dL + (int64_t)r0t * TILE * ld + (int64_t)(k + 1) * TILE; u.ldc = ld;
+            u.mt = mt; u.nt64 = 2 * (r0t + mt - (k + 1)); u.kc = TILE / KC; u.alpha = -1.0; u.beta = 1.0;
+            u.diag_skip = 1; u.row0 = (int64_t)r0t * TILE; u.col0 = (int64_t)(k + 1) * TILE;
+            u.wait_flag = fl.solved + k; u.wait_val = 1u; u.signal = signal; u.abort_flag = fl.abort;
+            return u;
+        };
+        CHK(launch_gemm_nt(g, upd(k + 2, 1, fl.crit + k), 1, g->side_stream));
+        if (T - (k + 3) > 0) CHK(launch_gemm_nt(g, upd(k + 3, T - (k + 3), nullptr), 1, g->side_stream));
+    }
+    HIPCHK(hipEventRecord(g->ev_bulk, g->side_stream));
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_bulk, 0));
+    if (T > 1) {
+        hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+
 static int refit(bohip_gp* g) {
     CHK(one_time_kernel_setup());
     const int64_t N = g->n;
@@ -351,6 +410,26 @@ static int refit(bohip_gp* g) {
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "cholesky");
+    if (g_chol_df) {
+        CHK(cholesky_dataflow(g, T));
+        t_end(g);
+        t_begin(g, "tri_inverse");
+        hipLaunchKernelGGL(k_inv128, dim3(T), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, g->dL, ld, g->dW, g->dWT, ld);
+        HIPCHK(hipGetLastError());
+        for (int h = 1; h < T; h *= 2) CHK(inverse_level(g, g->stream, 0, T, h));
+        t_end(g);
+        t_begin(g, "alpha");
+        CHK(compute_alpha(g));
+        t_end(g);
+        CHK(check_info(g));
+        unsigned aborted = 0;
+        HIPCHK(hipMemcpy(&aborted, g->dchol_flags + (size_t)T * (CH_PANELS + 2), sizeof(unsigned), hipMemcpyDeviceToHost));
+        if (aborted) { g->stale = true; return fail(BOHIP_E_HIP, "dataflow factorisation: a dependency wait timed out"); }
+        g->stale = false;
+        g->n_factored = N;
+        g->refits++;
+        return 0;
+    }
     // Right-looking on 128-column panels, with the trailing update applied in two tiers: inside an outer block
     // of OB panels only the block's own remaining columns are updated after every panel (K = 128); everything to
     // the right of the outer block is updated ONCE per outer block with K = 128 * OB.  The C tiles of the bulk
@@ -1518,6 +1597,11 @@ int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {
 }  // extern "C"
 #include "multigpu.hip"
 extern "C" {
+#if BOHIP_CHOL_TRACE
+int bohip_debug_chol_trace_read(unsigned long long* out, int64_t n_words) {   // tools only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_chol_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 #if BOHIP_TRACE
 int bohip_debug_trace_read(unsigned long long* out, int64_t n_words) {   // tools only
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -3;

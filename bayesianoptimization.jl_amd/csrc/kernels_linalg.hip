@@ -270,6 +270,46 @@ __device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int
     }
 }
 
+// B0 + B1 of the header above on an image whose strict upper triangle (mirror) holds L and whose idl[] holds 1 / L_ii:
+// W = L^-1 is built in the lower triangle and stored to Wblk (lower) and WTblk (upper).  Shared by k_potf2_inv and k_inv128.
+__device__ __forceinline__ void inverse_phase(double* a, const double* idl, int tid, double* __restrict__ Wblk,
+                                              double* __restrict__ WTblk, int64_t ldw) {
+    if (tid < TILE) {
+        const int q = tid & ~15, cc = tid & 15;
+        double w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) sacc += a[(q + k) * PF_LD + q + i] * w[k];  // w[k] = 0 for k < cc
+            w[i] = (i < cc) ? 0.0 : (i == cc ? idl[q + i] : -sacc * idl[q + i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i >= cc) a[(q + i) * PF_LD + q + cc] = w[i];
+    }
+    __syncthreads();
+    inv_level<16>(a, tid);
+    inv_level<32>(a, tid);
+    inv_level<64>(a, tid);
+    for (int e = tid; e < TILE * TILE / 2; e += PF_THREADS) {  // W (lower) and W' (upper), 16-B stores
+        const int i = e >> 6, c = (e & 63) * 2;
+        if (c <= i) {
+            d2 v;
+            v.x = a[i * PF_LD + c];
+            v.y = (c + 1 <= i) ? a[i * PF_LD + c + 1] : 0.0;
+            *reinterpret_cast<d2*>(Wblk + (int64_t)i * ldw + c) = v;
+        }
+        // W'[r][q] = W[q][r] for q >= r: row r = i, columns q = c, c + 1
+        if (c + 1 >= i) {
+            d2 v;
+            v.x = (c >= i) ? a[c * PF_LD + i] : 0.0;
+            v.y = a[(c + 1) * PF_LD + i];
+            *reinterpret_cast<d2*>(WTblk + (int64_t)i * ldw + c) = v;
+        }
+    }
+}
+
 #ifdef BOHIP_POTF2_CLOCKS
 #define PF_CLK(slot) do { if (threadIdx.x == 0) pf_clocks[slot] += clock64() - pf_t0; pf_t0 = clock64(); } while (0)
 __device__ long long pf_clocks[16];
@@ -320,7 +360,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
                 double sacc = a[i * PF_LD + P + c];
 #pragma unroll
                 for (int k = 0; k < c; ++k) sacc -= x[k] * a[(P + k) * PF_LD + P + c];
-                x[c] = sacc * idl[P + c];
+                x[c] = sacc * idl[P + c];   // (a right-looking form -- 16 x (mul, fma) on the chain -- measured 1 % slower)
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[(P + c) * PF_LD + i] = x[c];
@@ -366,45 +406,7 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
         *reinterpret_cast<d2*>(Lblk + (int64_t)i * ld + j) = v;
     }
     PF_CLK(4);
-    // B0: 16 x 16 diagonal inverses, thread = column
-    if (tid < TILE) {
-        const int q = tid & ~15, cc = tid & 15;
-        double w[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double sacc = 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) sacc += a[(q + k) * PF_LD + q + i] * w[k];  // w[k] = 0 for k < cc
-            w[i] = (i < cc) ? 0.0 : (i == cc ? idl[q + i] : -sacc * idl[q + i]);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (i >= cc) a[(q + i) * PF_LD + q + cc] = w[i];
-    }
-    __syncthreads();
-    PF_CLK(5);
-    inv_level<16>(a, tid);
-    PF_CLK(6);
-    inv_level<32>(a, tid);
-    PF_CLK(7);
-    inv_level<64>(a, tid);
-    PF_CLK(8);
-    for (int e = tid; e < TILE * TILE / 2; e += PF_THREADS) {  // W (lower) and W' (upper), 16-B stores
-        const int i = e >> 6, c = (e & 63) * 2;
-        if (c <= i) {
-            d2 v;
-            v.x = a[i * PF_LD + c];
-            v.y = (c + 1 <= i) ? a[i * PF_LD + c + 1] : 0.0;
-            *reinterpret_cast<d2*>(Wblk + (int64_t)i * ldw + c) = v;
-        }
-        // W'[r][q] = W[q][r] for q >= r: row r = i, columns q = c, c + 1
-        if (c + 1 >= i) {
-            d2 v;
-            v.x = (c >= i) ? a[c * PF_LD + i] : 0.0;
-            v.y = a[(c + 1) * PF_LD + i];
-            *reinterpret_cast<d2*>(WTblk + (int64_t)i * ldw + c) = v;
-        }
-    }
+    inverse_phase(a, idl, tid, Wblk, WTblk, ldw);
     PF_CLK(9);
 }
 
@@ -435,6 +437,13 @@ struct GemmNTParams {
     // ragged batches: tile (ti, tj64) of batch z exists iff  row_t0 + z row_ts + ti < total_t  and
     // col_t0 + z col_ts + tj64/2 < total_t  (all in 128-tiles); total_t <= 0 disables the check
     int row_t0, row_ts, col_t0, col_ts, total_t;
+    // dataflow gating (kernels_chol.hip): every workgroup waits until *wait_flag >= wait_val before it touches an operand,
+    // and each of its four storing waves adds 1 to *signal when its part of the tile is in memory (a workgroup without a
+    // tile adds 4), so a consumer can wait for 4 x gridDim.x x gridDim.y.  abort: see flag_wait_ge.
+    const unsigned* wait_flag;
+    unsigned wait_val;
+    unsigned* signal;
+    unsigned* abort_flag;
 };
 
 __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
@@ -443,8 +452,23 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
     const int ti = p.klo_from_n ? blockIdx.x % p.mt : blockIdx.x / p.nt64;
     const int tj = p.klo_from_n ? blockIdx.x / p.mt : blockIdx.x % p.nt64;
     const int z = blockIdx.y;
-    if (p.diag_skip && p.col0 + CTILE * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) return;
-    if (p.total_t > 0 && (p.row_t0 + z * p.row_ts + ti >= p.total_t || p.col_t0 + z * p.col_ts + (tj >> 1) >= p.total_t)) return;
+    const bool no_tile = (p.diag_skip && p.col0 + CTILE * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) ||
+                         (p.total_t > 0 && (p.row_t0 + z * p.row_ts + ti >= p.total_t || p.col_t0 + z * p.col_ts + (tj >> 1) >= p.total_t));
+    if (no_tile) {
+        if (p.signal && threadIdx.x == 0) atomicAdd(p.signal, 4u);
+        return;
+    }
+    if (p.wait_flag) {
+        if (threadIdx.x == 0) {
+            for (long it = 0;; ++it) {
+                if (__hip_atomic_load(p.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val) break;
+                if (p.abort_flag && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                __builtin_amdgcn_s_sleep(4);
+                if (it > 40000000L) { if (p.abort_flag) atomicExch(p.abort_flag, 1u); break; }
+            }
+        }
+        __syncthreads();   // what the flag guards was written with agent-scope stores (kernels_chol.hip): no cache maintenance here
+    }
     int kb = 0, ke = p.kc;
     const int koff = z * p.kz;
     if (p.klo_from_m) kb = max(kb, ti * (TILE / KC) - koff);
@@ -477,10 +501,15 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
             if (C) {
                 double* dst = C + (int64_t)r * p.ldc + c;
                 if (p.beta != 0.0) v += p.beta * *dst;
-                *dst = v;
+                if (p.signal) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a running kernel reads this tile
+                else *dst = v;
             }
             if (CT) CT[(int64_t)c * p.ldct + r] = v;
         }
+    }
+    if (p.signal) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the agent-scope stores above have landed
+        if (lane == 0) atomicAdd(p.signal, 1u);
     }
 }
 

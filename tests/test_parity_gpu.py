@@ -687,3 +687,44 @@ def test_device_ascent_against_scipy_lbfgsb_on_the_oracle(bohip, orc):
         np.testing.assert_allclose(Xd[:, sharp], xs[:, sharp], atol=1e-3)
         assert bf == pytest.approx(fs.max(), rel=1e-6, abs=1e-9 * scale)            # acquire_max's answer: the best over the starts
         np.testing.assert_allclose(bx, xs[:, int(np.argmax(fs))], atol=2e-4)
+
+
+def test_dataflow_cholesky_matches_the_launch_chained_one(bohip, orc):
+    """csrc/kernels_chol.hip (opt-in, BOHIP_CHOL_DATAFLOW=1): persistent chain workgroups + panel followers + flag-gated
+    updates.  Same factor as the default path to rounding, and against the oracle; run in a subprocess because the switch is
+    read once per process."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np, bohip
+out = {}
+for N, d in ((130, 2), (1000, 4), (3000, 8)):
+    rng = np.random.default_rng(N)
+    X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
+    m = bohip.ElasticGPE(d, kernel=bohip.SEArd(np.full(d, -0.6), 0.1), logNoise=-2.0, capacity=N)
+    m.append_(X.T, y)
+    L = m.factor()
+    mu, var = m.predict_f(X[:50].T + 0.01)
+    out[str(N)] = dict(Lsum=float(np.abs(L).sum()), Ldiag=np.diag(L)[::97].tolist(), Llast=L[-1, ::211].tolist(),
+                       alpha=m.alpha()[::113].tolist(), mu=mu.tolist(), var=var.tolist(), refits=m.info(2))
+print("RESULT" + json.dumps(out))
+''' % ROOT
+    res = {}
+    for flag in ("0", "1"):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BOHIP_CHOL_DATAFLOW=flag), capture_output=True,
+                           text=True, timeout=600)
+        assert o.returncode == 0, o.stderr[-2000:]
+        res[flag] = json.loads([l for l in o.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
+    for N in res["0"]:
+        a, b = res["0"][N], res["1"][N]
+        assert a["Lsum"] == pytest.approx(b["Lsum"], rel=1e-12)
+        for k in ("Ldiag", "Llast", "alpha", "mu"):
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(b["var"], a["var"], rtol=1e-7, atol=1e-12)

@@ -1,0 +1,39 @@
+"""Timeline of the dataflow Cholesky chain (build: make -C bayesianoptimization.jl_amd/csrc abl/libbohip_choltrace.so).
+wall_clock64 ticks are 10 ns.  usage: python tools/chol_trace.py [N]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bohip import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "abl", "libbohip_choltrace.so")
+import bohip
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+d = 8
+rng = np.random.default_rng(0)
+X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
+m = bohip.ElasticGPE(d, kernel=bohip.SEArd(np.full(d, np.log(0.5)), 0.0), logNoise=-2.0, capacity=N)
+m.append_(X.T, y)
+for _ in range(3):
+    m.set_params_(logNoise=-2.0); m.fit_()
+lib = _lib.load()
+buf = (C.c_ulonglong * 4096)()
+lib.bohip_debug_chol_trace_read.argtypes = [C.c_void_p, C.c_int64]
+assert lib.bohip_debug_chol_trace_read(buf, 4096) == 0
+t = np.array(buf, dtype=np.int64)
+T = (N + 1 + 127) // 128
+pub, saw, fin, blk = t[:1024], t[1024:2048], t[2048:3072], t[3072:]
+t0 = blk[0]
+us = lambda v: (v - t0) / 100.0
+for k in range(min(T, 6)):
+    print(f"block {k}: pivot start {us(blk[2*k]):8.1f} end {us(blk[2*k+1]):8.1f} us | published {[round(us(pub[8*k+p]),1) for p in range(8)]}")
+    if k + 1 < T:
+        print(f"          owner of row {k+1}: saw {[round(us(saw[8*k+p]),1) for p in range(8)]}")
+        print(f"                           done {[round(us(fin[8*k+p]),1) for p in range(8)]}")
+dur = [(blk[2*k+1] - blk[2*k]) / 100.0 for k in range(T)]
+gap = [(blk[2*(k+1)] - blk[2*k+1]) / 100.0 for k in range(T - 1)]
+print(f"pivot duration per block: mean {np.mean(dur):.1f} us (min {np.min(dur):.1f}, max {np.max(dur):.1f}); gap to next pivot start: mean {np.mean(gap):.1f} us (min {np.min(gap):.1f} max {np.max(gap):.1f}); total {us(blk[2*(T-1)+1]):.1f} us")
+
+ph = t[3584:3584 + 64].reshape(8, 8)
+print("block 1, follower phases per panel (us since flag seen): staged, solved+barrier, trailing done (t511), D1 done (t511)")
+for p_ in range(8):
+    base = saw[8 * 1 + p_]
+    print("  panel", p_, [round((ph[p_][i] - base) / 100.0, 2) for i in range(4)], " panel done", round((fin[8 + p_] - base) / 100.0, 2))
