@@ -83,6 +83,9 @@ struct bohip_gp {
     int64_t q_cap = 0, r_cap = 0, xs_cap = 0;
     Best *dblock_best = nullptr, *dbest = nullptr;
     int64_t bb_cap = 0;
+    unsigned* dfz_cnt = nullptr;   // fused finish of k_trigemm_sq: [tiles] arrivals per candidate tile + [1] finished tiles (kept at zero)
+    Best* dfz_best = nullptr;      // [tiles] per-tile arg-max records
+    int64_t fz_cap = 0;
     double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
     double asc_maxtime = 0.0;    // bohip_gp_set_maxtime: wall-clock budget of one acquire_max call in seconds (NLopt maxtime), 0 = none
     int64_t batch_hint = 0;      // bohip_gp_set_batch_hint: choose the scoring path as if the batch had at least this many candidates
@@ -238,6 +241,7 @@ static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wis
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
 static int g_chol_df = 0;  // BOHIP_CHOL_DATAFLOW=1: dataflow factorisation (kernels_chol.hip).  Correct (same tests), but measured slower than
                             // the launch-chained form (N=3000: 3.08 vs 2.77 ms; N=10^4: 21 vs 13.3 ms), see DESIGN.md section 6: opt-in
+static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
@@ -261,6 +265,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_inv128, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
+    if (const char* e = getenv("BOHIP_FUSE_FINISH")) g_fuse_finish = atoi(e);
     if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
     if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
@@ -645,6 +650,16 @@ static int ensure_score_scratch(bohip_gp* g, int64_t R) {
         HIPCHK(hipMalloc(&g->dscore, Rpad * 8));
         g->r_cap = Rpad;
     }
+    const int64_t tiles = Rpad / CTILE + 2;
+    if (g->fz_cap < tiles) {
+        if (g->dfz_cnt) hipFree(g->dfz_cnt);
+        if (g->dfz_best) hipFree(g->dfz_best);
+        g->dfz_cnt = nullptr; g->dfz_best = nullptr; g->fz_cap = 0;
+        HIPCHK(hipMalloc(&g->dfz_cnt, (size_t)(tiles + 1) * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&g->dfz_best, (size_t)tiles * sizeof(Best)));
+        HIPCHK(hipMemsetAsync(g->dfz_cnt, 0, (size_t)(tiles + 1) * sizeof(unsigned), g->stream));
+        g->fz_cap = tiles;
+    }
     const int64_t nb = (R + 255) / 256 + 1;
     if (g->bb_cap < nb) {
         if (g->dblock_best) hipFree(g->dblock_best);
@@ -683,14 +698,15 @@ static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1,
 }
 
 // V = W K* with the fused epilogue (k_trigemm_sq): one launch per K*' chunk.
-static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t Rpad, int64_t r0, double* VT) {
+static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t Rpad, int64_t r0, double* VT,
+                          const FuseParams& fz = FuseParams{}) {
     const int CT = (int)((ncand + CTILE - 1) / CTILE), n_local = (CT + 7) / 8;
     if (g_ks8)
         hipLaunchKernelGGL(k_trigemm_sq<2>, dim3(8 * n_local * T), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz);
     else
         hipLaunchKernelGGL(k_trigemm_sq<1>, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld);
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -755,7 +771,7 @@ static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r
     return 0;
 }
 
-static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
+static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R, const FuseParams& fz = FuseParams{}) {
     CHK(one_time_kernel_setup());
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE;  // +TILE: head-room for tile-granular writes
     const int T = (int)(Npad / TILE);
@@ -768,7 +784,7 @@ static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R) {
         CHK(launch_kstar_any(g, dXs, r0, r1, Npad, hp));
         t_end(g);
         t_begin(g, "trigemm_sq");
-        CHK(launch_trigemm(g, T, r1 - r0, N, Rpad, r0, nullptr));
+        CHK(launch_trigemm(g, T, r1 - r0, N, Rpad, r0, nullptr, fz));
         t_end(g);
     }
     return 0;
@@ -860,8 +876,20 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
         return small_posterior(g, dXs, 0, R, false, ap, d_mu, d_var, d_score, d_best, best_off);
     }
     const SplitPlan sp = split_plan(g, R);
-    if (sp.nsl > 0) CHK(split_posterior(g, dXs, R, sp, false));
-    else CHK(posterior_pass(g, dXs, R));
+    if (sp.nsl > 0) {
+        CHK(split_posterior(g, dXs, R, sp, false));
+    } else if (g_fuse_finish) {
+        // whole-K jobs: scoring and arg-max ride in k_trigemm_sq's epilogue (the workgroup that completes a candidate tile
+        // finishes it; the one that completes the last tile writes the record): no k_score / k_argmax_final launches
+        FuseParams fz{};
+        fz.tile_cnt = g->dfz_cnt; fz.total_cnt = g->dfz_cnt + g->fz_cap; fz.tile_best = g->dfz_best;
+        fz.tiles_total = (int)((R + CTILE - 1) / CTILE); fz.R_total = R;
+        fz.sigma2 = std::exp(2.0 * g->logsig); fz.beta = g->beta; fz.ap = ap;
+        fz.mu_out = d_mu; fz.var_out = d_var; fz.score_out = d_score; fz.best_out = d_best; fz.best_off = best_off;
+        return posterior_pass(g, dXs, R, fz);
+    } else {
+        CHK(posterior_pass(g, dXs, R));
+    }
     const int64_t Npad = round_up(g->n + 1, TILE), Rpad = round_up(R, TILE) + TILE;
     const int T = (int)(Npad / TILE);
     const int nb = (int)((R + 255) / 256);
@@ -1030,6 +1058,8 @@ void bohip_gp_destroy(bohip_gp* g) {
         if (*p) hipFree(*p);
     if (g->dblock_best) hipFree(g->dblock_best);
     if (g->dbest) hipFree(g->dbest);
+    if (g->dfz_cnt) hipFree(g->dfz_cnt);
+    if (g->dfz_best) hipFree(g->dfz_best);
     if (g->dgrad) hipFree(g->dgrad);
     if (g->dgparts) hipFree(g->dgparts);
     if (g->dsplit) hipFree(g->dsplit);

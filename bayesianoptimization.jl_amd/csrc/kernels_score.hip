@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ X, int
             rr += w[k] * (t * t);
         }
         const double v = (j < N) ? cov_from_r_fast(hp.kern, hp.sigma2, rr) : 0.0;
-        KsT[(r0 + c - r_begin) * ldk + j] = v;
+        KsT[(r0 + c - r_begin) * ldk + j] = v;   // plain stores: non-temporal ones evict K*' from L2/MALL and k_trigemm_sq
+                                                   // then runs at 0.70 instead of 0.635 ms (measured)
     }
 }
 
@@ -103,6 +104,30 @@ __global__ __launch_bounds__(256) void k_post_cov(const double* __restrict__ Xs,
 // Output: q_part[rt][r] = sum over the tile's rows of v^2 (fixed summation order -> deterministic),
 //         mu_raw[r] = alpha' k*_r taken from the row of W that stores alpha (alpha_row).
 // ------------------------------------------------------------------------------------------------
+struct AcqParams {
+    int acq;
+    double p0, p1;
+};
+// Fused finish of k_trigemm_sq (large batches, value-only scoring): the workgroup that delivers the LAST row tile of a
+// candidate tile turns the T partial sums into sigma^2, the acquisition value and the tile's arg-max; the one that
+// completes the last candidate tile reduces the per-tile records to the 16-byte result.  Replaces k_score +
+// k_argmax_final (two launches, ~16 us of a 0.69 ms step).  Same summation order as k_score -> bit-identical scores.
+// Cross-workgroup data (q_part, mu_raw, tile records) moves with agent-scope accesses; the counters are left at zero.
+struct FuseParams {
+    unsigned* tile_cnt;      // [candidate tiles of the whole batch]  arrivals per tile (nullptr: no fused finish)
+    unsigned* total_cnt;     // [1] finished candidate tiles
+    Best* tile_best;         // [candidate tiles]
+    int tiles_total;         // candidate tiles of the whole batch (all chunks)
+    int64_t R_total;         // candidates of the whole batch
+    double sigma2, beta;
+    AcqParams ap;
+    double *mu_out, *var_out, *score_out;   // nullable, indexed by the global candidate number
+    Best* best_out;          // nullable: the batch's arg-max record
+    long long best_off;      // added to the winner's index (sharded scoring)
+};
+__device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, const double* q_part, int64_t ldq,
+                                     const double* mu_raw);
+
 // BOHIP_TRACE (tools only, default 0 in gemm_core.h): per-workgroup start/end clocks of k_trigemm_sq (tools/trace_trigemm.py)
 #if BOHIP_TRACE
 __device__ unsigned long long g_trace[4 * 8192];
@@ -113,7 +138,7 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
                                                                 int T, int CT, int64_t alpha_row,
                                                                 double* __restrict__ q_part, int64_t ldq,
                                                                 double* __restrict__ mu_raw, int64_t r_off,
-                                                                double* __restrict__ VT, int64_t ldv) {
+                                                                double* __restrict__ VT, int64_t ldv, FuseParams fz) {
     constexpr int NJ = 4, CW = CTILE;
     extern __shared__ __attribute__((aligned(16))) double smem[];
 #if BOHIP_TRACE
@@ -161,7 +186,7 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
             const int64_t grow = row_base + acc_row(lane, wr, mi);
             const double v = acc[mi][nj];
             if (grow == alpha_row) {
-                mu_raw[r_off + (int64_t)ct * CW + acc_col<NJ>(lane, wc, nj)] = v;
+                __hip_atomic_store(mu_raw + r_off + (int64_t)ct * CW + acc_col<NJ>(lane, wc, nj), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 s += v * v;
             }
@@ -176,7 +201,17 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
     }
     __syncthreads();
     if (threadIdx.x < CW)
-        q_part[(int64_t)rt * ldq + r_off + (int64_t)ct * CW + threadIdx.x] = red[threadIdx.x] + red[CW + threadIdx.x];
+        __hip_atomic_store(q_part + (int64_t)rt * ldq + r_off + (int64_t)ct * CW + threadIdx.x, red[threadIdx.x] + red[CW + threadIdx.x],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fz.tile_cnt != nullptr) {
+        __shared__ int s_last;
+        const int tile_g = (int)(r_off / CW) + ct;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the agent-scope stores above have landed
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(fz.tile_cnt + tile_g, 1u) == (unsigned)(T - 1);
+        __syncthreads();
+        if (s_last && threadIdx.x < 64) trigemm_fused_finish(fz, tile_g, T, q_part, ldq, mu_raw);
+    }
 }
 
 // ---- split-K path for batches with too few candidate tiles to fill the chip (a few hundred candidates) -------------
@@ -228,11 +263,6 @@ __global__ __launch_bounds__(256) void k_split_combine_u(const double* __restric
 // Acquisition functors -- verbatim operation order of the reference, contraction OFF (Julia never
 // fuses a*b+c).  normal_pdf / normal_cdf: src/utils.jl:48-49.
 // ------------------------------------------------------------------------------------------------
-struct AcqParams {
-    int acq;
-    double p0, p1;
-};
-
 __device__ __forceinline__ double acq_eval(const AcqParams& a, double mu, double s2) {
 #pragma clang fp contract(off)
     switch (a.acq) {
@@ -276,6 +306,62 @@ __device__ __forceinline__ void block_argmax(double& v, long long& i, Best* sh) 
     if (threadIdx.x == 0) {
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
             if (better(sh[w].val, sh[w].idx, v, i)) { v = sh[w].val; i = sh[w].idx; }
+    }
+}
+
+// one wave: the 64 candidates of tile tile_g (see FuseParams)
+__device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, const double* q_part, int64_t ldq,
+                                     const double* mu_raw) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)tile_g * CTILE + lane;
+    double v = -INFINITY;
+    long long idx = -1;
+    if (r < fz.R_total) {
+        double q = 0.0;
+        for (int t = 0; t < T; ++t) q += __hip_atomic_load(q_part + (int64_t)t * ldq + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double s2 = fz.sigma2 - q;
+        if (s2 < 0.0) s2 = 0.0;  // predict_f: max(sigma2, 0)
+        const double mu = fz.beta + __hip_atomic_load(mu_raw + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fz.mu_out) fz.mu_out[r] = mu;
+        if (fz.var_out) fz.var_out[r] = s2;
+        const double f = acq_eval(fz.ap, mu, s2);
+        if (fz.score_out) fz.score_out[r] = f;
+        if (f > -INFINITY) { v = f; idx = r; }  // false for NaN and -Inf
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const long long oi = __shfl_xor(idx, o);
+        if (better(ov, oi, v, idx)) { v = ov; idx = oi; }
+    }
+    int last = 0;
+    if (lane == 0) {
+        fz.tile_cnt[tile_g] = 0u;   // ready for the next call
+        if (fz.best_out) {
+            __hip_atomic_store(&fz.tile_best[tile_g].val, idx >= 0 ? v : -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&fz.tile_best[tile_g].idx, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            last = atomicAdd(fz.total_cnt, 1u) == (unsigned)(fz.tiles_total - 1);
+        }
+    }
+    last = __shfl(last, 0);
+    if (!last) return;
+    v = -INFINITY;
+    idx = -1;
+    for (int i = lane; i < fz.tiles_total; i += 64) {
+        const double bv = __hip_atomic_load(&fz.tile_best[i].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long bi = __hip_atomic_load(&fz.tile_best[i].idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (better(bv, bi, v, idx)) { v = bv; idx = bi; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(v, o);
+        const long long oi = __shfl_xor(idx, o);
+        if (better(ov, oi, v, idx)) { v = ov; idx = oi; }
+    }
+    if (lane == 0) {
+        *fz.total_cnt = 0u;
+        fz.best_out->val = idx >= 0 ? v : -INFINITY;
+        fz.best_out->idx = idx >= 0 ? idx + fz.best_off : -1;
     }
 }
 

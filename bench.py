@@ -358,10 +358,23 @@ def main():
     fit_ms = dict(model.timing())
     in_library = backend == "nccl" and not share_gpu
     if in_library:
-        ids = [bohip.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)          # torch.distributed is only the courier of the 128 bytes
-        model.comm_init(ids[0], rank, world)
-    else:
+        # every rank must take the same path: agree on whether the in-library communicator came up everywhere, else fall back
+        # to the torch.distributed exchange of dist.py (same records, same reduction, one all_gather + a host reduce)
+        ok = 1
+        try:
+            ids = [bohip.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)      # torch.distributed is only the courier of the 128 bytes
+            model.comm_init(ids[0], rank, world)
+        except Exception as e:                          # noqa: BLE001
+            print(f"[rank {rank}] in-library RCCL unavailable ({e}); using the torch.distributed exchange", file=sys.stderr)
+            ok = 0
+        t_ok = torch.tensor([ok], device=torch.device("cuda", local_rank))
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 0:
+            if ok:
+                model.comm_destroy()
+            in_library = False
+    if not in_library:
         model.set_batch_hint(R_total)
 
     dev = torch.device("cuda", local_rank)
