@@ -22,6 +22,23 @@ if kt:
     for k, v in d.items():
         if "bohip" in k:
             print(f"{k[:70]:70s} n={len(v)} vgpr={v[0][1]} sgpr={v[0][2]} lds={v[0][3]} grid={v[-1][4]} wg={v[-1][5]}")
+    # the event time bench.py reports covers only its timed region = the LAST `steps` launches of the dominant kernel;
+    # --stats above averages every launch of the process (cold warm-up and host-buffer launches included)
+    steps = None
+    try:
+        line = [l for l in open(os.path.join(out, "bench_under_rocprof.log")) if l.startswith("{")][-1]
+        bj = json.loads(line)
+        steps = int(bj["steps"])
+        print(f"\nbench.py under rocprofv3: steps={steps} ms_per_step={bj['ms_per_step']:.4f} "
+              f"HIP-event avg of k_trigemm_sq over the timed region = {bj['roofline']['avg_launch_ms'] * 1e3:.1f} us "
+              f"(frac {bj['roofline']['frac']:.3f})")
+    except Exception as e:
+        print("no bench line:", e)
+    for k, v in d.items():
+        if "trigemm" in k and steps:
+            last = [x[0] for x in v[-steps:]]
+            print(f"kernel-trace avg of the LAST {steps} k_trigemm_sq launches (= the timed region): {sum(last) / len(last) / 1e3:.1f} us; "
+                  f"all {len(v)} launches: {sum(x[0] for x in v) / len(v) / 1e3:.1f} us")
 print("\n== PMC passes (separate runs; per-dispatch averages for bohip kernels) ==")
 traffic = {}
 for f in find("pmc_*/**/*counter_collection.csv"):
