@@ -63,7 +63,7 @@ struct bohip_gp {
     double* dApp = nullptr;  // [APP_ROWS][ld] scratch of the incremental append and of the row-wise (small-batch) posterior
     int* dinfo = nullptr;
     unsigned* dchol_flags = nullptr;   // dataflow factorisation (kernels_chol.hip): panel[T*8] | solved[T] | crit[T] | abort[1]
-    double* dchol_idl = nullptr;       // [T*128] published 1 / L_ii
+    double* dchol_idl = nullptr;       // [T*8][16][16] published inverses of the 16 x 16 pivot blocks
     std::vector<double> hX, hy;
     double loglen[DMAX], logsig = 0.0, lognoise = -2.0, beta = 0.0;
     bool stale = true;
@@ -215,8 +215,8 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
     HIPCHK(hipMalloc(&g->dApp, (size_t)APP_ROWS * g->ld * 8));
     {
         const size_t Tm = (size_t)(g->ld / TILE) + 1;
-        HIPCHK(hipMalloc(&g->dchol_flags, (Tm * (CH_PANELS + 2) + 4) * sizeof(unsigned)));
-        HIPCHK(hipMalloc(&g->dchol_idl, Tm * TILE * 8));
+        HIPCHK(hipMalloc(&g->dchol_flags, (Tm * (3 * CH_PANELS + 7) + 4) * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&g->dchol_idl, Tm * CH_PANELS * 256 * 8));   // W16 of every pivot block
     }
     HIPCHK(hipMemsetAsync(g->dL, 0, mat, g->stream));
     HIPCHK(hipMemsetAsync(g->dW, 0, mat, g->stream));
@@ -353,34 +353,63 @@ static int cholesky_dataflow(bohip_gp* g, int T) {
     fl.panel = g->dchol_flags;
     fl.solved = fl.panel + (size_t)T * CH_PANELS;
     fl.crit = fl.solved + T;
-    fl.abort = fl.crit + T;
-    fl.idl_g = g->dchol_idl;
-    fl.crit_want = 16u;   // the row-(k+2) launch: 4 workgroups x 4 storing waves
+    fl.rest = fl.crit + T;
+    fl.col = fl.rest + T;
+    fl.farall = fl.col + T;
+    fl.fol = fl.farall + T;
+    fl.colall = fl.fol + T;
+    fl.xp = fl.colall + T;
+    fl.abort = fl.xp + (size_t)T * 2 * CH_PANELS;
+    fl.w16_g = g->dchol_idl;
+    fl.crit_want = 16u;   // the row-(k+2) update: 4 workgroups x 4 storing waves
     fl.panel_want = 4u;   // four publishing waves per panel
-    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, ((size_t)T * (CH_PANELS + 2) + 4) * sizeof(unsigned), g->stream));
+    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, ((size_t)T * (3 * CH_PANELS + 7) + 4) * sizeof(unsigned), g->stream));
     HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
     HIPCHK(hipStreamWaitEvent(g->side_stream, g->ev_panels, 0));
-    hipLaunchKernelGGL(k_chol_chain, dim3(T > 1 ? 2 : 1), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo);
+    // ONE persistent launch: row owners, critical followers (rows k+1, k+2) and the gated update of row k+2 (kernels_chol.hip)
+    hipLaunchKernelGGL(k_chol_chain, dim3(T > 1 ? 8 : 1), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo);
     HIPCHK(hipGetLastError());
-    for (int k = 0; k + 2 < T; ++k) {
-        const int nfollow = T - (k + 2);
-        hipLaunchKernelGGL(k_chol_follow, dim3(nfollow), dim3(CH_THREADS), WK_LDS_DOUBLES * 8, g->side_stream, g->dL, ld, g->dS, k, fl);
+    HIPCHK(hipStreamWaitEvent(g->inv_stream, g->ev_panels, 0));
+    for (int k = 0; k + 3 < T; ++k) {
+        // Rows >= k+3 (rows k+1, k+2 belong to the chain launch).  Look-ahead split of their update with L(:, k):
+        //   side stream : followers (k_chol_follow) -> update of COLUMN k+1 only -- what block k+1's followers need
+        //   third stream: update of the columns >= k+2 (the bulk of the flops), behind the followers via a counter
+        const int mt = T - (k + 3);
+        hipLaunchKernelGGL(k_chol_follow, dim3(mt), dim3(CH_THREADS), WK_LDS_DOUBLES * 8, g->side_stream, g->dL, ld, g->dS, k, fl);
         HIPCHK(hipGetLastError());
-        // trailing update with block k's panel L(:, k) (rows >= k+1 of dS): row k+1's diagonal tile lives in the chain
-        // owner's registers, row k+2 is what the chain needs next (its own launch, counted in crit[k]), the rest follows
-        auto upd = [&](int r0t, int mt, unsigned* signal) {
-            GemmNTParams u{};
-            u.A = g->dS + (int64_t)r0t * TILE * ld + (int64_t)k * TILE; u.lda = ld;
-            u.B = g->dS + (int64_t)(k + 1) * TILE * ld + (int64_t)k * TILE; u.ldb = ld;
-            u.C = g->dL + (int64_t)r0t * TILE * ld + (int64_t)(k + 1) * TILE; u.ldc = ld;
-            u.mt = mt; u.nt64 = 2 * (r0t + mt - (k + 1)); u.kc = TILE / KC; u.alpha = -1.0; u.beta = 1.0;
-            u.diag_skip = 1; u.row0 = (int64_t)r0t * TILE; u.col0 = (int64_t)(k + 1) * TILE;
-            u.wait_flag = fl.solved + k; u.wait_val = 1u; u.signal = signal; u.abort_flag = fl.abort;
-            return u;
-        };
-        CHK(launch_gemm_nt(g, upd(k + 2, 1, fl.crit + k), 1, g->side_stream));
-        if (T - (k + 3) > 0) CHK(launch_gemm_nt(g, upd(k + 3, T - (k + 3), nullptr), 1, g->side_stream));
+        // The far update starts behind the followers through a host-side event, NOT an in-kernel wait: its hundreds of
+        // workgroups would otherwise sit in every CU slot spinning for followers that can then never be scheduled
+        // (observed: time-out at T = 24).  In-kernel waits are kept for launches of a few dozen workgroups only.
+        HIPCHK(hipEventRecord(g->ev_gate, g->side_stream));
+        HIPCHK(hipStreamWaitEvent(g->inv_stream, g->ev_gate, 0));
+        const unsigned* last1 = fl.xp + ((size_t)k * 2 + 0) * CH_PANELS + (CH_PANELS - 1);   // L(k+1, k) complete
+        const unsigned* last2 = fl.xp + ((size_t)k * 2 + 1) * CH_PANELS + (CH_PANELS - 1);   // L(k+2, k) complete
+        GemmNTParams u{};
+        u.A = g->dS + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; u.lda = ld;
+        u.B = g->dS + (int64_t)(k + 1) * TILE * ld + (int64_t)k * TILE; u.ldb = ld;
+        u.C = g->dL + (int64_t)(k + 3) * TILE * ld + (int64_t)(k + 1) * TILE; u.ldc = ld;
+        u.mt = mt; u.nt64 = 2; u.kc = TILE / KC; u.alpha = -1.0; u.beta = 1.0;
+        u.wait_flag = last1; u.wait_val = 1u;
+        if (k >= 1) {   // block k-1's far update wrote these tiles too (column k+1 was "far" for it): it must be complete
+            u.wait_flag2 = fl.farall + (k - 1);
+            u.wait_val2 = 4u * (unsigned)(T - k - 2) * 2u * (unsigned)(T - k - 1);
+        }
+        u.signal = fl.colall + k;           // (selects the agent-scope stores; nobody waits for the whole launch)
+        u.signal_row0 = fl.col + k;         // tile (k+3, k+1): what the critical follower of row k+3 waits for
+        u.abort_flag = fl.abort;
+        CHK(launch_gemm_nt(g, u, 1, g->side_stream));
+        GemmNTParams f{};
+        f.A = g->dS + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; f.lda = ld;
+        f.B = g->dS + (int64_t)(k + 2) * TILE * ld + (int64_t)k * TILE; f.ldb = ld;
+        f.C = g->dL + (int64_t)(k + 3) * TILE * ld + (int64_t)(k + 2) * TILE; f.ldc = ld;
+        f.mt = mt; f.nt64 = 2 * (T - (k + 2)); f.kc = TILE / KC; f.alpha = -1.0; f.beta = 1.0;
+        f.diag_skip = 1; f.row0 = (int64_t)(k + 3) * TILE; f.col0 = (int64_t)(k + 2) * TILE;
+        f.wait_flag = last2; f.wait_val = 1u;   // (set with the critical follower's last panel: long since, when the followers are done)
+        f.signal = fl.farall + k; f.signal_row0 = fl.rest + k; f.abort_flag = fl.abort;
+        CHK(launch_gemm_nt(g, f, 1, g->inv_stream));
     }
+    HIPCHK(hipEventRecord(g->ev_inv, g->inv_stream));
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
     HIPCHK(hipEventRecord(g->ev_bulk, g->side_stream));
     HIPCHK(hipStreamWaitEvent(g->stream, g->ev_bulk, 0));
     if (T > 1) {
@@ -428,7 +457,7 @@ static int refit(bohip_gp* g) {
         t_end(g);
         CHK(check_info(g));
         unsigned aborted = 0;
-        HIPCHK(hipMemcpy(&aborted, g->dchol_flags + (size_t)T * (CH_PANELS + 2), sizeof(unsigned), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&aborted, g->dchol_flags + (size_t)T * (3 * CH_PANELS + 7), sizeof(unsigned), hipMemcpyDeviceToHost));
         if (aborted) { g->stale = true; return fail(BOHIP_E_HIP, "dataflow factorisation: a dependency wait timed out"); }
         g->stale = false;
         g->n_factored = N;

@@ -7,7 +7,8 @@
 // the solve of the tile just below it, and the update of the NEXT diagonal block.  Here they are pipelined at 16-column
 // granularity and never leave the chip's registers / LDS:
 //
-//   k_chol_chain   2 persistent workgroups ("row owners", rows r = w, w+2, ...).  The owner of row r
+//   k_chol_chain   8 persistent workgroups: 2 row owners, 2 critical followers, 4 gated-update workgroups (roles below).
+//                  The owner of row r
 //                    during block r-1  holds tile (r, r-1) [128 x 128, registers] and tile (r, r) [lower, registers],
 //                                      follows the 16-column panels the other owner publishes: row solve of its 128 rows
 //                                      (substitution against the 16 x 16 pivot block), right-looking update of its
@@ -38,8 +39,8 @@ constexpr int CH_THREADS = 512;
 constexpr int CH_PANELS = TILE / 16;          // 8 panels of 16 columns per 128-block
 constexpr int WK_LPS = 16;                    // worker LDS: published panel LP[128][16]
 constexpr int WK_XS = 17;                     //             solved rows   XB[128][17]
-constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + TILE * WK_XS + 16;   // LPt[16][130] | XB[128][17] | idl[16]
-constexpr int CH_LDS_BYTES = (TILE * PF_LD + 2 * TILE) * 8;   // the potf2 image; the worker arrays alias its start
+constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + 2 * TILE * WK_XS + 256;   // LPt[16][130] | XB[128][17] | XS[128][17] | W16[16][16]
+constexpr int CH_LDS_BYTES = (TILE * PF_LD + 2 * TILE + 256) * 8;   // the potf2 image + dl + idl + W16 scratch; the worker arrays alias its start
 static_assert(WK_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "worker arrays must fit inside the diagonal-block image");
 
 struct CholFlags {
@@ -47,7 +48,13 @@ struct CholFlags {
     unsigned* solved;     // [T]       L(k+1, k) is complete in S (written by the owner of row k+1)
     unsigned* crit;       // [T]       counter: waves of the update launch for row k+2 of block k that have finished
     unsigned* abort;      // [1]       set on a spin time-out: every wait returns at once
-    double* idl_g;        // [T * 128] 1 / L_ii, published with each panel
+    double* w16_g;        // [T * 8][16][16] inverse of each 16 x 16 pivot block (lower, zeros above), published with its panel
+    unsigned* xp;         // [T * 2 * 8] rows k+1 (slot 0) and k+2 (slot 1) of block k: panel p of L(row, k) is complete in S
+    unsigned* rest;       // [T]       counter: storing waves of row k+3 (the first row tile) of block k's FAR update (columns >= k+2)
+    unsigned* col;        // [T]       the same for block k's update of column k+1 (tile (k+3, k+1): what row k+3's follower needs next)
+    unsigned* farall;     // [T]       every storing wave of block k's far update
+    unsigned* fol;        // [T]       bulk followers of block k that have finished
+    unsigned* colall;     // [T]       (every storing wave of block k's column update; not waited on)
     unsigned crit_want;   // value of crit[k] when the whole row-(k+2) update launch of block k is in memory
     unsigned panel_want;  // value of panel[..] when every publishing wave has seen its stores land
 };
@@ -75,7 +82,14 @@ __device__ unsigned long long g_chol_trace[4 * 1024];   // [0,1024): panel publi
 #endif
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void release_wg() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// 16-byte agent-scope loads (the atomic builtin stops at 8 bytes): issue, then ONE wait that also ties the results in
+__device__ __forceinline__ void ld_agent_x2_issue(const double* p, d2& out) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(out) : "v"(p) : "memory");
+}
+// "All my stores have left this CU and were acknowledged": an explicit s_waitcnt.  NOT __builtin_amdgcn_fence(release,
+// "workgroup") -- in the default (non-tgsplit) execution mode the compiler emits no vmcnt wait for that scope (checked in
+// the ISA), the flag then overtook the data and large factorisations came out wrong once in a few runs.
+__device__ __forceinline__ void release_wg() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void flag_set(unsigned* flag, unsigned v) {
     __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -103,28 +117,22 @@ __host__ __device__ constexpr int blk_bj(int idx) { return idx - blk_bi(idx) * (
 // took 10 us.  With an 8-row x 4-column register block per lane, a step of the update needs 8 + 4 operands for 32 FMAs.
 constexpr int WK_LS = TILE + 2;   // row stride of LPt (even: 16-B aligned rows; +2 spreads the staging writes over the banks)
 
-// x L16' = r  (L16 = pivot block), right-looking: once x[c] is known every later entry is updated at once, so the dependent
-// chain is 16 x (mul, fma) instead of 120 fused multiply-adds in a row.
-__device__ __forceinline__ void solve16(double (&r)[16], const double* LPt_p, const double* idl_s) {
-#pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        r[c] *= idl_s[c];
-        const double* col = LPt_p + c * WK_LS;   // L16[c'][c] for c' = 0..15 at col[c']
-#pragma unroll
-        for (int k = c + 1; k < 16; ++k) r[k] -= r[c] * col[k];
-    }
-}
-
+// x L16' = r  <=>  x = r W16',  W16 = L16^-1 published by the pivot workgroup: 4 of the 16 entries per thread, all 512
+// threads, no dependent chain (the substitution by one thread per row -- 16 dependent steps behind two barriers -- took 4 us
+// of a 10 us panel).
 // Thread t of a follower: wave w = t >> 6 owns columns 16w..16w+15 of tile (i, k); lane (r16 = lane & 15, cg = lane >> 4)
 // holds rows r16 + 16 i (i < 8) x columns 16w + 4cg + e (e < 4):  a[4 i + e].
 template <bool WITH_D1, int H>
 __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ S,
                                              int i_tile, int k_blk, const CholFlags& fl, double* wk, double (&a)[32],
-                                             double (&d)[18]) {
+                                             double (&d)[18], unsigned* xf) {
+    // xf (rows k+1, k+2 only): raised per panel once its 16 columns of L(i, k) are in S -- the gated update of row k+2 consumes
+    // them chunk by chunk while the block is still being factored
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), r16 = lane & 15, cg = lane >> 4;
     double* LPt = wk;                        // [16][WK_LS]
-    double* XB = wk + 16 * WK_LS;            // [128][17]
-    double* idl_s = XB + TILE * WK_XS;       // [16]
+    double* XB = wk + 16 * WK_LS;            // [128][17]  panel entries before the solve
+    double* XS = XB + TILE * WK_XS;          // [128][17]  x = the 16 new columns of L(i, k)
+    double* W16s = XS + TILE * WK_XS;        // [16][16]
     const double* Lkk = Lmat + (int64_t)k_blk * TILE * (ld + 1);
     const int ty = (t & 255) >> 4, tx = t & 15;
     for (int p = 0; p < CH_PANELS; ++p) {
@@ -138,7 +146,7 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
                 double* dst = LPt + (4 * mq) * WK_LS + i;
                 dst[0] = v0; dst[WK_LS] = v1; dst[2 * WK_LS] = v2; dst[3 * WK_LS] = v3;
             }
-            if (t < 16) idl_s[t] = ld_agent(fl.idl_g + k_blk * TILE + 16 * p + t);
+            if (t < 256) W16s[t] = ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p) * 256 + t);
         }
         if (w == p) {   // the wave that holds the panel's columns hands them to the row solvers
 #pragma unroll
@@ -148,16 +156,27 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
         }
         __syncthreads();
         if (WITH_D1 && t == 0 && k_blk == 1) CH_MARK(3584 + 8 * p + 0);
-        if (t < TILE) {   // one thread per row: 16 new entries of L(i, k)
-            double r[16];
+        {   // thread (row = t & 127, part = t >> 7): x[4 part .. 4 part + 3] = sum_k r[k] W16[c][k]
+            const int row = t & 127, part = t >> 7;
+            double r[16], x4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < 16; ++c) r[c] = XB[t * WK_XS + c];
-            solve16(r, LPt + 16 * p, idl_s);
+            for (int c = 0; c < 16; ++c) r[c] = XB[row * WK_XS + c];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) XB[t * WK_XS + c] = r[c];
-            double* Srow = S + ((int64_t)i_tile * TILE + t) * ld + (int64_t)k_blk * TILE + 16 * p;
+            for (int cc = 0; cc < 4; ++cc) {
+                const d2* wrow = reinterpret_cast<const d2*>(W16s + (4 * part + cc) * 16);
 #pragma unroll
-            for (int c = 0; c < 16; ++c) st_agent(Srow + c, r[c]);
+                for (int k2 = 0; k2 < 8; ++k2) {
+                    const d2 wv = wrow[k2];
+                    x4[cc] += r[2 * k2] * wv.x;
+                    x4[cc] += r[2 * k2 + 1] * wv.y;
+                }
+            }
+            double* Srow = S + ((int64_t)i_tile * TILE + row) * ld + (int64_t)k_blk * TILE + 16 * p + 4 * part;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                XS[row * WK_XS + 4 * part + cc] = x4[cc];
+                st_agent(Srow + cc, x4[cc]);
+            }
         }
         __syncthreads();
         if (WITH_D1 && t == 0 && k_blk == 1) CH_MARK(3584 + 8 * p + 1);
@@ -168,7 +187,7 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
                 const d2 l01 = *reinterpret_cast<const d2*>(lp + m * WK_LS), l23 = *reinterpret_cast<const d2*>(lp + m * WK_LS + 2);
                 double xv[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xv[i] = XB[(r16 + 16 * i) * WK_XS + m];
+                for (int i = 0; i < 8; ++i) xv[i] = XS[(r16 + 16 * i) * WK_XS + m];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     a[4 * i + 0] -= xv[i] * l01.x;
@@ -179,26 +198,11 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
             }
         }
         if (WITH_D1 && t == 511 && k_blk == 1) CH_MARK(3584 + 8 * p + 2);
-        if constexpr (WITH_D1) {
-            double acc[18];
-#pragma unroll
-            for (int s = 0; s < 18; ++s) acc[s] = 0.0;
-#pragma unroll 4
-            for (int m = 0; m < 16; ++m) {
-                double li[8], lk[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    li[u] = XB[(16 * u + ty) * WK_XS + m];
-                    lk[u] = XB[(16 * u + tx) * WK_XS + m];
-                }
-#pragma unroll
-                for (int s = 0; s < 18; ++s) acc[s] += li[blk_bi(2 * s + H)] * lk[blk_bj(2 * s + H)];
-            }
-#pragma unroll
-            for (int s = 0; s < 18; ++s) d[s] -= acc[s];
-        }
+        if constexpr (WITH_D1) d1_rank16<H>(XS, d);
         if (WITH_D1 && t == 511 && k_blk == 1) CH_MARK(3584 + 8 * p + 3);
+        if (xf) release_wg();   // the S stores of this panel were issued two phases ago: they have landed by now
         __syncthreads();   // LPt / XB are rewritten by the next panel
+        if (xf && t == 0) flag_set(xf + p, 1u);
         if (WITH_D1 && t == 0) CH_MARK(2048 + k_blk * CH_PANELS + p);
     }
 }
@@ -207,10 +211,22 @@ __device__ __forceinline__ void load_row_piece(const double* __restrict__ Lmat, 
                                                double (&a)[32]) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, r16 = lane & 15, cg = lane >> 4;
     const double* base = Lmat + ((int64_t)i_tile * TILE + r16) * ld + (int64_t)k_blk * TILE + 16 * w + 4 * cg;
+    d2 v[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
+        ld_agent_x2_issue(base + (int64_t)16 * i * ld, v[2 * i]);
+        ld_agent_x2_issue(base + (int64_t)16 * i * ld + 2, v[2 * i + 1]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                 :
+                 : "memory");
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[4 * i + e] = ld_agent(base + (int64_t)16 * i * ld + e);
+    for (int i = 0; i < 16; ++i) {
+        a[2 * i] = v[i].x;
+        a[2 * i + 1] = v[i].y;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -220,7 +236,7 @@ __device__ __forceinline__ void load_row_piece(const double* __restrict__ Lmat, 
 // and its flag is raised: that is what the followers are waiting for.
 // ------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void publish_panel(double* __restrict__ Lblk, int64_t ld, const double* a, const double* dl,
-                                              const double* idl, double* idl_out, int P, int tid) {
+                                              const double* w16s, double* w16_out, int P, int tid) {
     // columns P..P+15 of L_kk, rows P..127: thread (i = tid & 127, h = tid >> 7) writes 8 columns = 64 B
     const int i = tid & 127, h = tid >> 7;
     if (i >= P) {
@@ -231,7 +247,7 @@ __device__ __forceinline__ void publish_panel(double* __restrict__ Lblk, int64_t
             st_agent(dst + c, (i > c0) ? a[c0 * PF_LD + i] : (i == c0 ? dl[i] : 0.0));
         }
     }
-    if (tid < 16) st_agent(idl_out + P + tid, idl[P + tid]);
+    st_agent(w16_out + tid, w16s[tid]);   // 256 publishing threads, 256 entries
 }
 
 __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, double* __restrict__ Lblk, int64_t ld,
@@ -239,12 +255,27 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool act = tid < PF_THREADS;
     unsigned* pflag = fl.panel + k_blk * CH_PANELS;
-    double* idl_out = fl.idl_g + k_blk * TILE;
+    double* w16s = idl + TILE;   // [16][16] inverse of the current pivot block
     if (wave == 0) factor16(a, dl, idl, 0, lane, info, row0);
     __syncthreads();
     for (int jb = 0; jb < CH_PANELS; ++jb) {
         const int P = 16 * jb;
         const int base = P + 16, m = TILE - base;
+        if (tid >= PF_THREADS && tid < PF_THREADS + 16) {
+            // W16 = inverse of the pivot block (column cc per thread, substitution in registers) for the followers; runs on an
+            // otherwise idle wave beside the row solves
+            const int cc = tid - PF_THREADS;
+            double wv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = 0; k < i; ++k) sacc += a[(P + k) * PF_LD + P + i] * wv[k];  // wv[k] = 0 for k < cc
+                wv[i] = (i < cc) ? 0.0 : (i == cc ? idl[P + i] : -sacc * idl[P + i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) w16s[i * 16 + cc] = wv[i];
+        }
         if (act && tid < m) {  // row solves below the pivot block
             const int i = base + tid;
             double x[16], rw[16];
@@ -263,7 +294,7 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
         // Panel jb is final.  The four waves that take no part in the factorisation publish it -- their stores and the wait for
         // them to land stay off the pivot chain: they are issued here, awaited behind the next barrier, and each wave then
         // adds 1 to the panel's flag (followers wait for 4).
-        if (!act) publish_panel(Lblk, ld, a, dl, idl, idl_out, P, tid - PF_THREADS);
+        if (!act) publish_panel(Lblk, ld, a, dl, w16s, fl.w16_g + ((size_t)k_blk * CH_PANELS + jb) * 256, P, tid - PF_THREADS);
         if (m > 0 && act) {   // rank-16 update of the next pivot block
             const int ty = tid >> 4, tx = tid & 15;
             double acc = 0.0;
@@ -321,14 +352,40 @@ __device__ __forceinline__ void d1_to_image(double* a, const double (&d)[18]) {
     }
 }
 
+// rank-16 update of the diagonal tile held in registers (18 sub-block elements per thread) with the panel rows in XB
+template <int H>
+__device__ __forceinline__ void d1_rank16(const double* XB, double (&d)[18]) {
+    const int t = threadIdx.x, ty = (t & 255) >> 4, tx = t & 15;
+    double acc[18];
+#pragma unroll
+    for (int s = 0; s < 18; ++s) acc[s] = 0.0;
+#pragma unroll 4
+    for (int m = 0; m < 16; ++m) {
+        double li[8], lk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            li[u] = XB[(16 * u + ty) * WK_XS + m];
+            lk[u] = XB[(16 * u + tx) * WK_XS + m];
+        }
+#pragma unroll
+        for (int s = 0; s < 18; ++s) acc[s] += li[blk_bi(2 * s + H)] * lk[blk_bj(2 * s + H)];
+    }
+#pragma unroll
+    for (int s = 0; s < 18; ++s) d[s] -= acc[s];
+}
+
+// ---- role 1 (workgroups 0, 1): row owner.  During block r-1 it only keeps the diagonal tile (r, r) up to date -- in
+// registers, one rank-16 update per panel of L(r, r-1), which the critical follower of row r delivers through S -- and
+// during block r it runs the pivot chain on that tile.
 template <int H>
 __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t ld, double* __restrict__ S, int T,
                                             const CholFlags& fl, int* info, double* sm, int w) {
     double* a = sm;
     double* dl = sm + TILE * PF_LD;
     double* idl = dl + TILE;
+    double* XB = sm;   // [128][17] while the image is not in use
     const int tid = threadIdx.x;
-    double ar[32], d[18];
+    double d[18];
     for (int r = w; r < T; r += 2) {
         if (r == 0) {   // tile (0, 0) straight from HBM into the image
             const double* Lblk = Lmat;
@@ -338,17 +395,30 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             }
             __syncthreads();
         } else {
-            // follower role during block r-1: tiles (r, r-1) and (r, r) must carry every update from blocks <= r-2
-            if (r >= 2) {
-                if (tid == 0) flag_wait_ge(fl.crit + (r - 2), fl.crit_want, fl.abort);
+            if (r >= 2) {   // tile (r, r) carries every update from blocks <= r-2 once the gated update of block r-2 is in memory
+                if (tid == 0) { CH_MARK(3300 + 4 * (r - 2) + 3); flag_wait_ge(fl.crit + (r - 2), fl.crit_want, fl.abort); CH_MARK(3400 + r); }
                 __syncthreads();
             }
-            load_row_piece(Lmat, ld, r, r - 1, ar);
             d1_load<H>(Lmat, ld, r, d);
-            follow_block<true, H>(Lmat, ld, S, r, r - 1, fl, sm, ar, d);
-            release_wg();
-            __syncthreads();
-            if (tid == 0) flag_set(fl.solved + (r - 1), 1u);   // L(r, r-1) is complete in S
+            if (tid == 0) CH_MARK(3500 + r);
+            const unsigned* xf = fl.xp + ((size_t)(r - 1) * 2 + 0) * CH_PANELS;
+            const double* Sx = S + ((int64_t)r * TILE + (tid >> 2)) * ld + (int64_t)(r - 1) * TILE + 4 * (tid & 3);
+            for (int p = 0; p < CH_PANELS; ++p) {
+                if (tid == 0) { flag_wait_ge(xf + p, 1u, fl.abort); CH_MARK(1024 + (r - 1) * CH_PANELS + p); }
+                __syncthreads();
+                {   // panel p of L(r, r-1): 128 rows x 16 columns, 32 B per thread
+                    d2 v0, v1;
+                    ld_agent_x2_issue(Sx + 16 * p, v0);
+                    ld_agent_x2_issue(Sx + 16 * p + 2, v1);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1) : : "memory");
+                    double* dst = XB + (tid >> 2) * WK_XS + 4 * (tid & 3);
+                    dst[0] = v0.x; dst[1] = v0.y; dst[2] = v1.x; dst[3] = v1.y;
+                }
+                __syncthreads();
+                d1_rank16<H>(XB, d);
+                __syncthreads();
+                if (tid == 0) CH_MARK(2048 + (r - 1) * CH_PANELS + p);
+            }
             d1_to_image<H>(a, d);
             __syncthreads();
         }
@@ -359,22 +429,147 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
     }
 }
 
+// storing waves of the first row tile of block k's far update (host: nt64 = 2 (T - k - 2); every workgroup adds 4)
+__device__ __forceinline__ unsigned rest_want(int T, int k) { return 4u * 2u * (unsigned)(T - k - 2); }
+
+// ---- role 2 (workgroups 2, 3): critical followers.  Row r is followed twice -- as "row k+2" during block k = r-2 and as
+// "row k+1" during block k = r-1 -- always by the workgroup of its parity, so at any block the two rows next to the pivot
+// are each in one workgroup's registers and their panels of L reach S (and the flags xp) 16 columns at a time.
+__device__ __forceinline__ void crit_follower(double* __restrict__ Lmat, int64_t ld, double* __restrict__ S, int T,
+                                              const CholFlags& fl, double* sm, int pf) {
+    const int tid = threadIdx.x;
+    double ar[32], dd[18];
+    for (int k = 0; k + 1 < T; ++k) {
+        const int r = (((k + 1) & 1) == pf) ? k + 1 : k + 2;
+        if (r >= T) continue;
+        if (k >= 1) {   // tile (r, k) must carry block k-1's update: row k+1 gets it from the gated update, row k+2 from the column launch
+            if (tid == 0) {
+                if (r == k + 1) flag_wait_ge(fl.crit + (k - 1), fl.crit_want, fl.abort);
+                else flag_wait_ge(fl.col + (k - 1), 8u, fl.abort);   // tile (k+2, k): first row tile of block k-1's column update
+            }
+            __syncthreads();
+        }
+        load_row_piece(Lmat, ld, r, k, ar);
+        follow_block<false, 0>(Lmat, ld, S, r, k, fl, sm, ar, dd, fl.xp + ((size_t)k * 2 + (r - k - 1)) * CH_PANELS);
+    }
+}
+
+// ---- role 3 (workgroups 4..7): the update of row k+2 with block k's panel -- the two tiles (k+2, k+1), (k+2, k+2) the
+// chain needs next -- as a GEMM whose contraction index ARRIVES 16 columns at a time: chunk c of L(k+2, k) and L(k+1, k) is
+// consumed as soon as the critical followers raise its flags, so the tiles are final a few microseconds after block k's
+// last panel instead of one launch + one K = 128 GEMM later (the next owner waited 36 us per block for that).  One
+// workgroup per 128 x 64 tile, waves 0-3, the contraction engine's fragment layout (gemm_core.h) on an LDS image staged
+// with agent-scope loads.
+__device__ __forceinline__ void gated_worker(double* __restrict__ Lmat, int64_t ld, const double* __restrict__ S, int T,
+                                             const CholFlags& fl, double* sm, int tj) {
+    double* As = sm;                       // [128][16]
+    double* Bs = sm + TILE * GL_ROW;       // [64][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = (wave & 3) >> 1, wc = wave & 1;
+    const bool act = tid < GEMM_THREADS;
+    const int kq = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
+    const int r7a = 4 * (b >> 1) + t, r7b = 4 * (b & 1) + t;
+    int oa[2], ob[2];
+#pragma unroll
+    for (int S_ = 0; S_ < 2; ++S_) {
+        oa[S_] = ((4 * S_ + kq) ^ r7a) << 1;
+        ob[S_] = ((4 * S_ + kq) ^ r7b) << 1;
+    }
+    const int a_frag = (wr * 64 + r7a) * GL_ROW, b_frag = (wc * 32 + r7b) * GL_ROW;
+    for (int k = 0; k + 2 < T; ++k) {
+        const double* A = S + (int64_t)(k + 2) * TILE * ld + (int64_t)k * TILE;
+        const double* B = S + ((int64_t)(k + 1) * TILE + (int64_t)tj * CTILE) * ld + (int64_t)k * TILE;
+        double* C = Lmat + (int64_t)(k + 2) * TILE * ld + (int64_t)(k + 1) * TILE + (int64_t)tj * CTILE;
+        const int64_t row0 = (int64_t)(k + 2) * TILE, col0 = (int64_t)(k + 1) * TILE + (int64_t)tj * CTILE;
+        const unsigned* fa = fl.xp + ((size_t)k * 2 + 1) * CH_PANELS;
+        const unsigned* fb = tj < 2 ? fl.xp + ((size_t)k * 2 + 0) * CH_PANELS : fa;
+        // The tile's current value (all updates from earlier blocks) is fetched BEFORE the contraction, into the accumulators:
+        // the launch that writes it finishes early in the block, and the read then overlaps the wait for the panels (read in
+        // the epilogue it added ~10 us of scattered agent-scope round trips to the chain's hand-over).
+        if (k >= 1) {
+            if (tid == 0) flag_wait_ge(fl.rest + (k - 1), rest_want(T, k - 1), fl.abort);
+            __syncthreads();
+        }
+        double acc[8][4];   // holds  -C  so that the contraction adds A B' and the store writes  -(acc)
+        if (act) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int r = acc_row(lane, wr, mi);
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    const int cc = acc_col<4>(lane, wc, nj);
+                    acc[mi][nj] = (col0 + cc > row0 + r) ? 0.0 : -ld_agent(C + (int64_t)r * ld + cc);
+                }
+            }
+        }
+        for (int c = 0; c < TILE / KC; ++c) {
+            if (tid == 0) { flag_wait_ge(fa + c, 1u, fl.abort); flag_wait_ge(fb + c, 1u, fl.abort); }
+            __syncthreads();   // (also: the previous chunk's fragments have been read)
+            if (act) {
+                // LDS[row][slot] holds the 16-B segment slot ^ (row & 7) of the row's 128-B chunk (the swizzle of gemm_core.h)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7, seg = slot ^ (row & 7);
+                    const double* src = A + (int64_t)row * ld + c * KC + 2 * seg;
+                    As[row * GL_ROW + 2 * slot] = ld_agent(src);
+                    As[row * GL_ROW + 2 * slot + 1] = ld_agent(src + 1);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7, seg = slot ^ (row & 7);
+                    const double* src = B + (int64_t)row * ld + c * KC + 2 * seg;
+                    Bs[row * GL_ROW + 2 * slot] = ld_agent(src);
+                    Bs[row * GL_ROW + 2 * slot + 1] = ld_agent(src + 1);
+                }
+            }
+            __syncthreads();
+            if (act) mma_chunk_swz<4>(As + a_frag, Bs + b_frag, oa, ob, acc);
+        }
+        if (tid == 0 && tj == 0) CH_MARK(3300 + 4 * k + 0);
+        if (act) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int r = acc_row(lane, wr, mi);
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) {
+                    const int cc = acc_col<4>(lane, wc, nj);
+                    if (col0 + cc > row0 + r) continue;   // the strict upper triangle stays zero
+                    st_agent(C + (int64_t)r * ld + cc, -acc[mi][nj]);
+                }
+            }
+            release_wg();
+            if (lane == 0) atomicAdd(fl.crit + k, 1u);
+        }
+        if (tid == 0 && tj == 0) CH_MARK(3300 + 4 * k + 2);
+        __syncthreads();
+    }
+}
+
+// The persistent chain: 8 workgroups of 512 threads, one per CU (the owners' LDS image fills it).
 __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_chain(double* __restrict__ Lmat, int64_t ld, double* __restrict__ S,
                                                            int T, CholFlags fl, int* __restrict__ info) {
     extern __shared__ double sm[];
-    const int w = blockIdx.x;   // 0 / 1: owns rows w, w + 2, ...
-    if ((threadIdx.x >> 8) == 0) chain_owner<0>(Lmat, ld, S, T, fl, info, sm, w);
-    else chain_owner<1>(Lmat, ld, S, T, fl, info, sm, w);
+    const int b = blockIdx.x;
+    if (b < 2) {
+        if ((threadIdx.x >> 8) == 0) chain_owner<0>(Lmat, ld, S, T, fl, info, sm, b);
+        else chain_owner<1>(Lmat, ld, S, T, fl, info, sm, b);
+    } else if (b < 4) {
+        crit_follower(Lmat, ld, S, T, fl, sm, b - 2);
+    } else {
+        gated_worker(Lmat, ld, S, T, fl, sm, b - 4);
+    }
 }
 
-// one workgroup per tile (i, k), i = k + 2 + blockIdx.x: solves L(i, k) panel by panel as block k's pivot chain runs
+// bulk followers: one workgroup per tile (i, k), i = k + 3 + blockIdx.x: solves L(i, k) panel by panel as block k's pivot chain runs
 __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_follow(const double* __restrict__ Lmat, int64_t ld,
                                                             double* __restrict__ S, int k_blk, CholFlags fl) {
     extern __shared__ double sm[];
-    const int i_tile = k_blk + 2 + blockIdx.x;
+    const int i_tile = k_blk + 3 + blockIdx.x;
     double ar[32], d[18];
     load_row_piece(Lmat, ld, i_tile, k_blk, ar);
-    follow_block<false, 0>(Lmat, ld, S, i_tile, k_blk, fl, sm, ar, d);
+    follow_block<false, 0>(Lmat, ld, S, i_tile, k_blk, fl, sm, ar, d, nullptr);
+    release_wg();
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(fl.fol + k_blk, 1u);   // this row of L(:, k) is complete in S
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -240,33 +240,72 @@ __device__ __forceinline__ void trailing_dispatch(double* a, int P, int nb, int 
         default: break;
     }
 }
-// A1: the 16 x 16 diagonal block at (P, P) in registers, lane r (< 16) of ONE wave holds row r.  Finished columns go to
-// the mirror position, the diagonal to dl / idl.
-__device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int P, int lane, int* info, int row0) {
-    const int r = lane & 15;
-    double row[16], dkeep[16];
+// A1: the 16 x 16 diagonal block at (P, P), factored by ONE wave with all 64 lanes: lane (r = lane & 15, q = lane >> 4) holds
+// A[r][4q .. 4q+3] of the FULL symmetric block.  Step j needs three things from other lanes, none of them through LDS
+// memory and none on the reciprocal-square-root chain (they move the un-scaled entries; the scaling by 1/L_jj follows):
+//     a_jj            v_readlane from lane (j, j >> 2)                          (wave-uniform)
+//     a[r][j]         ds_bpermute from lane (r, j >> 2): the row's entry in column j
+//     a[j][4q + e]    ds_swizzle "lane j of my 16-row": row j's entries in my columns -- by symmetry these ARE the
+//                     multipliers l_k of my columns, so no per-column broadcast is needed
+// The first version kept a row per lane (16 of 64 lanes busy) and fetched every l_k with its own v_readlane pair:
+// 240 pairs per block, 8.7 k cycles per block on the critical path of every panel.  Same arithmetic, same operation order:
+// the factor is bit-identical.  Finished columns go to the mirror position, the diagonal to dl / idl.
+template <int J>
+__device__ __forceinline__ double row_bcast16(double v) {   // value of lane J of this lane's row of 16
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, (J << 5) | 0x10);
+    hi = __builtin_amdgcn_ds_swizzle(hi, (J << 5) | 0x10);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_fetch(double v, int byte_addr) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_bpermute(byte_addr, lo);
+    hi = __builtin_amdgcn_ds_bpermute(byte_addr, hi);
+    return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ void factor16_step(double (&v)[4], int r, int q, double* dl, double* idl, int P, int lane, int* info,
+                                              int row0) {
+    constexpr int QJ = J >> 2, EJ = J & 3;
+    double ajj = readlane_f64(v[EJ], J + 16 * QJ);
+    const double arj = lane_fetch(v[EJ], 4 * (r + 16 * QJ));
+    double ajk[4];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) row[k] = a[(P + r) * PF_LD + P + k];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        double ajj = readlane_f64(row[j], j);
-        if (!(ajj > 0.0)) {
-            if (lane == 0) atomicCAS(info, 0, row0 + P + j + 1);
-            ajj = 1.0;
-        }
-        const double inv = fast_rsqrt(ajj);
-        const double lj = row[j] * inv;  // lane j: the pivot L_jj = ajj * inv
-        dkeep[j] = ajj * inv;
-        row[j] = (r == j) ? inv : lj;    // keep 1/L_jj on the diagonal
-#pragma unroll
-        for (int k = j + 1; k < 16; ++k) row[k] -= lj * readlane_f64(lj, k);
+    for (int e = 0; e < 4; ++e) ajk[e] = row_bcast16<J>(v[e]);
+    if (!(ajj > 0.0)) {
+        if (lane == 0) atomicCAS(info, 0, row0 + P + J + 1);
+        ajj = 1.0;
     }
-    if (lane < 16) {
+    const double inv = fast_rsqrt(ajj);
+    const double lr = arj * inv;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (r > j) a[(P + j) * PF_LD + P + r] = row[j];  // mirror
-            if (r == j) { idl[P + j] = row[j]; dl[P + j] = dkeep[j]; }
-        }
+    for (int e = 0; e < 4; ++e) {
+        const double lk = ajk[e] * inv;
+        if (4 * q + e > J) v[e] -= lr * lk;
+    }
+    if (q == QJ) v[EJ] = lr;                       // column J is final: L[r][J] for r > J (rows <= J: dead entries)
+    if (lane == J + 16 * QJ) { dl[P + J] = ajj * inv; idl[P + J] = inv; }
+}
+__device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int P, int lane, int* info, int row0) {
+    const int r = lane & 15, q = lane >> 4;
+    double v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * q + e;
+        v[e] = (k <= r) ? a[(P + r) * PF_LD + P + k] : a[(P + k) * PF_LD + P + r];   // lower triangle, mirrored into the upper
+    }
+    factor16_step<0>(v, r, q, dl, idl, P, lane, info, row0);   factor16_step<1>(v, r, q, dl, idl, P, lane, info, row0);
+    factor16_step<2>(v, r, q, dl, idl, P, lane, info, row0);   factor16_step<3>(v, r, q, dl, idl, P, lane, info, row0);
+    factor16_step<4>(v, r, q, dl, idl, P, lane, info, row0);   factor16_step<5>(v, r, q, dl, idl, P, lane, info, row0);
+    factor16_step<6>(v, r, q, dl, idl, P, lane, info, row0);   factor16_step<7>(v, r, q, dl, idl, P, lane, info, row0);
+    factor16_step<8>(v, r, q, dl, idl, P, lane, info, row0);   factor16_step<9>(v, r, q, dl, idl, P, lane, info, row0);
+    factor16_step<10>(v, r, q, dl, idl, P, lane, info, row0);  factor16_step<11>(v, r, q, dl, idl, P, lane, info, row0);
+    factor16_step<12>(v, r, q, dl, idl, P, lane, info, row0);  factor16_step<13>(v, r, q, dl, idl, P, lane, info, row0);
+    factor16_step<14>(v, r, q, dl, idl, P, lane, info, row0);  factor16_step<15>(v, r, q, dl, idl, P, lane, info, row0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * q + e;
+        if (k < r) a[(P + k) * PF_LD + P + r] = v[e];   // mirror
     }
 }
 
@@ -380,6 +419,9 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
             if (tx <= ty) a[(base + ty) * PF_LD + base + tx] -= acc;
         }
         __syncthreads();
+#ifdef BOHIP_POTF2_CLOCKS
+        const long long tq0 = clock64();
+#endif
         if (wave == 0) {
             factor16(a, dl, idl, base, lane, info, row0);
         } else {
@@ -391,6 +433,11 @@ __global__ __launch_bounds__(PF_THREADS) void k_potf2_inv(double* __restrict__ L
             else if (wave == 2) trailing_dispatch<true, 1>(a, P, m >> 4, ty0, tx0);
             else trailing_dispatch<true, 2>(a, P, m >> 4, ty0, tx0);
         }
+#ifdef BOHIP_POTF2_CLOCKS
+        if (tid == 0) pf_clocks[10] += clock64() - tq0;     // factor16 alone (wave 0)
+        if (tid == 64) pf_clocks[11] += clock64() - tq0;    // trailing update alone (wave 1)
+        if (tid == 192) pf_clocks[12] += clock64() - tq0;   // trailing update alone (wave 3)
+#endif
         __syncthreads();
         PF_CLK(3);
     }
@@ -442,7 +489,10 @@ struct GemmNTParams {
     // tile adds 4), so a consumer can wait for 4 x gridDim.x x gridDim.y.  abort: see flag_wait_ge.
     const unsigned* wait_flag;
     unsigned wait_val;
+    const unsigned* wait_flag2;   // optional second flag, same rule
+    unsigned wait_val2;
     unsigned* signal;
+    unsigned* signal_row0;        // the workgroups of the first row tile (ti == 0, scheduled first) also count here
     unsigned* abort_flag;
 };
 
@@ -456,12 +506,14 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
                          (p.total_t > 0 && (p.row_t0 + z * p.row_ts + ti >= p.total_t || p.col_t0 + z * p.col_ts + (tj >> 1) >= p.total_t));
     if (no_tile) {
         if (p.signal && threadIdx.x == 0) atomicAdd(p.signal, 4u);
+        if (p.signal_row0 && ti == 0 && threadIdx.x == 0) atomicAdd(p.signal_row0, 4u);
         return;
     }
     if (p.wait_flag) {
         if (threadIdx.x == 0) {
             for (long it = 0;; ++it) {
-                if (__hip_atomic_load(p.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val) break;
+                if (__hip_atomic_load(p.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val &&
+                    (!p.wait_flag2 || __hip_atomic_load(p.wait_flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val2)) break;
                 if (p.abort_flag && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
                 if (it > 40000000L) { if (p.abort_flag) atomicExch(p.abort_flag, 1u); break; }
@@ -508,8 +560,9 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
         }
     }
     if (p.signal) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // s_waitcnt vmcnt(0): the agent-scope stores above have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the agent-scope stores above have landed (a workgroup-scope fence emits no such wait)
         if (lane == 0) atomicAdd(p.signal, 1u);
+        if (p.signal_row0 && ti == 0 && lane == 0) atomicAdd(p.signal_row0, 1u);
     }
 }
 

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
     if (fz.tile_cnt != nullptr) {
         __shared__ int s_last;
         const int tile_g = (int)(r_off / CW) + ct;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the agent-scope stores above have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the agent-scope stores above have landed (a workgroup-scope fence emits no such wait)
         __syncthreads();
         if (threadIdx.x == 0) s_last = atomicAdd(fz.tile_cnt + tile_g, 1u) == (unsigned)(T - 1);
         __syncthreads();
@@ -340,7 +340,7 @@ __device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, co
         if (fz.best_out) {
             __hip_atomic_store(&fz.tile_best[tile_g].val, idx >= 0 ? v : -INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&fz.tile_best[tile_g].idx, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile record stored before it is counted
             last = atomicAdd(fz.total_cnt, 1u) == (unsigned)(fz.tiles_total - 1);
         }
     }

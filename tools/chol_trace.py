@@ -32,6 +32,11 @@ dur = [(blk[2*k+1] - blk[2*k]) / 100.0 for k in range(T)]
 gap = [(blk[2*(k+1)] - blk[2*k+1]) / 100.0 for k in range(T - 1)]
 print(f"pivot duration per block: mean {np.mean(dur):.1f} us (min {np.min(dur):.1f}, max {np.max(dur):.1f}); gap to next pivot start: mean {np.mean(gap):.1f} us (min {np.min(gap):.1f} max {np.max(gap):.1f}); total {us(blk[2*(T-1)+1]):.1f} us")
 
+for k in range(min(T - 2, 4)):
+    g_ = t[3300 + 4 * k: 3300 + 4 * k + 4]
+    r = k + 2
+    print(f"block {k}: gated row-{r} update: chunks done {us(g_[0]):.1f}, pre ok {us(g_[1]):.1f}, stored {us(g_[2]):.1f} | owner of row {r}: starts waiting {us(g_[3]):.1f}, "
+          f"sees crit {us(t[3400 + r]):.1f}, tiles loaded {us(t[3500 + r]):.1f}")
 ph = t[3584:3584 + 64].reshape(8, 8)
 print("block 1, follower phases per panel (us since flag seen): staged, solved+barrier, trailing done (t511), D1 done (t511)")
 for p_ in range(8):

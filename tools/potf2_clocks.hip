@@ -20,7 +20,8 @@ int main(){
     hipMemcpyFromSymbol(z,HIP_SYMBOL(pf_clocks),sizeof(z));
     long long tot=0; for(int i=0;i<10;i++) tot+=z[i];
     printf("rep %d: %.1f us total, %lld cycles (s_memtime)\n",rep,ms*1e3,tot);
-    if(rep==2) for(int i=0;i<10;i++) printf("  %-18s %8lld cyc  %5.1f%%\n",names[i],z[i],100.0*z[i]/tot);
+    if(rep==2) { for(int i=0;i<10;i++) printf("  %-18s %8lld cyc  %5.1f%%\n",names[i],z[i],100.0*z[i]/tot);
+      printf("  inside A3 (x7): factor16 alone %lld cyc, trailing alone wave1 %lld / wave3 %lld cyc\n", z[10], z[11], z[12]); }
   }
   std::vector<double> L(n*n),W(n*n); hipMemcpy(L.data(),dA,n*n*8,hipMemcpyDeviceToHost); hipMemcpy(W.data(),dW,n*n*8,hipMemcpyDeviceToHost);
   double e1=0,e2=0; for(int i=0;i<n;i++)for(int j=0;j<n;j++){ double s=0,t=0; for(int k=0;k<n;k++){ s+=L[i*n+k]*L[j*n+k]; t+=L[i*n+k]*W[k*n+j]; } e1=fmax(e1,fabs(s-A[i*n+j])); e2=fmax(e2,fabs(t-(i==j))); }
