@@ -239,8 +239,10 @@ static int g_split = 1;   // split-K path for batches of a few hundred candidate
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
-static int g_chol_df = 0;  // BOHIP_CHOL_DATAFLOW=1: dataflow factorisation (kernels_chol.hip).  Correct (same tests), but measured slower than
-                            // the launch-chained form (N=3000: 3.08 vs 2.77 ms; N=10^4: 21 vs 13.3 ms), see DESIGN.md section 6: opt-in
+static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <= T <= g_chol_df_tmax row tiles: N=3000 2.19 vs 2.71 ms, N=1000 0.66
+                            // vs 0.82 ms.  Beyond ~36 tiles its one-tier K=128 bulk updates lose to the two-tier launch chain (N=6000: 7.4 vs
+                            // 5.8 ms), below 3 there is nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every T >= 2.
+static int g_chol_df_tmax = 36;
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
@@ -444,7 +446,7 @@ static int refit(bohip_gp* g) {
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "cholesky");
-    if (g_chol_df) {
+    if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2)) {
         CHK(cholesky_dataflow(g, T));
         t_end(g);
         t_begin(g, "tri_inverse");
@@ -458,7 +460,14 @@ static int refit(bohip_gp* g) {
         CHK(check_info(g));
         unsigned aborted = 0;
         HIPCHK(hipMemcpy(&aborted, g->dchol_flags + (size_t)T * (3 * CH_PANELS + 7), sizeof(unsigned), hipMemcpyDeviceToHost));
-        if (aborted) { g->stale = true; return fail(BOHIP_E_HIP, "dataflow factorisation: a dependency wait timed out"); }
+        if (aborted) {
+            // a flag never arrived (e.g. two of the three streams share a hardware queue on this system): every wait has
+            // returned, nothing hangs; the factor is garbage.  Fall back to the launch-chained form for the rest of the process.
+            fprintf(stderr, "libbohip: dataflow factorisation timed out on a dependency; using the launch-chained form from now on\n");
+            g_chol_df = 0;
+            g->stale = true;
+            return refit(g);
+        }
         g->stale = false;
         g->n_factored = N;
         g->refits++;

@@ -718,7 +718,7 @@ print("RESULT" + json.dumps(out))
 ''' % ROOT
     res = {}
     for flag in ("0", "1"):
-        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BOHIP_CHOL_DATAFLOW=flag), capture_output=True,
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BOHIP_CHOL_DATAFLOW={"0": "0", "1": "2"}[flag]), capture_output=True,
                            text=True, timeout=600)
         assert o.returncode == 0, o.stderr[-2000:]
         res[flag] = json.loads([l for l in o.stdout.splitlines() if l.startswith("RESULT")][-1][6:])

@@ -1,0 +1,17 @@
+"""Cholesky time of the two factorisation paths over N (run once per path: BOHIP_CHOL_DATAFLOW=0/1)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, bohip
+rng = np.random.default_rng(0)
+for N in (500, 1000, 2000, 3000, 4000, 5000, 6000, 8000):
+    d = 8
+    X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
+    m = bohip.ElasticGPE(d, kernel=bohip.SEArd(np.full(d, np.log(0.5)), 0.0), logNoise=-2.0, capacity=N)
+    m.append_(X.T, y)
+    m.enable_timing(True)
+    best = 1e9
+    for _ in range(5):
+        m.set_params_(logNoise=-2.0); m.fit_()
+        best = min(best, dict(m.timing())["cholesky"])
+    print(f"N={N}: cholesky {best:.3f} ms = {N**3/3/best/1e9:.2f} TF/s", flush=True)
+    m.close()
