@@ -71,6 +71,7 @@ struct bohip_gp {
     hipStream_t stream = nullptr, own_stream = nullptr;
     hipStream_t side_stream = nullptr;            // bulk trailing updates of the factorisation run here (look-ahead)
     hipEvent_t ev_panels = nullptr, ev_bulk = nullptr;
+    hipStream_t col_stream = nullptr;             // dataflow factorisation: bulk followers + column updates (high priority)
     hipStream_t inv_stream = nullptr;             // W = L^-1 grows block by block beside the factorisation's diagonal chain
     hipEvent_t ev_blk = nullptr, ev_inv = nullptr;
     hipEvent_t ev_gate = nullptr;                 // a diagonal-block kernel is about to start: release one piece of the pending bulk update
@@ -192,6 +193,8 @@ static int free_model(bohip_gp* g) {
     if (g->dchol_flags) { hipFree(g->dchol_flags); g->dchol_flags = nullptr; }
     return 0;
 }
+static size_t chol_flag_words(int T);
+static size_t chol_abort_word(int T);
 static int alloc_model(bohip_gp* g, int64_t cap) {
     free_model(g);
     // chunk buffers are sized by ld: drop them, they are re-made on demand
@@ -215,7 +218,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
     HIPCHK(hipMalloc(&g->dApp, (size_t)APP_ROWS * g->ld * 8));
     {
         const size_t Tm = (size_t)(g->ld / TILE) + 1;
-        HIPCHK(hipMalloc(&g->dchol_flags, (Tm * (3 * CH_PANELS + 7) + 4) * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&g->dchol_flags, chol_flag_words((int)std::min<size_t>(Tm, 48)) * sizeof(unsigned)));   // dataflow path: T <= 36
         HIPCHK(hipMalloc(&g->dchol_idl, Tm * CH_PANELS * 256 * 8));   // W16 of every pivot block
     }
     HIPCHK(hipMemsetAsync(g->dL, 0, mat, g->stream));
@@ -349,9 +352,12 @@ static int inverse_join(bohip_gp* g, hipStream_t st, int P, int nb) {
 
 // ---- A2, dataflow form (kernels_chol.hip): ONE persistent chain launch on the critical stream; the panel followers and the
 // flag-gated trailing updates of every block are enqueued up front on the side stream.  No host events inside the factorisation.
+static size_t chol_abort_word(int T) { return (size_t)T * (CH_PANELS + 7) + (size_t)T * T * (CH_PANELS + 1); }   // see the layout in cholesky_dataflow
+static size_t chol_flag_words(int T) { return chol_abort_word(T) + 4; }
 static int cholesky_dataflow(bohip_gp* g, int T) {
     const int64_t ld = g->ld;
     CholFlags fl{};
+    fl.T = T;
     fl.panel = g->dchol_flags;
     fl.solved = fl.panel + (size_t)T * CH_PANELS;
     fl.crit = fl.solved + T;
@@ -360,60 +366,52 @@ static int cholesky_dataflow(bohip_gp* g, int T) {
     fl.farall = fl.col + T;
     fl.fol = fl.farall + T;
     fl.colall = fl.fol + T;
-    fl.xp = fl.colall + T;
-    fl.abort = fl.xp + (size_t)T * 2 * CH_PANELS;
+    fl.colr = fl.colall + T;
+    fl.xp = fl.colr + (size_t)T * T;
+    fl.abort = fl.xp + (size_t)T * T * CH_PANELS;
     fl.w16_g = g->dchol_idl;
     fl.crit_want = 16u;   // the row-(k+2) update: 4 workgroups x 4 storing waves
     fl.panel_want = 4u;   // four publishing waves per panel
-    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, ((size_t)T * (3 * CH_PANELS + 7) + 4) * sizeof(unsigned), g->stream));
+    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
     HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
-    HIPCHK(hipStreamWaitEvent(g->side_stream, g->ev_panels, 0));
-    // ONE persistent launch: row owners, critical followers (rows k+1, k+2) and the gated update of row k+2 (kernels_chol.hip)
+    // Four launches that live for the whole factorisation and talk through flags:
+    //   critical stream: the chain (row owners, critical followers of rows k+1 / k+2, gated update of row k+2)
+    //   two more       : one follower workgroup per row >= 3, two column-updater workgroups per row >= 3
     hipLaunchKernelGGL(k_chol_chain, dim3(T > 1 ? 8 : 1), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamWaitEvent(g->inv_stream, g->ev_panels, 0));
-    for (int k = 0; k + 3 < T; ++k) {
-        // Rows >= k+3 (rows k+1, k+2 belong to the chain launch).  Look-ahead split of their update with L(:, k):
-        //   side stream : followers (k_chol_follow) -> update of COLUMN k+1 only -- what block k+1's followers need
-        //   third stream: update of the columns >= k+2 (the bulk of the flops), behind the followers via a counter
-        const int mt = T - (k + 3);
-        hipLaunchKernelGGL(k_chol_follow, dim3(mt), dim3(CH_THREADS), WK_LDS_DOUBLES * 8, g->side_stream, g->dL, ld, g->dS, k, fl);
+    if (T > 3) {
+        HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
+        HIPCHK(hipStreamWaitEvent(g->side_stream, g->ev_panels, 0));
+        HIPCHK(hipStreamWaitEvent(g->inv_stream, g->ev_panels, 0));
+        hipLaunchKernelGGL(k_chol_rows, dim3(T - 3), dim3(CH_THREADS), WK_LDS_DOUBLES * 8, g->col_stream, g->dL, ld, g->dS, T, fl);
+        hipLaunchKernelGGL(k_chol_cols, dim3(2 * (T - 3)), dim3(GEMM_THREADS), 0, g->side_stream, g->dL, ld, g->dS, T, fl);
         HIPCHK(hipGetLastError());
-        // The far update starts behind the followers through a host-side event, NOT an in-kernel wait: its hundreds of
-        // workgroups would otherwise sit in every CU slot spinning for followers that can then never be scheduled
-        // (observed: time-out at T = 24).  In-kernel waits are kept for launches of a few dozen workgroups only.
-        HIPCHK(hipEventRecord(g->ev_gate, g->side_stream));
-        HIPCHK(hipStreamWaitEvent(g->inv_stream, g->ev_gate, 0));
-        const unsigned* last1 = fl.xp + ((size_t)k * 2 + 0) * CH_PANELS + (CH_PANELS - 1);   // L(k+1, k) complete
-        const unsigned* last2 = fl.xp + ((size_t)k * 2 + 1) * CH_PANELS + (CH_PANELS - 1);   // L(k+2, k) complete
-        GemmNTParams u{};
-        u.A = g->dS + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; u.lda = ld;
-        u.B = g->dS + (int64_t)(k + 1) * TILE * ld + (int64_t)k * TILE; u.ldb = ld;
-        u.C = g->dL + (int64_t)(k + 3) * TILE * ld + (int64_t)(k + 1) * TILE; u.ldc = ld;
-        u.mt = mt; u.nt64 = 2; u.kc = TILE / KC; u.alpha = -1.0; u.beta = 1.0;
-        u.wait_flag = last1; u.wait_val = 1u;
-        if (k >= 1) {   // block k-1's far update wrote these tiles too (column k+1 was "far" for it): it must be complete
-            u.wait_flag2 = fl.farall + (k - 1);
-            u.wait_val2 = 4u * (unsigned)(T - k - 2) * 2u * (unsigned)(T - k - 1);
-        }
-        u.signal = fl.colall + k;           // (selects the agent-scope stores; nobody waits for the whole launch)
-        u.signal_row0 = fl.col + k;         // tile (k+3, k+1): what the critical follower of row k+3 waits for
-        u.abort_flag = fl.abort;
-        CHK(launch_gemm_nt(g, u, 1, g->side_stream));
+    }
+    for (int k = 0; k + 3 < T; ++k) {
+        // fourth stream: the rest of block k's update -- rows >= k+3, columns >= k+2 -- on the MFMA engine; each workgroup
+        // waits for the last panel of the two rows of L(:, k) it reads
         GemmNTParams f{};
         f.A = g->dS + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; f.lda = ld;
         f.B = g->dS + (int64_t)(k + 2) * TILE * ld + (int64_t)k * TILE; f.ldb = ld;
         f.C = g->dL + (int64_t)(k + 3) * TILE * ld + (int64_t)(k + 2) * TILE; f.ldc = ld;
-        f.mt = mt; f.nt64 = 2 * (T - (k + 2)); f.kc = TILE / KC; f.alpha = -1.0; f.beta = 1.0;
+        f.mt = T - (k + 3); f.nt64 = 2 * (T - (k + 2)); f.kc = TILE / KC; f.alpha = -1.0; f.beta = 1.0;
         f.diag_skip = 1; f.row0 = (int64_t)(k + 3) * TILE; f.col0 = (int64_t)(k + 2) * TILE;
-        f.wait_flag = last2; f.wait_val = 1u;   // (set with the critical follower's last panel: long since, when the followers are done)
-        f.signal = fl.farall + k; f.signal_row0 = fl.rest + k; f.abort_flag = fl.abort;
+        f.wait_flag = fl.xp + ((size_t)k * T + (k + 3)) * CH_PANELS + (CH_PANELS - 1); f.wait_val = 1u; f.wait_stride_ti = CH_PANELS;
+        f.wait_flag2 = fl.xp + ((size_t)k * T + (k + 2)) * CH_PANELS + (CH_PANELS - 1); f.wait_val2 = 1u; f.wait_stride_tj2 = CH_PANELS;
+        f.signal = fl.colall + k;          // (selects the agent-scope stores; nobody waits for the whole launch)
+        f.signal_row0 = fl.rest + k;       // row k+3: what the gated update of block k+1 starts from
+        f.signal_col0 = fl.farall + k;     // column k+2: what block k+1's column updaters write next
+        f.first_row_col = 1; f.abort_flag = fl.abort;
         CHK(launch_gemm_nt(g, f, 1, g->inv_stream));
     }
-    HIPCHK(hipEventRecord(g->ev_inv, g->inv_stream));
-    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
-    HIPCHK(hipEventRecord(g->ev_bulk, g->side_stream));
-    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_bulk, 0));
+    if (T > 3) {
+        HIPCHK(hipEventRecord(g->ev_bulk, g->col_stream));
+        HIPCHK(hipStreamWaitEvent(g->stream, g->ev_bulk, 0));
+        HIPCHK(hipEventRecord(g->ev_gate, g->side_stream));
+        HIPCHK(hipStreamWaitEvent(g->stream, g->ev_gate, 0));
+        HIPCHK(hipEventRecord(g->ev_inv, g->inv_stream));
+        HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
+    }
     if (T > 1) {
         hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
         HIPCHK(hipGetLastError());
@@ -446,7 +444,7 @@ static int refit(bohip_gp* g) {
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "cholesky");
-    if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2)) {
+    if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= 48)) {
         CHK(cholesky_dataflow(g, T));
         t_end(g);
         t_begin(g, "tri_inverse");
@@ -459,7 +457,7 @@ static int refit(bohip_gp* g) {
         t_end(g);
         CHK(check_info(g));
         unsigned aborted = 0;
-        HIPCHK(hipMemcpy(&aborted, g->dchol_flags + (size_t)T * (3 * CH_PANELS + 7), sizeof(unsigned), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&aborted, g->dchol_flags + chol_abort_word(T), sizeof(unsigned), hipMemcpyDeviceToHost));
         if (aborted) {
             // a flag never arrived (e.g. two of the three streams share a hardware queue on this system): every wait has
             // returned, nothing hangs; the factor is garbage.  Fall back to the launch-chained form for the rest of the process.
@@ -1068,6 +1066,7 @@ int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohi
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_panels, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_bulk, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->inv_stream, hipStreamNonBlocking, prio_lo);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&g->col_stream, hipStreamNonBlocking, prio_hi);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_blk, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_inv, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_gate, hipEventDisableTiming);
@@ -1118,6 +1117,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->ev_panels) hipEventDestroy(g->ev_panels);
     if (g->ev_bulk) hipEventDestroy(g->ev_bulk);
     if (g->inv_stream) { hipStreamSynchronize(g->inv_stream); hipStreamDestroy(g->inv_stream); }
+    if (g->col_stream) { hipStreamSynchronize(g->col_stream); hipStreamDestroy(g->col_stream); }
     if (g->ev_blk) hipEventDestroy(g->ev_blk);
     if (g->ev_inv) hipEventDestroy(g->ev_inv);
     if (g->ev_gate) hipEventDestroy(g->ev_gate);

@@ -49,10 +49,12 @@ struct CholFlags {
     unsigned* crit;       // [T]       counter: waves of the update launch for row k+2 of block k that have finished
     unsigned* abort;      // [1]       set on a spin time-out: every wait returns at once
     double* w16_g;        // [T * 8][16][16] inverse of each 16 x 16 pivot block (lower, zeros above), published with its panel
-    unsigned* xp;         // [T * 2 * 8] rows k+1 (slot 0) and k+2 (slot 1) of block k: panel p of L(row, k) is complete in S
+    unsigned* xp;         // [T * T * 8] panel p of L(i, k) is complete in S: xp[(k T + i) 8 + p], every row i > k
+    unsigned* colr;       // [T * T]     counter: waves that have stored their part of tile (i, k+1) updated with block k's panel: colr[k T + i]
+    int T;
     unsigned* rest;       // [T]       counter: storing waves of row k+3 (the first row tile) of block k's FAR update (columns >= k+2)
     unsigned* col;        // [T]       the same for block k's update of column k+1 (tile (k+3, k+1): what row k+3's follower needs next)
-    unsigned* farall;     // [T]       every storing wave of block k's far update
+    unsigned* farall;     // [T]       storing waves of the first 128 columns (column k+2) of block k's far update
     unsigned* fol;        // [T]       bulk followers of block k that have finished
     unsigned* colall;     // [T]       (every storing wave of block k's column update; not waited on)
     unsigned crit_want;   // value of crit[k] when the whole row-(k+2) update launch of block k is in memory
@@ -93,6 +95,7 @@ __device__ __forceinline__ void release_wg() { asm volatile("s_waitcnt vmcnt(0)"
 __device__ __forceinline__ void flag_set(unsigned* flag, unsigned v) {
     __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ unsigned* xp_at(const CholFlags& fl, int k, int i) { return fl.xp + ((size_t)k * fl.T + i) * CH_PANELS; }
 
 // ---- the 36 lower 16 x 16 sub-blocks of a 128 x 128 tile, dealt to the two halves of a 512-thread workgroup ----------
 __host__ __device__ constexpr int blk_bi(int idx) {
@@ -202,7 +205,7 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
         if (WITH_D1 && t == 511 && k_blk == 1) CH_MARK(3584 + 8 * p + 3);
         if (xf) release_wg();   // the S stores of this panel were issued two phases ago: they have landed by now
         __syncthreads();   // LPt / XB are rewritten by the next panel
-        if (xf && t == 0) flag_set(xf + p, 1u);
+        if (xf && t == 0) { flag_set(xf + p, 1u); if (!WITH_D1 && k_blk < 24 && i_tile - k_blk <= 2) CH_MARK(3648 + (k_blk * 2 + (i_tile - k_blk - 1)) * 9 + p); }
         if (WITH_D1 && t == 0) CH_MARK(2048 + k_blk * CH_PANELS + p);
     }
 }
@@ -401,7 +404,7 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             }
             d1_load<H>(Lmat, ld, r, d);
             if (tid == 0) CH_MARK(3500 + r);
-            const unsigned* xf = fl.xp + ((size_t)(r - 1) * 2 + 0) * CH_PANELS;
+            const unsigned* xf = xp_at(fl, r - 1, r);
             const double* Sx = S + ((int64_t)r * TILE + (tid >> 2)) * ld + (int64_t)(r - 1) * TILE + 4 * (tid & 3);
             for (int p = 0; p < CH_PANELS; ++p) {
                 if (tid == 0) { flag_wait_ge(xf + p, 1u, fl.abort); CH_MARK(1024 + (r - 1) * CH_PANELS + p); }
@@ -429,8 +432,8 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
     }
 }
 
-// storing waves of the first row tile of block k's far update (host: nt64 = 2 (T - k - 2); every workgroup adds 4)
-__device__ __forceinline__ unsigned rest_want(int T, int k) { return 4u * 2u * (unsigned)(T - k - 2); }
+// waves of the first row tile of block k's far update (host: nt64 = 2 (T - k - 2); every workgroup adds 8)
+__device__ __forceinline__ unsigned rest_want(int T, int k) { return 8u * 2u * (unsigned)(T - k - 2); }
 
 // ---- role 2 (workgroups 2, 3): critical followers.  Row r is followed twice -- as "row k+2" during block k = r-2 and as
 // "row k+1" during block k = r-1 -- always by the workgroup of its parity, so at any block the two rows next to the pivot
@@ -445,23 +448,25 @@ __device__ __forceinline__ void crit_follower(double* __restrict__ Lmat, int64_t
         if (k >= 1) {   // tile (r, k) must carry block k-1's update: row k+1 gets it from the gated update, row k+2 from the column launch
             if (tid == 0) {
                 if (r == k + 1) flag_wait_ge(fl.crit + (k - 1), fl.crit_want, fl.abort);
-                else flag_wait_ge(fl.col + (k - 1), 8u, fl.abort);   // tile (k+2, k): first row tile of block k-1's column update
+                else flag_wait_ge(fl.colr + (size_t)(k - 1) * T + r, 8u, fl.abort);   // tile (k+2, k): its column updaters of block k-1
             }
             __syncthreads();
         }
         load_row_piece(Lmat, ld, r, k, ar);
-        follow_block<false, 0>(Lmat, ld, S, r, k, fl, sm, ar, dd, fl.xp + ((size_t)k * 2 + (r - k - 1)) * CH_PANELS);
+        if (tid == 0 && k < 24) CH_MARK(3648 + (k * 2 + (r - k - 1)) * 9 + 8);
+        follow_block<false, 0>(Lmat, ld, S, r, k, fl, sm, ar, dd, xp_at(fl, k, r));
     }
 }
 
-// ---- role 3 (workgroups 4..7): the update of row k+2 with block k's panel -- the two tiles (k+2, k+1), (k+2, k+2) the
-// chain needs next -- as a GEMM whose contraction index ARRIVES 16 columns at a time: chunk c of L(k+2, k) and L(k+1, k) is
-// consumed as soon as the critical followers raise its flags, so the tiles are final a few microseconds after block k's
-// last panel instead of one launch + one K = 128 GEMM later (the next owner waited 36 us per block for that).  One
-// workgroup per 128 x 64 tile, waves 0-3, the contraction engine's fragment layout (gemm_core.h) on an LDS image staged
-// with agent-scope loads.
-__device__ __forceinline__ void gated_worker(double* __restrict__ Lmat, int64_t ld, const double* __restrict__ S, int T,
-                                             const CholFlags& fl, double* sm, int tj) {
+// ---- chunk-gated tile update: C (128 x 64) -= A (128 x 128) B' (64 x 128) where the contraction index ARRIVES 16 columns
+// at a time: chunk c of A and B is consumed as soon as the followers that produce it raise its panel flags, so the tile is
+// final a few microseconds after the block's last panel instead of one launch + one K = 128 GEMM later.  Waves 0-3 compute
+// (the contraction engine's fragment layout, gemm_core.h, on an LDS image staged with agent-scope loads); any other
+// waves of the workgroup only keep the barriers company.
+__device__ __forceinline__ void gated_tile(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C,
+                                           int64_t ld, int64_t row0, int64_t col0, const unsigned* fa, const unsigned* fb,
+                                           const unsigned* pre, unsigned pre_want, unsigned* signal, const CholFlags& fl,
+                                           double* sm) {
     double* As = sm;                       // [128][16]
     double* Bs = sm + TILE * GL_ROW;       // [64][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = (wave & 3) >> 1, wc = wave & 1;
@@ -475,72 +480,81 @@ __device__ __forceinline__ void gated_worker(double* __restrict__ Lmat, int64_t 
         ob[S_] = ((4 * S_ + kq) ^ r7b) << 1;
     }
     const int a_frag = (wr * 64 + r7a) * GL_ROW, b_frag = (wc * 32 + r7b) * GL_ROW;
+    // The tile's current value (all updates from earlier blocks: *pre) is fetched BEFORE the contraction, into the accumulators:
+    // the launch that writes it finishes early in the block, and the read then overlaps the wait for the panels (read in the
+    // epilogue it added ~10 us of scattered agent-scope round trips to the hand-over).
+    if (pre) {
+        if (tid == 0) flag_wait_ge(pre, pre_want, fl.abort);
+        __syncthreads();
+    }
+    double acc[8][4];   // holds  -C  so that the contraction adds A B' and the store writes  -(acc)
+    if (act) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int r = acc_row(lane, wr, mi);
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) {
+                const int cc = acc_col<4>(lane, wc, nj);
+                acc[mi][nj] = (col0 + cc > row0 + r) ? 0.0 : -ld_agent(C + (int64_t)r * ld + cc);
+            }
+        }
+    }
+    for (int c = 0; c < TILE / KC; ++c) {
+        if (tid == 0) { flag_wait_ge(fa + c, 1u, fl.abort); flag_wait_ge(fb + c, 1u, fl.abort); }
+        __syncthreads();   // (also: the previous chunk's fragments have been read)
+        if (act) {
+            // LDS[row][slot] holds the 16-B segment slot ^ (row & 7) of the row's 128-B chunk (the swizzle of gemm_core.h)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7, seg = slot ^ (row & 7);
+                const double* src = A + (int64_t)row * ld + c * KC + 2 * seg;
+                As[row * GL_ROW + 2 * slot] = ld_agent(src);
+                As[row * GL_ROW + 2 * slot + 1] = ld_agent(src + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7, seg = slot ^ (row & 7);
+                const double* src = B + (int64_t)row * ld + c * KC + 2 * seg;
+                Bs[row * GL_ROW + 2 * slot] = ld_agent(src);
+                Bs[row * GL_ROW + 2 * slot + 1] = ld_agent(src + 1);
+            }
+        }
+        __syncthreads();
+        if (act) mma_chunk_swz<4>(As + a_frag, Bs + b_frag, oa, ob, acc);
+    }
+    if (act) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int r = acc_row(lane, wr, mi);
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) {
+                const int cc = acc_col<4>(lane, wc, nj);
+                if (col0 + cc > row0 + r) continue;   // the strict upper triangle stays zero
+                st_agent(C + (int64_t)r * ld + cc, -acc[mi][nj]);
+            }
+        }
+        release_wg();
+        if (lane == 0) atomicAdd(signal, 1u);
+    }
+    __syncthreads();
+}
+
+// waves of the first 128 columns of block k's far update (host: mt = T - k - 3 row tiles x 2 column tiles; every workgroup adds 8)
+__device__ __forceinline__ unsigned farcol_want(int T, int k) { return 8u * 2u * (unsigned)(T - k - 3); }
+
+// ---- role 3 (workgroups 4..7): the update of row k+2 with block k's panel -- the two tiles (k+2, k+1), (k+2, k+2) the
+// chain needs next (the next owner waited 36 us per block for the launch-based form of this update).
+__device__ __forceinline__ void gated_worker(double* __restrict__ Lmat, int64_t ld, const double* __restrict__ S, int T,
+                                             const CholFlags& fl, double* sm, int tj) {
     for (int k = 0; k + 2 < T; ++k) {
         const double* A = S + (int64_t)(k + 2) * TILE * ld + (int64_t)k * TILE;
         const double* B = S + ((int64_t)(k + 1) * TILE + (int64_t)tj * CTILE) * ld + (int64_t)k * TILE;
         double* C = Lmat + (int64_t)(k + 2) * TILE * ld + (int64_t)(k + 1) * TILE + (int64_t)tj * CTILE;
-        const int64_t row0 = (int64_t)(k + 2) * TILE, col0 = (int64_t)(k + 1) * TILE + (int64_t)tj * CTILE;
-        const unsigned* fa = fl.xp + ((size_t)k * 2 + 1) * CH_PANELS;
-        const unsigned* fb = tj < 2 ? fl.xp + ((size_t)k * 2 + 0) * CH_PANELS : fa;
-        // The tile's current value (all updates from earlier blocks) is fetched BEFORE the contraction, into the accumulators:
-        // the launch that writes it finishes early in the block, and the read then overlaps the wait for the panels (read in
-        // the epilogue it added ~10 us of scattered agent-scope round trips to the chain's hand-over).
-        if (k >= 1) {
-            if (tid == 0) flag_wait_ge(fl.rest + (k - 1), rest_want(T, k - 1), fl.abort);
-            __syncthreads();
-        }
-        double acc[8][4];   // holds  -C  so that the contraction adds A B' and the store writes  -(acc)
-        if (act) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int r = acc_row(lane, wr, mi);
-#pragma unroll
-                for (int nj = 0; nj < 4; ++nj) {
-                    const int cc = acc_col<4>(lane, wc, nj);
-                    acc[mi][nj] = (col0 + cc > row0 + r) ? 0.0 : -ld_agent(C + (int64_t)r * ld + cc);
-                }
-            }
-        }
-        for (int c = 0; c < TILE / KC; ++c) {
-            if (tid == 0) { flag_wait_ge(fa + c, 1u, fl.abort); flag_wait_ge(fb + c, 1u, fl.abort); }
-            __syncthreads();   // (also: the previous chunk's fragments have been read)
-            if (act) {
-                // LDS[row][slot] holds the 16-B segment slot ^ (row & 7) of the row's 128-B chunk (the swizzle of gemm_core.h)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7, seg = slot ^ (row & 7);
-                    const double* src = A + (int64_t)row * ld + c * KC + 2 * seg;
-                    As[row * GL_ROW + 2 * slot] = ld_agent(src);
-                    As[row * GL_ROW + 2 * slot + 1] = ld_agent(src + 1);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7, seg = slot ^ (row & 7);
-                    const double* src = B + (int64_t)row * ld + c * KC + 2 * seg;
-                    Bs[row * GL_ROW + 2 * slot] = ld_agent(src);
-                    Bs[row * GL_ROW + 2 * slot + 1] = ld_agent(src + 1);
-                }
-            }
-            __syncthreads();
-            if (act) mma_chunk_swz<4>(As + a_frag, Bs + b_frag, oa, ob, acc);
-        }
-        if (tid == 0 && tj == 0) CH_MARK(3300 + 4 * k + 0);
-        if (act) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int r = acc_row(lane, wr, mi);
-#pragma unroll
-                for (int nj = 0; nj < 4; ++nj) {
-                    const int cc = acc_col<4>(lane, wc, nj);
-                    if (col0 + cc > row0 + r) continue;   // the strict upper triangle stays zero
-                    st_agent(C + (int64_t)r * ld + cc, -acc[mi][nj]);
-                }
-            }
-            release_wg();
-            if (lane == 0) atomicAdd(fl.crit + k, 1u);
-        }
-        if (tid == 0 && tj == 0) CH_MARK(3300 + 4 * k + 2);
-        __syncthreads();
+        const unsigned* fa = xp_at(fl, k, k + 2);
+        gated_tile(A, B, C, ld, (int64_t)(k + 2) * TILE, (int64_t)(k + 1) * TILE + (int64_t)tj * CTILE, fa,
+                   tj < 2 ? xp_at(fl, k, k + 1) : fa, k >= 1 ? fl.rest + (k - 1) : nullptr, k >= 1 ? rest_want(T, k - 1) : 0u,
+                   fl.crit + k, fl, sm);
+        if (threadIdx.x == 0 && tj == 0) CH_MARK(3300 + 4 * k + 2);
     }
 }
 
@@ -559,17 +573,38 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_chain(double* __restrict
     }
 }
 
-// bulk followers: one workgroup per tile (i, k), i = k + 3 + blockIdx.x: solves L(i, k) panel by panel as block k's pivot chain runs
-__global__ __launch_bounds__(CH_THREADS, 1) void k_chol_follow(const double* __restrict__ Lmat, int64_t ld,
-                                                            double* __restrict__ S, int k_blk, CholFlags fl) {
+// Rows >= 3 before they reach the chain.  One PERSISTENT workgroup per row i follows blocks k = 0 .. i-3 (tile (i, k) each:
+// the same panel follower as the critical ones), and two persistent workgroups per row keep tile (i, k+1) -- the tile the
+// row follows NEXT -- updated chunk by chunk (gated_tile).  A row's work for block k+1 can therefore start a few
+// microseconds after its work for block k ends; with one launch per block for each of the two steps (the first version)
+// the cycle follower -> launch gap -> K = 128 update -> launch gap was 80 us against a 58 us pivot block and paced everything.
+__global__ __launch_bounds__(CH_THREADS, 1) void k_chol_rows(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ S,
+                                                          int T, CholFlags fl) {
     extern __shared__ double sm[];
-    const int i_tile = k_blk + 3 + blockIdx.x;
+    const int i_tile = 3 + blockIdx.x;
     double ar[32], d[18];
-    load_row_piece(Lmat, ld, i_tile, k_blk, ar);
-    follow_block<false, 0>(Lmat, ld, S, i_tile, k_blk, fl, sm, ar, d, nullptr);
-    release_wg();
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(fl.fol + k_blk, 1u);   // this row of L(:, k) is complete in S
+    for (int k = 0; k + 3 <= i_tile; ++k) {
+        if (k >= 1) {   // tile (i, k) carries block k-1's update once its two column updaters have stored
+            if (threadIdx.x == 0) flag_wait_ge(fl.colr + (size_t)(k - 1) * T + i_tile, 8u, fl.abort);
+            __syncthreads();
+        }
+        load_row_piece(Lmat, ld, i_tile, k, ar);
+        follow_block<false, 0>(Lmat, ld, S, i_tile, k, fl, sm, ar, d, xp_at(fl, k, i_tile));
+    }
+}
+__global__ __launch_bounds__(GEMM_THREADS) void k_chol_cols(double* __restrict__ Lmat, int64_t ld, const double* __restrict__ S,
+                                                         int T, CholFlags fl) {
+    __shared__ __attribute__((aligned(16))) double sm[(TILE + CTILE) * GL_ROW];
+    const int i_tile = 3 + (blockIdx.x >> 1), h = blockIdx.x & 1;
+    for (int k = 0; k + 3 <= i_tile; ++k) {   // tile (i, k+1), columns [64 h, 64 h + 64): -= L(i, k) L(k+1, k)'
+        const double* A = S + (int64_t)i_tile * TILE * ld + (int64_t)k * TILE;
+        const double* B = S + ((int64_t)(k + 1) * TILE + (int64_t)h * CTILE) * ld + (int64_t)k * TILE;
+        double* C = Lmat + (int64_t)i_tile * TILE * ld + (int64_t)(k + 1) * TILE + (int64_t)h * CTILE;
+        // block k-1's far update wrote this tile too (column k+1 was its FIRST column, dispatched early, own counter)
+        gated_tile(A, B, C, ld, (int64_t)i_tile * TILE, (int64_t)(k + 1) * TILE + (int64_t)h * CTILE, xp_at(fl, k, i_tile),
+                   xp_at(fl, k, k + 1), k >= 1 ? fl.farall + (k - 1) : nullptr, k >= 1 ? farcol_want(T, k - 1) : 0u,
+                   fl.colr + (size_t)k * T + i_tile, fl, sm);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

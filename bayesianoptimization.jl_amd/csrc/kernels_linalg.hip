@@ -485,35 +485,47 @@ struct GemmNTParams {
     // col_t0 + z col_ts + tj64/2 < total_t  (all in 128-tiles); total_t <= 0 disables the check
     int row_t0, row_ts, col_t0, col_ts, total_t;
     // dataflow gating (kernels_chol.hip): every workgroup waits until *wait_flag >= wait_val before it touches an operand,
-    // and each of its four storing waves adds 1 to *signal when its part of the tile is in memory (a workgroup without a
-    // tile adds 4), so a consumer can wait for 4 x gridDim.x x gridDim.y.  abort: see flag_wait_ge.
+    // and each of its eight waves adds 1 to *signal when its part of the tile is in memory (a workgroup without a
+    // tile adds 8), so a consumer can wait for 8 x gridDim.x x gridDim.y.  abort: see flag_wait_ge.
     const unsigned* wait_flag;
     unsigned wait_val;
     const unsigned* wait_flag2;   // optional second flag, same rule
     unsigned wait_val2;
+    int wait_stride_ti, wait_stride_tj2;   // this workgroup waits on wait_flag[ti * stride_ti] and wait_flag2[(tj / 2) * stride_tj2]
     unsigned* signal;
     unsigned* signal_row0;        // the workgroups of the first row tile (ti == 0, scheduled first) also count here
+    unsigned* signal_col0;        // the workgroups of the first 128 columns (tj < 2) also count here
+    int first_row_col;            // dispatch order: first row tile, then the first 128 columns of the other rows, then the rest
+                                  // (the chain waits for exactly those tiles; the bulk of the launch follows)
     unsigned* abort_flag;
 };
 
 __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // klo_from_n: the contraction of column tile tj starts at 128 (tj/2) -> low tj = long jobs: issue them first
-    const int ti = p.klo_from_n ? blockIdx.x % p.mt : blockIdx.x / p.nt64;
-    const int tj = p.klo_from_n ? blockIdx.x / p.mt : blockIdx.x % p.nt64;
+    int ti = p.klo_from_n ? blockIdx.x % p.mt : blockIdx.x / p.nt64;
+    int tj = p.klo_from_n ? blockIdx.x / p.mt : blockIdx.x % p.nt64;
+    if (p.first_row_col && p.nt64 > 2) {
+        const int b = blockIdx.x, edge = p.nt64 + 2 * (p.mt - 1);
+        if (b < p.nt64) { ti = 0; tj = b; }
+        else if (b < edge) { ti = 1 + (b - p.nt64) / 2; tj = (b - p.nt64) & 1; }
+        else { ti = 1 + (b - edge) / (p.nt64 - 2); tj = 2 + (b - edge) % (p.nt64 - 2); }
+    }
     const int z = blockIdx.y;
     const bool no_tile = (p.diag_skip && p.col0 + CTILE * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) ||
                          (p.total_t > 0 && (p.row_t0 + z * p.row_ts + ti >= p.total_t || p.col_t0 + z * p.col_ts + (tj >> 1) >= p.total_t));
     if (no_tile) {
-        if (p.signal && threadIdx.x == 0) atomicAdd(p.signal, 4u);
-        if (p.signal_row0 && ti == 0 && threadIdx.x == 0) atomicAdd(p.signal_row0, 4u);
+        if (p.signal && threadIdx.x == 0) atomicAdd(p.signal, 8u);
+        if (p.signal_row0 && ti == 0 && threadIdx.x == 0) atomicAdd(p.signal_row0, 8u);
+        if (p.signal_col0 && tj < 2 && threadIdx.x == 0) atomicAdd(p.signal_col0, 8u);
         return;
     }
     if (p.wait_flag) {
         if (threadIdx.x == 0) {
             for (long it = 0;; ++it) {
-                if (__hip_atomic_load(p.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val &&
-                    (!p.wait_flag2 || __hip_atomic_load(p.wait_flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val2)) break;
+                if (__hip_atomic_load(p.wait_flag + (int64_t)ti * p.wait_stride_ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val &&
+                    (!p.wait_flag2 || __hip_atomic_load(p.wait_flag2 + (int64_t)(tj >> 1) * p.wait_stride_tj2, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val2)) break;
                 if (p.abort_flag && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
                 if (it > 40000000L) { if (p.abort_flag) atomicExch(p.abort_flag, 1u); break; }
@@ -538,8 +550,45 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
     gemm_tile_loop_glds3_ks<4>(p.A + z * p.zA + (int64_t)ti * TILE * p.lda, p.lda, p.B + z * p.zB + (int64_t)tj * CTILE * p.ldb,
                                p.ldb, kb, ke, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
-    if (wave >= 4) return;  // waves 4-7 only contributed partial sums (already folded into waves 0-3)
     double* C = p.C ? p.C + z * p.zC + (int64_t)ti * TILE * p.ldc + (int64_t)tj * CTILE : nullptr;
+    if (p.signal && C) {
+        // A running kernel reads this tile: the stores are agent-scope (write-through).  Issued straight from the MFMA
+        // accumulator layout they are 8-byte pieces in 32-byte runs -- 15-25 us per tile, longer than the contraction.  So
+        // the tile takes a turn through LDS and leaves as 16-byte pieces, 1 KB contiguous per wave instruction, by all 8 waves.
+        constexpr int TS = CTILE + 2;
+        double* Tl = smem;   // [128][66]: the staging buffers are free (the loop ended on a barrier)
+        if (wave < 4) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int nj = 0; nj < 4; ++nj) Tl[acc_row(lane, wr, mi) * TS + acc_col<4>(lane, wc, nj)] = p.alpha * acc[mi][nj];
+        }
+        __syncthreads();
+        const int64_t grow0 = p.row0 + (int64_t)ti * TILE, gcol0 = p.col0 + (int64_t)tj * CTILE;
+#pragma unroll
+        for (int u = 0; u < (TILE * CTILE / 2) / GEMM_THREADS_8; ++u) {
+            const int piece = threadIdx.x + GEMM_THREADS_8 * u, r = piece >> 5, c = (piece & 31) * 2;
+            double* dst = C + (int64_t)r * p.ldc + c;
+            const bool k0 = !(p.diag_skip && gcol0 + c > grow0 + r), k1 = !(p.diag_skip && gcol0 + c + 1 > grow0 + r);
+            if (!k0) continue;   // (k1 implies k0)
+            d2 v = *reinterpret_cast<const d2*>(Tl + r * TS + c);
+            if (p.beta != 0.0) {
+                const d2 old = *reinterpret_cast<const d2*>(dst);
+                v.x += p.beta * old.x;
+                v.y += p.beta * old.y;
+            }
+            if (k1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+            else __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed (a workgroup-scope fence emits no such wait)
+        if (lane == 0) {
+            atomicAdd(p.signal, 1u);
+            if (p.signal_row0 && ti == 0) atomicAdd(p.signal_row0, 1u);
+            if (p.signal_col0 && tj < 2) atomicAdd(p.signal_col0, 1u);
+        }
+        return;
+    }
+    if (wave >= 4) return;  // waves 4-7 only contributed partial sums (already folded into waves 0-3)
     double* CT = p.CT ? p.CT + z * p.zCT + (int64_t)tj * CTILE * p.ldct + (int64_t)ti * TILE : nullptr;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
@@ -553,16 +602,10 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
             if (C) {
                 double* dst = C + (int64_t)r * p.ldc + c;
                 if (p.beta != 0.0) v += p.beta * *dst;
-                if (p.signal) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a running kernel reads this tile
-                else *dst = v;
+                *dst = v;
             }
             if (CT) CT[(int64_t)c * p.ldct + r] = v;
         }
-    }
-    if (p.signal) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the agent-scope stores above have landed (a workgroup-scope fence emits no such wait)
-        if (lane == 0) atomicAdd(p.signal, 1u);
-        if (p.signal_row0 && ti == 0 && lane == 0) atomicAdd(p.signal_row0, 1u);
     }
 }
 

@@ -37,6 +37,11 @@ for k in range(min(T - 2, 4)):
     r = k + 2
     print(f"block {k}: gated row-{r} update: chunks done {us(g_[0]):.1f}, pre ok {us(g_[1]):.1f}, stored {us(g_[2]):.1f} | owner of row {r}: starts waiting {us(g_[3]):.1f}, "
           f"sees crit {us(t[3400 + r]):.1f}, tiles loaded {us(t[3500 + r]):.1f}")
+for k in range(min(T - 1, 5)):
+    for sl in (0, 1):
+        b = 3648 + (k * 2 + sl) * 9
+        if t[b + 8] > 0:
+            print(f"block {k}: critical follower of row {k + 1 + sl}: tile loaded {us(t[b + 8]):.1f}, panels done {[round(us(t[b + p]), 1) for p in range(8)]}")
 ph = t[3584:3584 + 64].reshape(8, 8)
 print("block 1, follower phases per panel (us since flag seen): staged, solved+barrier, trailing done (t511), D1 done (t511)")
 for p_ in range(8):
