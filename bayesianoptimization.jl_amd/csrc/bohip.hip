@@ -371,7 +371,7 @@ static int cholesky_dataflow(bohip_gp* g, int T) {
     fl.abort = fl.xp + (size_t)T * T * CH_PANELS;
     fl.w16_g = g->dchol_idl;
     fl.crit_want = 16u;   // the row-(k+2) update: 4 workgroups x 4 storing waves
-    fl.panel_want = 4u;   // four publishing waves per panel
+    fl.panel_want = 3u;   // three publishing waves per panel
     HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
     HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
     // Four launches that live for the whole factorisation and talk through flags:

@@ -158,7 +158,6 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
                 for (int e = 0; e < 4; ++e) XB[(r16 + 16 * i) * WK_XS + 4 * cg + e] = a[4 * i + e];
         }
         __syncthreads();
-        if (WITH_D1 && t == 0 && k_blk == 1) CH_MARK(3584 + 8 * p + 0);
         {   // thread (row = t & 127, part = t >> 7): x[4 part .. 4 part + 3] = sum_k r[k] W16[c][k]
             const int row = t & 127, part = t >> 7;
             double r[16], x4[4] = {0.0, 0.0, 0.0, 0.0};
@@ -182,7 +181,6 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
             }
         }
         __syncthreads();
-        if (WITH_D1 && t == 0 && k_blk == 1) CH_MARK(3584 + 8 * p + 1);
         if (w > p) {   // wave-uniform: this wave's columns lie beyond the panel
             const double* lp = LPt + 16 * w + 4 * cg;
 #pragma unroll 4
@@ -200,9 +198,7 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
                 }
             }
         }
-        if (WITH_D1 && t == 511 && k_blk == 1) CH_MARK(3584 + 8 * p + 2);
         if constexpr (WITH_D1) d1_rank16<H>(XS, d);
-        if (WITH_D1 && t == 511 && k_blk == 1) CH_MARK(3584 + 8 * p + 3);
         if (xf) release_wg();   // the S stores of this panel were issued two phases ago: they have landed by now
         __syncthreads();   // LPt / XB are rewritten by the next panel
         if (xf && t == 0) { flag_set(xf + p, 1u); if (!WITH_D1 && k_blk < 24 && i_tile - k_blk <= 2) CH_MARK(3648 + (k_blk * 2 + (i_tile - k_blk - 1)) * 9 + p); }
@@ -268,13 +264,14 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
             // W16 = inverse of the pivot block (column cc per thread, substitution in registers) for the followers; runs on an
             // otherwise idle wave beside the row solves
             const int cc = tid - PF_THREADS;
-            double wv[16];
+            double wv[16], sacc[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                double sacc = 0.0;
+            for (int i = 0; i < 16; ++i) sacc[i] = 0.0;
 #pragma unroll
-                for (int k = 0; k < i; ++k) sacc += a[(P + k) * PF_LD + P + i] * wv[k];  // wv[k] = 0 for k < cc
-                wv[i] = (i < cc) ? 0.0 : (i == cc ? idl[P + i] : -sacc * idl[P + i]);
+            for (int k = 0; k < 16; ++k) {   // right-looking: w[k] is final, every later partial sum takes its term at once
+                wv[k] = (k < cc) ? 0.0 : (k == cc ? idl[P + k] : -sacc[k] * idl[P + k]);
+#pragma unroll
+                for (int i = k + 1; i < 16; ++i) sacc[i] += a[(P + k) * PF_LD + P + i] * wv[k];
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) w16s[i * 16 + cc] = wv[i];
@@ -294,10 +291,14 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
             for (int c = 0; c < 16; ++c) a[(P + c) * PF_LD + i] = x[c];
         }
         __syncthreads();
-        // Panel jb is final.  The four waves that take no part in the factorisation publish it -- their stores and the wait for
+        if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 0);
+        // Panel jb is final.  Waves that take no part in the factorisation publish it -- their stores and the wait for
         // them to land stay off the pivot chain: they are issued here, awaited behind the next barrier, and each wave then
         // adds 1 to the panel's flag (followers wait for 4).
-        if (!act) publish_panel(Lblk, ld, a, dl, w16s, fl.w16_g + ((size_t)k_blk * CH_PANELS + jb) * 256, P, tid - PF_THREADS);
+        if (tid >= 320) {   // waves 5-7 publish (192 threads walk the 256 publishing slots)
+            for (int s_ = tid - 320; s_ < PF_THREADS; s_ += 192)
+                publish_panel(Lblk, ld, a, dl, w16s, fl.w16_g + ((size_t)k_blk * CH_PANELS + jb) * 256, P, s_);
+        }
         if (m > 0 && act) {   // rank-16 update of the next pivot block
             const int ty = tid >> 4, tx = tid & 15;
             double acc = 0.0;
@@ -309,22 +310,25 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
             if (tx <= ty) a[(base + ty) * PF_LD + base + tx] -= acc;
         }
         __syncthreads();
-        if (!act) {
+        if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 1);
+        if (tid >= 320) {
             release_wg();   // s_waitcnt vmcnt(0): this wave's part of the panel has left the CU
-            if (lane == 0) { atomicAdd(pflag + jb, 1u); if (wave == 4) CH_MARK(k_blk * CH_PANELS + jb); }
+            if (lane == 0) { atomicAdd(pflag + jb, 1u); if (wave == 5) CH_MARK(k_blk * CH_PANELS + jb); }
         }
         if (m == 0) break;
         if (wave == 0) {
             factor16(a, dl, idl, base, lane, info, row0);
-        } else if (act) {
+            if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 3);
+        } else if (wave <= 4) {
+            // waves 1-4: one (ty, tx) position of every live 16 x 16 sub-block per thread.  (k_potf2_inv has three waves for this
+            // and splits the fourth wave's rows three ways: four code variants per size, 28 in all, ~30 KB, each run once per
+            // block from a cold instruction cache -- the first panel's update took 14 us for ~2 us of work.)
             const int u = tid - 64;
-            trailing_dispatch<true, -1>(a, P, m >> 4, 4 + (u >> 4), u & 15);
-            const int ty0 = (u >> 4) & 3, tx0 = u & 15;
-            if (wave == 1) trailing_dispatch<true, 0>(a, P, m >> 4, ty0, tx0);
-            else if (wave == 2) trailing_dispatch<true, 1>(a, P, m >> 4, ty0, tx0);
-            else trailing_dispatch<true, 2>(a, P, m >> 4, ty0, tx0);
+            trailing_dispatch<true, -1>(a, P, m >> 4, u >> 4, u & 15);
+            if (tid == 64 && k_blk == 1) CH_MARK(3584 + 8 * jb + 4);
         }
         __syncthreads();
+        if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 2);
     }
 }
 

@@ -43,7 +43,8 @@ for k in range(min(T - 1, 5)):
         if t[b + 8] > 0:
             print(f"block {k}: critical follower of row {k + 1 + sl}: tile loaded {us(t[b + 8]):.1f}, panels done {[round(us(t[b + p]), 1) for p in range(8)]}")
 ph = t[3584:3584 + 64].reshape(8, 8)
-print("block 1, follower phases per panel (us since flag seen): staged, solved+barrier, trailing done (t511), D1 done (t511)")
+b1 = blk[2]
+print("block 1, pivot workgroup, per panel (us since the block's pivot start): row solves done | next pivot block updated | "
+      "factor16 done (wave 0) | trailing done (wave 1) | panel end")
 for p_ in range(8):
-    base = saw[8 * 1 + p_]
-    print("  panel", p_, [round((ph[p_][i] - base) / 100.0, 2) for i in range(4)], " panel done", round((fin[8 + p_] - base) / 100.0, 2))
+    print("  panel", p_, [round((ph[p_][i] - b1) / 100.0, 2) if ph[p_][i] > 0 else None for i in (0, 1, 3, 4, 2)])
