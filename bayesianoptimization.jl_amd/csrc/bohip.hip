@@ -55,6 +55,7 @@ static constexpr int APP_UT_ROW0 = SMALL_MAX;              // rows [0, 256): V' 
 static constexpr int APP_ROWS = 2 * SMALL_MAX;
 static_assert(APPEND_PMAX <= SMALL_MAX && SMALL_R <= SMALL_MAX, "the append shares the small-batch row area");
 
+static constexpr int CHOL_DF_TCAP = 96;   // the dataflow factorisation's flag storage is sized for this many row tiles
 struct bohip_gp {
     int device = 0, d = 0, kern = 0;
     int64_t n = 0, cap = 0, ld = 0;
@@ -218,7 +219,7 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
     HIPCHK(hipMalloc(&g->dApp, (size_t)APP_ROWS * g->ld * 8));
     {
         const size_t Tm = (size_t)(g->ld / TILE) + 1;
-        HIPCHK(hipMalloc(&g->dchol_flags, chol_flag_words((int)std::min<size_t>(Tm, 48)) * sizeof(unsigned)));   // dataflow path: T <= 36
+        HIPCHK(hipMalloc(&g->dchol_flags, chol_flag_words((int)std::min<size_t>(Tm, CHOL_DF_TCAP)) * sizeof(unsigned)));
         HIPCHK(hipMalloc(&g->dchol_idl, Tm * CH_PANELS * 256 * 8));   // W16 of every pivot block
     }
     HIPCHK(hipMemsetAsync(g->dL, 0, mat, g->stream));
@@ -242,10 +243,10 @@ static int g_split = 1;   // split-K path for batches of a few hundred candidate
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
-static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <= T <= g_chol_df_tmax row tiles: N=3000 2.19 vs 2.71 ms, N=1000 0.66
-                            // vs 0.82 ms.  Beyond ~36 tiles its one-tier K=128 bulk updates lose to the two-tier launch chain (N=6000: 7.4 vs
-                            // 5.8 ms), below 3 there is nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every T >= 2.
-static int g_chol_df_tmax = 36;
+static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <= T <= g_chol_df_tmax row tiles: N=3000 1.66 vs 2.71 ms, N=1000 0.57
+                            // vs 0.82 ms.  Far beyond that its one-tier K=128 bulk updates lose to the two-tier launch chain, below 3 there is
+                            // nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every 2 <= T <= CHOL_DF_TCAP.
+static int g_chol_df_tmax = 48;   // N <= ~6100 (N=5000: 3.72 vs 4.74 ms, N=6000: 5.32 vs 5.75 ms)
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
@@ -444,7 +445,7 @@ static int refit(bohip_gp* g) {
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "cholesky");
-    if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= 48)) {
+    if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP)) {
         CHK(cholesky_dataflow(g, T));
         t_end(g);
         t_begin(g, "tri_inverse");
