@@ -11,7 +11,7 @@ import sys
 import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbohip.so")
+LIB_PATH = os.environ.get("BOHIP_LIB") or os.path.join(_HERE, "csrc", "libbohip.so")   # BOHIP_LIB: measurement builds (csrc/abl)
 
 OK, E_ARG, E_NOTPD, E_HIP, E_NODEVICE, E_STATE, E_UNSUPPORTED, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 KERN = {"SEArd": 0, "SEIso": 1, "Mat52Ard": 2}

@@ -270,6 +270,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inv128, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_DF_TMAX")) g_chol_df_tmax = atoi(e);
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_FUSE_FINISH")) g_fuse_finish = atoi(e);
     if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
@@ -456,17 +457,21 @@ static int refit(bohip_gp* g) {
         t_begin(g, "alpha");
         CHK(compute_alpha(g));
         t_end(g);
-        CHK(check_info(g));
+        HIPCHK(hipStreamSynchronize(g->stream));
         unsigned aborted = 0;
         HIPCHK(hipMemcpy(&aborted, g->dchol_flags + chol_abort_word(T), sizeof(unsigned), hipMemcpyDeviceToHost));
         if (aborted) {
-            // a flag never arrived (e.g. two of the three streams share a hardware queue on this system): every wait has
-            // returned, nothing hangs; the factor is garbage.  Fall back to the launch-chained form for the rest of the process.
+            // a flag never arrived (e.g. two of the streams share a hardware queue on this system, or a spinning launch kept a
+            // persistent workgroup off the chip): every wait has returned, nothing hangs; the factor -- and any pivot failure it
+            // reports, hence this check BEFORE check_info -- is garbage.  Fall back to the launch-chained form for the rest of
+            // the process (BOHIP_CHOL_DF_STRICT=1: report it instead, for tests and tools).
             fprintf(stderr, "libbohip: dataflow factorisation timed out on a dependency; using the launch-chained form from now on\n");
+            if (getenv("BOHIP_CHOL_DF_STRICT")) return fail(BOHIP_E_HIP, "dataflow factorisation timed out on a dependency (BOHIP_CHOL_DF_STRICT)");
             g_chol_df = 0;
             g->stale = true;
             return refit(g);
         }
+        CHK(check_info(g));
         g->stale = false;
         g->n_factored = N;
         g->refits++;

@@ -7,21 +7,26 @@
 // the solve of the tile just below it, and the update of the NEXT diagonal block.  Here they are pipelined at 16-column
 // granularity and never leave the chip's registers / LDS:
 //
-//   k_chol_chain   8 persistent workgroups: 2 row owners, 2 critical followers, 4 gated-update workgroups (roles below).
-//                  The owner of row r
-//                    during block r-1  holds tile (r, r-1) [128 x 128, registers] and tile (r, r) [lower, registers],
-//                                      follows the 16-column panels the other owner publishes: row solve of its 128 rows
-//                                      (substitution against the 16 x 16 pivot block), right-looking update of its
-//                                      remaining columns, rank-16 update of (r, r);
+//   k_chol_chain   8 persistent workgroups, one per CU:
+//                  2 row owners (rows alternate).  The owner of row r
+//                    during block r-1  holds the diagonal tile (r, r) [lower, registers] and gives it one rank-16 update per
+//                                      16-column panel of L(r, r-1) that row r's critical follower delivers through S;
 //                    during block r    moves (r, r) -- fully updated -- into LDS and runs the pivot chain itself
 //                                      (the body of k_potf2_inv without the inverse), publishing each finished panel of
-//                                      L_rr to HBM/L2 with a release flag.
+//                                      L_rr and the inverse of its 16 x 16 pivot block with a release flag.
+//                  2 critical followers: rows k+1 and k+2 of the current block k, one tile (r, k) each in registers:
+//                    per published panel the row solve of their 128 rows (x = r W16'), the right-looking update of their
+//                    remaining columns, their 16 new columns of L to S with a per-panel flag.
+//                  4 gated-update workgroups: the two tiles (k+2, k+1), (k+2, k+2) the chain needs next, as an MFMA tile
+//                    product whose contraction index arrives 16 columns at a time (gated_tile).
 //                  The chain per block is therefore the pivot time + one flag hand-over, not pivot + 2 launches + 2 GEMMs.
-//   k_chol_follow  one workgroup per tile (i, k), i >= k+2: the same panel follower without the diagonal tile.  No
-//                  inverse W_kk is needed during the factorisation any more (k_inv128 builds all of them afterwards,
-//                  in parallel, for the triangular inverse W = L^-1).
-//   k_gemm_nt      trailing updates on the MFMA engine as before, gated by flags instead of host events: the row the
-//                  chain needs next (k+2) is its own small launch whose completion counter the next owner waits on.
+//   k_chol_rows    one persistent workgroup per row i >= 3: the same panel follower for tile (i, k), k = 0 .. i-3.
+//   k_chol_cols    two persistent workgroups per row i >= 3: gated_tile on (i, k+1), the tile the row follows next.
+//   k_gemm_nt      (kernels_linalg.hip) the rest of block k's update -- rows >= k+3, columns >= k+2 -- on the MFMA engine,
+//                  one launch per block on its own stream, gated by flags instead of host events and counting into the
+//                  counters the persistent workgroups wait on.
+//   k_inv128       afterwards: the inverses W_kk of all diagonal blocks at once (no inverse is needed during the factorisation
+//                  any more), seeds of the triangular inverse W = L^-1.
 //
 // Cross-workgroup protocol.  The chip has 8 XCDs with one L2 each; an agent-scope fence (__threadfence) is correct but is a
 // whole-L2 write-back (release) / invalidate (acquire) of that XCD -- measured ~18 us per panel hand-over and it wrecks the

@@ -1,9 +1,9 @@
-"""Cholesky time of the two factorisation paths over N (run once per path: BOHIP_CHOL_DATAFLOW=0/1)."""
+"""Cholesky time of the factorisation paths over N (run once per path: BOHIP_CHOL_DATAFLOW=0 / 1 / 2).  usage: python tools/chol_sizes.py [N ...]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bohip
 rng = np.random.default_rng(0)
-for N in (500, 1000, 2000, 3000, 4000, 5000, 6000, 8000):
+for N in ([int(a) for a in sys.argv[1:]] or (500, 1000, 2000, 3000, 4000, 5000, 6000, 8000)):
     d = 8
     X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
     m = bohip.ElasticGPE(d, kernel=bohip.SEArd(np.full(d, np.log(0.5)), 0.0), logNoise=-2.0, capacity=N)

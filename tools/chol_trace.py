@@ -22,7 +22,7 @@ t = np.array(buf, dtype=np.int64)
 T = (N + 1 + 127) // 128
 pub, saw, fin, blk = t[:1024], t[1024:2048], t[2048:3072], t[3072:]
 t0 = blk[0]
-us = lambda v: (v - t0) / 100.0
+us = lambda v: float(v - t0) / 100.0
 for k in range(min(T, 6)):
     print(f"block {k}: pivot start {us(blk[2*k]):8.1f} end {us(blk[2*k+1]):8.1f} us | published {[round(us(pub[8*k+p]),1) for p in range(8)]}")
     if k + 1 < T:
