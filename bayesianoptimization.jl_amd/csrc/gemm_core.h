@@ -20,6 +20,7 @@
 #ifndef BOHIP_ABL
 #define BOHIP_ABL 0   // ablation of k_trigemm_sq's loop (tools only, see gemm_tile_loop_glds3_ks)
 #endif
+#include <type_traits>
 #include "common.h"
 
 namespace bohip {
@@ -84,12 +85,16 @@ __device__ __forceinline__ d2 ds_read128(uint32_t lds_byte_addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(lds_byte_addr), "n"(OFF));
     return r;
 }
-template <int NJ>
+template <int NJ, int XY = 0>   // XY: 0 both members of the contraction-index pair, 1 the even one only, 2 the odd one only
 __device__ __forceinline__ void mma_row(const d2& a, const d2 (&bv)[NJ], double (&acc)[NJ]) {
+    if constexpr (XY != 2) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[j] = mfma444(a.x, bv[j].x, acc[j]);
+        for (int j = 0; j < NJ; ++j) acc[j] = mfma444(a.x, bv[j].x, acc[j]);
+    }
+    if constexpr (XY != 1) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[j] = mfma444(a.y, bv[j].y, acc[j]);
+        for (int j = 0; j < NJ; ++j) acc[j] = mfma444(a.y, bv[j].y, acc[j]);
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -177,6 +182,43 @@ __device__ __forceinline__ void gemm_tile_loop_glds3(const double* __restrict__ 
     }
 }
 
+// One chunk's fragment reads + MFMAs of one wave of the 8-wave loop (below).  B fragments first, then A row by row, issued as
+// inline asm so that the waits are OURS: hipcc answers an LDS read that follows an LDS-DMA with s_waitcnt lgkmcnt(0) (all 12
+// reads) before the first MFMA; here row i starts as soon as its own fragment has landed (LDS returns in order): lgkmcnt(7 - i).
+// skip: row groups below it are all-zero in a triangular block (wave-uniform).
+template <int NJ, int ABL, int XY>
+__device__ __forceinline__ void chunk_mma(const double* ap, const double* bp, int skip, double (&acc)[8][NJ]) {
+    d2 av[8], bv[NJ];
+    const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const double*)ap;
+    const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const double*)bp;
+    if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bv[j]) : "v"(pb));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(av[i]) : "v"(pa));
+    } else {
+        bv[0] = ds_read128<0>(pb); bv[1] = ds_read128<1024>(pb); bv[2] = ds_read128<2048>(pb); bv[3] = ds_read128<3072>(pb);
+        av[0] = ds_read128<0>(pa); av[1] = ds_read128<1024>(pa); av[2] = ds_read128<2048>(pa); av[3] = ds_read128<3072>(pa);
+        av[4] = ds_read128<4096>(pa); av[5] = ds_read128<5120>(pa); av[6] = ds_read128<6144>(pa); av[7] = ds_read128<7168>(pa);
+    }
+    asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(av[0]));
+    if (skip <= 0) mma_row<NJ, XY>(av[0], bv, acc[0]);
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(av[1]));
+    if (skip <= 1) mma_row<NJ, XY>(av[1], bv, acc[1]);
+    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(av[2]));
+    if (skip <= 2) mma_row<NJ, XY>(av[2], bv, acc[2]);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(av[3]));
+    if (skip <= 3) mma_row<NJ, XY>(av[3], bv, acc[3]);
+    asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(av[4]));
+    if (skip <= 4) mma_row<NJ, XY>(av[4], bv, acc[4]);
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(av[5]));
+    if (skip <= 5) mma_row<NJ, XY>(av[5], bv, acc[5]);
+    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(av[6]));
+    if (skip <= 6) mma_row<NJ, XY>(av[6], bv, acc[6]);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[7]));
+    if (skip <= 7) mma_row<NJ, XY>(av[7], bv, acc[7]);
+}
+
 // ---- 8-wave variant: intra-workgroup split of the contraction index ------------------------------
 // Waves 0-3 take the first half (8 of 16 contraction indices) of every chunk, waves 4-7 the second half,
 // same 128 x 64 output tile; partial accumulators are added through LDS at the end.  Per SIMD this puts
@@ -219,9 +261,16 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
     const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
     const int r7a = 4 * (b >> 1) + t, r7b = 4 * (b & 1) + t;
     const int oa = ((4 * khalf + k) ^ r7a) << 1, ob = ((4 * khalf + k) ^ r7b) << 1;
-    const int a_frag = (wr * 64 + r7a) * GL_ROW + oa, b_frag = (wc * 8 * NJ + r7b) * GL_ROW + ob;
-    const bool wave_active = wr * 64 < active_rows;
-    const int skip0 = __builtin_amdgcn_readfirstlane(khalf - 8 * wr);   // wave-uniform: keep it in an SGPR
+    // HALF mode (active_rows <= 64, e.g. the last row tile of W at N = 3000: 57 rows): instead of leaving the waves of the lower
+    // 64 rows idle for the whole job, both row halves of the wave grid work on rows 0..63 -- wr = 0 takes the even member of every
+    // contraction-index pair, wr = 1 the odd one -- and the partial sums are added at the end.  Half the MFMAs per wave and
+    // chunk: the job takes about half as long (those jobs are the LONGEST ones, K = N).
+    const bool half = active_rows <= TILE / 2;
+    const int wre = half ? 0 : wr;
+    const int xy = __builtin_amdgcn_readfirstlane(half ? 1 + wr : 0);
+    const int a_frag = (wre * 64 + r7a) * GL_ROW + oa, b_frag = (wc * 8 * NJ + r7b) * GL_ROW + ob;
+    const bool wave_active = half || wr * 64 < active_rows;
+    const int skip0 = __builtin_amdgcn_readfirstlane(khalf - 8 * wre);   // wave-uniform: keep it in an SGPR
     issue(kc_begin, 0);
     if (kc_begin + 1 < kc_end) {
         issue(kc_begin + 1, 1);
@@ -230,81 +279,55 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    int cur = 0;
+    // the chunk loop exists three times (both / even / odd members): a choice INSIDE the loop costs 40 VGPRs of copies
+    auto run = [&](auto xy_tag) {
+        int cur = 0;
 #if BOHIP_TRACE
-    unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, phn = 0;
+        unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, phn = 0;
 #endif
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        for (int kc = kc_begin; kc < kc_end; ++kc) {
 #if BOHIP_TRACE
-        const unsigned long long tA = __builtin_amdgcn_s_memtime();
+            const unsigned long long tA = __builtin_amdgcn_s_memtime();
 #endif
-        const int nxt2 = cur == 0 ? 2 : cur - 1;
-        const bool more2 = kc + 2 < kc_end;
-        if (more2 && !(ABL & 1)) issue(kc + 2, nxt2);
-        if (wave_active) {
-            d2 av[8], bv[NJ];
-            const double* ap = As + cur * AT + a_frag;
-            const double* bp = Bs + cur * BT + b_frag;
-            // B fragments first, then A row by row, issued as inline asm so that the waits are OURS: hipcc answers an
-            // LDS read that follows an LDS-DMA with s_waitcnt lgkmcnt(0) (all 12 reads) before the first MFMA; here
-            // row i starts as soon as its own fragment has landed (LDS returns in order): lgkmcnt(7 - i).
-            const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const double*)ap;
-            const uint32_t pb = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const double*)bp;
-            if constexpr ((ABL & 2) != 0) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) asm volatile("" : "=v"(bv[j]) : "v"(pb));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(av[i]) : "v"(pa));
-            } else {
-            bv[0] = ds_read128<0>(pb); bv[1] = ds_read128<1024>(pb); bv[2] = ds_read128<2048>(pb); bv[3] = ds_read128<3072>(pb);
-            av[0] = ds_read128<0>(pa); av[1] = ds_read128<1024>(pa); av[2] = ds_read128<2048>(pa); av[3] = ds_read128<3072>(pa);
-            av[4] = ds_read128<4096>(pa); av[5] = ds_read128<5120>(pa); av[6] = ds_read128<6144>(pa); av[7] = ds_read128<7168>(pa);
+            const int nxt2 = cur == 0 ? 2 : cur - 1;
+            const bool more2 = kc + 2 < kc_end;
+            if (more2 && !(ABL & 1)) issue(kc + 2, nxt2);
+            if (wave_active) {
+                const double* ap = As + cur * AT + a_frag;
+                const double* bp = Bs + cur * BT + b_frag;
+                const int skip = kc >= tri_kc ? 2 * (kc - tri_kc) + skip0 : 0;   // all-zero row groups of a triangular block
+                chunk_mma<NJ, ABL, decltype(xy_tag)::value>(ap, bp, skip, acc);
             }
-            // row groups below `skip` are all-zero in a triangular block (wave-uniform): 2 (kc - tri_kc) + khalf - 8 wr
-            const int skip = kc >= tri_kc ? 2 * (kc - tri_kc) + skip0 : 0;
-            asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(av[0]));
-            if (skip <= 0) mma_row<NJ>(av[0], bv, acc[0]);
-            asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(av[1]));
-            if (skip <= 1) mma_row<NJ>(av[1], bv, acc[1]);
-            asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(av[2]));
-            if (skip <= 2) mma_row<NJ>(av[2], bv, acc[2]);
-            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(av[3]));
-            if (skip <= 3) mma_row<NJ>(av[3], bv, acc[3]);
-            asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(av[4]));
-            if (skip <= 4) mma_row<NJ>(av[4], bv, acc[4]);
-            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(av[5]));
-            if (skip <= 5) mma_row<NJ>(av[5], bv, acc[5]);
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(av[6]));
-            if (skip <= 6) mma_row<NJ>(av[6], bv, acc[6]);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[7]));
-            if (skip <= 7) mma_row<NJ>(av[7], bv, acc[7]);
+            __builtin_amdgcn_sched_barrier(0);
+#if BOHIP_TRACE
+            const unsigned long long tB = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (more2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if BOHIP_TRACE
+            const unsigned long long tC = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#if BOHIP_TRACE
+            const unsigned long long tD = __builtin_amdgcn_s_memtime();
+            ph0 += tB - tA; ph1 += tC - tB; ph2 += tD - tC; phn += 1;
+#endif
+            cur = cur == 2 ? 0 : cur + 1;
         }
-        __builtin_amdgcn_sched_barrier(0);
 #if BOHIP_TRACE
-        const unsigned long long tB = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_sched_barrier(0);
+        if (lane == 0 && blockIdx.x < 8192) {
+            unsigned long long* o = g_phase + ((size_t)blockIdx.x * 8 + wave) * 4;
+            o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = phn;
+        }
 #endif
-        if (more2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if BOHIP_TRACE
-        const unsigned long long tC = __builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if constexpr ((ABL & 4) == 0) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-#if BOHIP_TRACE
-        const unsigned long long tD = __builtin_amdgcn_s_memtime();
-        ph0 += tB - tA; ph1 += tC - tB; ph2 += tD - tC; phn += 1;
-#endif
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-#if BOHIP_TRACE
-    if (lane == 0 && blockIdx.x < 8192) {
-        unsigned long long* o = g_phase + ((size_t)blockIdx.x * 8 + wave) * 4;
-        o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = phn;
-    }
-#endif
+    };
+    if (xy == 0) run(std::integral_constant<int, 0>{});
+    else if (xy == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
     // add the second half's partial accumulators into the first half's (through LDS: 32 doubles per lane)
     double* xch = smem;  // 256 lanes x 32 doubles = 64 KB <= staging area
     if (khalf == 1) {
@@ -321,6 +344,25 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
             for (int j = 0; j < NJ; ++j) acc[i][j] += xch[(i * NJ + j) * 256 + tid];
     }
     __syncthreads();
+    if (half) {   // rows 0..63: waves 2, 3 (odd members) into waves 0, 1 (even members); the lower row half ends up zero
+        if (khalf == 0 && wr == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    xch[(i * NJ + j) * 256 + (tid - 128)] = acc[i][j];
+                    acc[i][j] = 0.0;
+                }
+        }
+        __syncthreads();
+        if (khalf == 0 && wr == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] += xch[(i * NJ + j) * 256 + tid];
+        }
+        __syncthreads();
+    }
 }
 
 // Where this lane's accumulator acc[mi][nj] lives inside the 128 x (16 NJ) workgroup tile.

@@ -133,7 +133,7 @@ __device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, co
 __device__ unsigned long long g_trace[4 * 8192];
 #endif
 template <int KS>  // 1: 4 waves; 2: 8 waves, contraction index halved inside the workgroup (default)
-__global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
+__global__ __launch_bounds__(KS * GEMM_THREADS, 2 * KS) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
                                                                 const double* __restrict__ KsT, int64_t ldk,
                                                                 int T, int CT, int64_t alpha_row,
                                                                 double* __restrict__ q_part, int64_t ldq,
@@ -158,7 +158,13 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2) void k_trigemm_sq(const doubl
 #endif
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int n_local = (CT + 7) >> 3;
-    const int rt = T - 1 - slot / n_local;
+    // heaviest first.  Job length = K extent = rt + 1 units, except that a last row tile with <= 64 live rows runs in the
+    // loop's half mode and costs (rt + 1) / 2: it is issued where a job of that length belongs
+    int rt = T - 1 - slot / n_local;
+    if (alpha_row + 1 - (int64_t)(T - 1) * TILE <= TILE / 2 && T > 2) {
+        const int s = slot / n_local, n_before = T - 1 - T / 2;   // row tiles rt <= T-2 that are longer than T / 2 units
+        rt = s < n_before ? T - 2 - s : s == n_before ? T - 1 : T - 1 - s;
+    }
     const int ct = xcd + 8 * (slot % n_local);
     if (ct >= CT || rt < 0) return;
     double acc[8][NJ];
