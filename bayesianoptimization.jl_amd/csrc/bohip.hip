@@ -248,6 +248,7 @@ static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <=
                             // nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every 2 <= T <= CHOL_DF_TCAP.
 static int g_chol_df_tmax = 48;   // N <= ~6100 (N=5000: 3.72 vs 4.74 ms, N=6000: 5.32 vs 5.75 ms)
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
+static int g_trigemm_pull = 0;  // BOHIP_TRIGEMM_PULL=1: persistent k_trigemm_sq_pull (512 workgroups pull jobs) instead of one workgroup per job -- measured slower (0.622 vs 0.596 ms at C2)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
@@ -267,11 +268,13 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq_pull, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inv128, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF_TMAX")) g_chol_df_tmax = atoi(e);
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
+    if (const char* e = getenv("BOHIP_TRIGEMM_PULL")) g_trigemm_pull = atoi(e);
     if (const char* e = getenv("BOHIP_FUSE_FINISH")) g_fuse_finish = atoi(e);
     if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
@@ -697,9 +700,9 @@ static int ensure_score_scratch(bohip_gp* g, int64_t R) {
         if (g->dfz_cnt) hipFree(g->dfz_cnt);
         if (g->dfz_best) hipFree(g->dfz_best);
         g->dfz_cnt = nullptr; g->dfz_best = nullptr; g->fz_cap = 0;
-        HIPCHK(hipMalloc(&g->dfz_cnt, (size_t)(tiles + 1) * sizeof(unsigned)));
+        HIPCHK(hipMalloc(&g->dfz_cnt, (size_t)(tiles + 1 + 16) * sizeof(unsigned)));   // + the job cursors of k_trigemm_sq_pull
         HIPCHK(hipMalloc(&g->dfz_best, (size_t)tiles * sizeof(Best)));
-        HIPCHK(hipMemsetAsync(g->dfz_cnt, 0, (size_t)(tiles + 1) * sizeof(unsigned), g->stream));
+        HIPCHK(hipMemsetAsync(g->dfz_cnt, 0, (size_t)(tiles + 1 + 16) * sizeof(unsigned), g->stream));
         g->fz_cap = tiles;
     }
     const int64_t nb = (R + 255) / 256 + 1;
@@ -743,7 +746,10 @@ static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1,
 static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t Rpad, int64_t r0, double* VT,
                           const FuseParams& fz = FuseParams{}) {
     const int CT = (int)((ncand + CTILE - 1) / CTILE), n_local = (CT + 7) / 8;
-    if (g_ks8)
+    if (g_ks8 && g_trigemm_pull && g->dfz_cnt && 8 * n_local * T > 512)
+        hipLaunchKernelGGL(k_trigemm_sq_pull, dim3(512), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz, g->dfz_cnt + g->fz_cap + 1);
+    else if (g_ks8)
         hipLaunchKernelGGL(k_trigemm_sq<2>, dim3(8 * n_local * T), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->stream, g->dW,
                            g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz);
     else

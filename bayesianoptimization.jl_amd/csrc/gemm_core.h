@@ -230,17 +230,22 @@ constexpr int GEMM_THREADS_8 = 512;
 #if BOHIP_TRACE
 __device__ unsigned long long g_phase[8192 * 8 * 4];   // [block][wave]{issue+mfma, vmcnt wait, barrier wait, iterations}
 #endif
-template <int NJ, int ABL = 0>  // ABL: ablation switches (tools only): 1 no DMA, 2 no LDS reads, 4 no barriers
+// SWAVE: keep the wave index in an SGPR (readfirstlane).  k_trigemm_sq: 128 VGPRs without a spill and scalar branches on the
+// wave's role, +2 %.  k_gemm_nt keeps the vector form: with it it needs 129 VGPRs = ONE workgroup per CU, and the launches
+// that run beside the factorisation's chain (and the inverse's small levels) are faster that way than with two.
+template <int NJ, int ABL = 0, bool SWAVE = false>  // ABL: ablation switches (tools only): 1 no DMA, 2 no LDS reads, 4 no barriers
 __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict__ A, int64_t lda,
                                                         const double* __restrict__ B, int64_t ldb, int kc_begin,
                                                         int kc_end, double* smem, double (&acc)[8][NJ],
-                                                        int active_rows = TILE, int tri_kc = 1 << 30) {
+                                                        int active_rows = TILE, int tri_kc = 1 << 30, int tid_in = -1) {
     // tri_kc: first chunk of a 128 x 128 block of A that is LOWER-TRIANGULAR (row r has zeros at k > r): from there on
     // an 8-row group whose rows all lie above this wave's 8 contraction indices contributes nothing and is skipped
     // (47 % of that block's MFMAs).
     static_assert(NJ == 4, "piece distribution below assumes 16 + 8 DMA pieces per chunk");
     constexpr int AT = TILE * GL_ROW, BT = 16 * NJ * GL_ROW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // tid_in: the caller's copy of threadIdx.x (a persistent kernel passes one the compiler cannot see through, so that
+    // nothing lane-dependent is hoisted out of its job loop and kept alive across the whole job)
+    const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = SWAVE ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
     const int khalf = wave >> 2, w4 = wave & 3, wr = w4 >> 1, wc = w4 & 1;
     double* As = smem;             // [3][128][16]
     double* Bs = smem + 3 * AT;    // [3][64][16]

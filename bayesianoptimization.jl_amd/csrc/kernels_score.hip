@@ -132,41 +132,23 @@ __device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, co
 #if BOHIP_TRACE
 __device__ unsigned long long g_trace[4 * 8192];
 #endif
-template <int KS>  // 1: 4 waves; 2: 8 waves, contraction index halved inside the workgroup (default)
-__global__ __launch_bounds__(KS * GEMM_THREADS, 2 * KS) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
-                                                                const double* __restrict__ KsT, int64_t ldk,
-                                                                int T, int CT, int64_t alpha_row,
-                                                                double* __restrict__ q_part, int64_t ldq,
-                                                                double* __restrict__ mu_raw, int64_t r_off,
-                                                                double* __restrict__ VT, int64_t ldv, FuseParams fz) {
-    constexpr int NJ = 4, CW = CTILE;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-#if BOHIP_TRACE
-    const unsigned long long t_start = wall_clock64();
-    struct TraceEnd {
-        unsigned long long t0;
-        __device__ ~TraceEnd() {
-            if (threadIdx.x == 0) {
-                unsigned hw, xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                unsigned long long* t = g_trace + 4 * (size_t)blockIdx.x;
-                t[0] = t0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;
-            }
-        }
-    } trace_end{t_start};
-#endif
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int n_local = (CT + 7) >> 3;
-    // heaviest first.  Job length = K extent = rt + 1 units, except that a last row tile with <= 64 live rows runs in the
-    // loop's half mode and costs (rt + 1) / 2: it is issued where a job of that length belongs
-    int rt = T - 1 - slot / n_local;
+// position `sq` of the heaviest-first row-tile sequence.  Job length = K extent = rt + 1 units, except that a last row tile
+// with <= 64 live rows runs in the loop's half mode and costs (rt + 1) / 2: it is issued where a job of that length belongs
+__device__ __forceinline__ int trigemm_row_tile(int sq, int T, int64_t alpha_row) {
     if (alpha_row + 1 - (int64_t)(T - 1) * TILE <= TILE / 2 && T > 2) {
-        const int s = slot / n_local, n_before = T - 1 - T / 2;   // row tiles rt <= T-2 that are longer than T / 2 units
-        rt = s < n_before ? T - 2 - s : s == n_before ? T - 1 : T - 1 - s;
+        const int n_before = T - 1 - T / 2;   // row tiles rt <= T-2 that are longer than T / 2 units
+        return sq < n_before ? T - 2 - sq : sq == n_before ? T - 1 : T - 1 - sq;
     }
-    const int ct = xcd + 8 * (slot % n_local);
-    if (ct >= CT || rt < 0) return;
+    return T - 1 - sq;
+}
+
+// one job: row tile rt of W against candidate tile ct of the chunk (all arguments wave-uniform)
+template <int KS>
+__device__ __forceinline__ void trigemm_job(int rt, int ct, const double* __restrict__ W, int64_t ldw,
+                                            const double* __restrict__ KsT, int64_t ldk, int T, int64_t alpha_row,
+                                            double* __restrict__ q_part, int64_t ldq, double* __restrict__ mu_raw, int64_t r_off,
+                                            double* __restrict__ VT, int64_t ldv, const FuseParams& fz, double* smem, int tid) {
+    constexpr int NJ = 4, CW = CTILE;
     double acc[8][NJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -174,12 +156,12 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2 * KS) void k_trigemm_sq(const 
         for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0;
     const int active_rows = (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE);  // rows past alpha' are padding
     if constexpr (KS == 2)
-        gemm_tile_loop_glds3_ks<NJ, BOHIP_ABL>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
-                                    (rt + 1) * (TILE / KC), smem, acc, active_rows, rt * (TILE / KC));
+        gemm_tile_loop_glds3_ks<NJ, BOHIP_ABL, true>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+                                    (rt + 1) * (TILE / KC), smem, acc, active_rows, rt * (TILE / KC), tid);
     else
         gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
                                  (rt + 1) * (TILE / KC), smem, acc, active_rows);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = (wave & 3) >> 1, wc = wave & 1;
+    const int lane = tid & 63, wave = tid >> 6, wr = (wave & 3) >> 1, wc = wave & 1;
     __syncthreads();     // (the raw-barrier loops end on s_barrier; make the reuse of smem below explicit)
     double* red = smem;  // [2][CW]
     if (wave < 4) {
@@ -206,17 +188,96 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2 * KS) void k_trigemm_sq(const 
     }
     }
     __syncthreads();
-    if (threadIdx.x < CW)
-        __hip_atomic_store(q_part + (int64_t)rt * ldq + r_off + (int64_t)ct * CW + threadIdx.x, red[threadIdx.x] + red[CW + threadIdx.x],
+    if (tid < CW)
+        __hip_atomic_store(q_part + (int64_t)rt * ldq + r_off + (int64_t)ct * CW + tid, red[tid] + red[CW + tid],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (fz.tile_cnt != nullptr) {
         __shared__ int s_last;
         const int tile_g = (int)(r_off / CW) + ct;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the agent-scope stores above have landed (a workgroup-scope fence emits no such wait)
         __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicAdd(fz.tile_cnt + tile_g, 1u) == (unsigned)(T - 1);
+        if (tid == 0) s_last = atomicAdd(fz.tile_cnt + tile_g, 1u) == (unsigned)(T - 1);
         __syncthreads();
-        if (s_last && threadIdx.x < 64) trigemm_fused_finish(fz, tile_g, T, q_part, ldq, mu_raw);
+        if (s_last && tid < 64) trigemm_fused_finish(fz, tile_g, T, q_part, ldq, mu_raw);
+    }
+}
+
+template <int KS>  // 1: 4 waves; 2: 8 waves, contraction index halved inside the workgroup (default)
+__global__ __launch_bounds__(KS * GEMM_THREADS, 2 * KS) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
+                                                                const double* __restrict__ KsT, int64_t ldk,
+                                                                int T, int CT, int64_t alpha_row,
+                                                                double* __restrict__ q_part, int64_t ldq,
+                                                                double* __restrict__ mu_raw, int64_t r_off,
+                                                                double* __restrict__ VT, int64_t ldv, FuseParams fz) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+#if BOHIP_TRACE
+    const unsigned long long t_start = wall_clock64();
+    struct TraceEnd {
+        unsigned long long t0;
+        __device__ ~TraceEnd() {
+            if (threadIdx.x == 0) {
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                unsigned long long* t = g_trace + 4 * (size_t)blockIdx.x;
+                t[0] = t0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;
+            }
+        }
+    } trace_end{t_start};
+#endif
+    // blocks are dealt to XCDs round-robin (block b runs on XCD b % 8): an XCD owns the candidate tiles ct = xcd (mod 8) and
+    // walks the row tiles together, heaviest first
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int n_local = (CT + 7) >> 3;
+    const int rt = trigemm_row_tile(slot / n_local, T, alpha_row);
+    const int ct = xcd + 8 * (slot % n_local);
+    if (ct >= CT || rt < 0) return;
+    trigemm_job<KS>(rt, ct, W, ldw, KsT, ldk, T, alpha_row, q_part, ldq, mu_raw, r_off, VT, ldv, fz, smem, (int)threadIdx.x);
+}
+
+// Persistent form: 512 workgroups (two per CU) PULL jobs.  Each XCD has its own list (the candidate tiles ct = xcd (mod 8),
+// row tiles heaviest first -- the W row-tile stream stays shared through that XCD's L2) behind an atomic cursor; a workgroup
+// whose list has run dry steals from the next XCD's.  Against one workgroup per job this removes the per-job dispatch and the
+// fixed eighth of the work per XCD (the XCDs finish up to 2.5 % apart).  jobq: 8 cursors + 1 exit counter, all left at zero.
+__global__ __launch_bounds__(2 * GEMM_THREADS, 4) void k_trigemm_sq_pull(const double* __restrict__ W, int64_t ldw,
+                                                                const double* __restrict__ KsT, int64_t ldk,
+                                                                int T, int CT, int64_t alpha_row,
+                                                                double* __restrict__ q_part, int64_t ldq,
+                                                                double* __restrict__ mu_raw, int64_t r_off,
+                                                                double* __restrict__ VT, int64_t ldv, FuseParams fz,
+                                                                unsigned* __restrict__ jobq) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_job, s_probe;
+    const int xcd = blockIdx.x & 7;
+    const int n_local = (CT + 7) >> 3, per = n_local * T;
+    int probe = 0;   // lists found empty so far, starting from the own one
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int j = -1, p = probe;
+            for (; p < 8; ++p) {
+                const int x = (xcd + p) & 7;
+                const unsigned sq = atomicAdd(jobq + x, 1u);
+                if (sq < (unsigned)per) { j = x * per + (int)sq; break; }
+            }
+            s_job = j; s_probe = p;
+        }
+        __syncthreads();
+        const int j = __builtin_amdgcn_readfirstlane(s_job);
+        probe = __builtin_amdgcn_readfirstlane(s_probe);
+        __syncthreads();
+        if (j < 0) break;
+        const int x = j / per, sq = j - x * per;
+        const int rt = trigemm_row_tile(sq / n_local, T, alpha_row);
+        const int ct = x + 8 * (sq % n_local);
+        if (ct >= CT) continue;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));   // opaque per job: nothing lane-dependent is hoisted out of this loop (it cost 86 spilled VGPRs)
+        trigemm_job<2>(rt, ct, W, ldw, KsT, ldk, T, alpha_row, q_part, ldq, mu_raw, r_off, VT, ldv, fz, smem, tid);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && atomicAdd(jobq + 8, 1u) == gridDim.x - 1) {   // last one out resets the cursors
+#pragma unroll
+        for (int x = 0; x < 9; ++x) __hip_atomic_store(jobq + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

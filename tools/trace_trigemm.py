@@ -41,6 +41,9 @@ try:
     slot = np.arange(nb) >> 3
     n_local = (CT + 7) // 8
     rt = T - 1 - slot // n_local
+    if (N_OBS + 1) - (T - 1) * 128 <= 64 and T > 2:   # half-mode last tile is issued where a job of its length belongs
+        sq = slot // n_local; nbf = T - 1 - T // 2
+        rt = np.where(sq < nbf, T - 2 - sq, np.where(sq == nbf, T - 1, T - 1 - sq))
     for r in sorted(set(rt[ok])):
         sel = ok & (rt == r)
         print(f"  rt={r:2d} jobs {sel.sum():4d} dur mean {np.mean((t1 - t0)[sel]):8.1f} ticks  per-unit {np.mean((t1 - t0)[sel]) / (r + 1):6.1f}  start mean {np.mean(t0[sel] - start):9.1f}  end mean {np.mean(t1[sel]):9.1f}")
@@ -49,6 +52,10 @@ try:
     for k_, a, b in zip(key[ok], t0[ok], t1[ok]):
         ends[k_] = max(ends.get(k_, 0), b - start)
         busy[k_] = busy.get(k_, 0) + (b - a)
+    for x in range(8):   # does a whole XCD (a fixed eighth of the jobs: blockIdx % 8) finish early or late?
+        sel = ok & (xcc == x)
+        ex = [v for k_, v in ends.items() if (k_ >> 8) == x]
+        print(f"  XCD {x}: CUs {len(ex):3d}  jobs {sel.sum():4d}  last end {t1[sel].max():7d}  mean CU end {np.mean(ex):9.0f}  sum of WG durations {np.sum((t1 - t0)[sel]):10d}")
     e = np.array(list(ends.values()))
     print(f"per-CU last end: min {e.min()} mean {e.mean():.0f} max {e.max()} (span {span}); mean idle tail {(span - e.mean()) / span:.3%}")
     bz = np.array(list(busy.values()))
