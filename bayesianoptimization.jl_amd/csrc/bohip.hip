@@ -76,6 +76,8 @@ struct bohip_gp {
     hipStream_t inv_stream = nullptr;             // W = L^-1 grows block by block beside the factorisation's diagonal chain
     hipEvent_t ev_blk = nullptr, ev_inv = nullptr;
     hipEvent_t ev_gate = nullptr;                 // a diagonal-block kernel is about to start: release one piece of the pending bulk update
+    std::vector<hipEvent_t> ev_tier;              // its cross-stream hand-overs (two per group of four blocks)
+    bool w_seeded = false;                        // the diagonal blocks of W were produced during the factorisation (k_chol_inverter)
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
@@ -243,16 +245,21 @@ static int g_split = 1;   // split-K path for batches of a few hundred candidate
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
+static int g_chol_df2_hi = 1;          // its K = 512 launches with two workgroups per CU (BOHIP_CHOL_DF2_HI=0: one)
+static int g_chol_df2_win = 6;         // its window: block k's flagged update reaches column 4 (k / 4) + win (BOHIP_CHOL_DF2_WIN, 6..10; 6 is the least that keeps the chain's next tiles inside)
+static int g_chol_df2_min = 47;  // cholesky_dataflow2 (large-T form) from this many row tiles on (BOHIP_CHOL_DF2_MIN): N=6000 5.13 vs 5.3 ms, N=8000 7.8
+                                 // vs 8.65, N=10000 12.1 vs 13.06, N=11000 14.6 vs 15.4; below (N=5600) the first form is faster (4.58 vs 4.78)
 static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <= T <= g_chol_df_tmax row tiles: N=3000 1.66 vs 2.71 ms, N=1000 0.57
                             // vs 0.82 ms.  Far beyond that its one-tier K=128 bulk updates lose to the two-tier launch chain, below 3 there is
                             // nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every 2 <= T <= CHOL_DF_TCAP.
-static int g_chol_df_tmax = 48;   // N <= ~6100 (N=5000: 3.72 vs 4.74 ms, N=6000: 5.32 vs 5.75 ms)
+static int g_chol_df_tmax = 88;   // N <= ~11200 (N=12000: the launch chain is ahead again, 18.5 vs 18.9 ms)
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int g_trigemm_pull = 0;  // BOHIP_TRIGEMM_PULL=1: persistent k_trigemm_sq_pull (512 workgroups pull jobs) instead of one workgroup per job -- measured slower (0.622 vs 0.596 ms at C2)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
-static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr) {
+static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr, bool hi = false) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
-    hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), st ? st : g->stream, p);
+    if (hi) hipLaunchKernelGGL(k_gemm_nt_hi, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), st ? st : g->stream, p);
+    else hipLaunchKernelGGL(k_gemm_nt, dim3(p.mt * p.nt64, batch), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), st ? st : g->stream, p);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -271,7 +278,12 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq_pull, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inv128, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_pair, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_hi, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_DF2_MIN")) g_chol_df2_min = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_DF2_HI")) g_chol_df2_hi = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_DF2_WIN")) g_chol_df2_win = std::min(10, std::max(6, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_DF_TMAX")) g_chol_df_tmax = atoi(e);
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_PULL")) g_trigemm_pull = atoi(e);
@@ -359,8 +371,7 @@ static int inverse_join(bohip_gp* g, hipStream_t st, int P, int nb) {
 // flag-gated trailing updates of every block are enqueued up front on the side stream.  No host events inside the factorisation.
 static size_t chol_abort_word(int T) { return (size_t)T * (CH_PANELS + 7) + (size_t)T * T * (CH_PANELS + 1); }   // see the layout in cholesky_dataflow
 static size_t chol_flag_words(int T) { return chol_abort_word(T) + 4; }
-static int cholesky_dataflow(bohip_gp* g, int T) {
-    const int64_t ld = g->ld;
+static CholFlags chol_flags_layout(bohip_gp* g, int T) {
     CholFlags fl{};
     fl.T = T;
     fl.panel = g->dchol_flags;
@@ -377,12 +388,18 @@ static int cholesky_dataflow(bohip_gp* g, int T) {
     fl.w16_g = g->dchol_idl;
     fl.crit_want = 16u;   // the row-(k+2) update: 4 workgroups x 4 storing waves
     fl.panel_want = 3u;   // three publishing waves per panel
+    return fl;
+}
+static int cholesky_dataflow(bohip_gp* g, int T) {
+    const int64_t ld = g->ld;
+    CholFlags fl = chol_flags_layout(g, T);
+    g->w_seeded = false;
     HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
     HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
     // Four launches that live for the whole factorisation and talk through flags:
     //   critical stream: the chain (row owners, critical followers of rows k+1 / k+2, gated update of row k+2)
     //   two more       : one follower workgroup per row >= 3, two column-updater workgroups per row >= 3
-    hipLaunchKernelGGL(k_chol_chain, dim3(T > 1 ? 8 : 1), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo);
+    hipLaunchKernelGGL(k_chol_chain, dim3(T > 1 ? 8 : 1), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
     HIPCHK(hipGetLastError());
     if (T > 3) {
         HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
@@ -424,6 +441,118 @@ static int cholesky_dataflow(bohip_gp* g, int T) {
     return 0;
 }
 
+// ---- A2, dataflow form for LARGE T.  The form above keeps T - 3 row followers and 2 (T - 3) column updaters resident for the
+// whole factorisation: at T = 63 they sit on ~180 of the 256 CUs and halve the rate of every GEMM beside them, and its far
+// updates are one K = 128 launch per block over the whole trailing matrix (~16 TF/s).  Here only the chain (8 workgroups)
+// and one inverter workgroup are persistent:
+//   rows >= k+3 of L(:, k)      one launch: product with W_kk' (k_chol_inverter raises solved[k] a few us after the pivot block)
+//   columns k+1 .. 4m+6, m=k/4  one flagged K = 128 launch (first row = what the chain reads next, counted in rest[k])
+//   columns 4m+7 .. 4m+10       K = 512, plain, once group m (four blocks) is solved; the next group's flagged update waits for it
+//   columns >= 4m+11            K = 512, plain, behind it on the same low-priority stream
+// Every launch with an in-kernel wait is on ONE in-order stream and waits only for the chain or for launches before it on that
+// stream; the plain launches are released by host events: no spinning workgroup can keep a producer off the chip.
+static int cholesky_dataflow2(bohip_gp* g, int T) {
+    const int64_t ld = g->ld;
+    // the handle's four streams and no more: a fifth and sixth stream ended up sharing a hardware queue on the first handle of a
+    // process (the long plain launches then sat in front of the flagged ones: 14.2 instead of 12.2 ms at N = 10000)
+    hipStream_t flagged_stream = g->col_stream, bulk_stream = g->side_stream;
+    CholFlags fl = chol_flags_layout(g, T);
+    const int win = g_chol_df2_win;
+    fl.mode2 = win;
+    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
+    HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
+    hipLaunchKernelGGL(k_chol_chain, dim3(9), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamWaitEvent(flagged_stream, g->ev_panels, 0));
+    HIPCHK(hipStreamWaitEvent(bulk_stream, g->ev_panels, 0));
+    while ((int)g->ev_tier.size() < 2 * (T / 4 + 1)) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g->ev_tier.push_back(ev);
+    }
+    // ONE in-order stream of flagged launches.  Launch k carries Update(k) and Solve(k+1) in one grid (k_gemm_nt_pair), so that
+    // the row solve is already resident when the inverse of its diagonal block arrives:
+    //   Solve(k)   row i waits for solved[k] and for tile (i, k) from Update(k-1); counts S(i, k) into colr[k T + i] (16 = done)
+    //   Update(k)  tile (i, j) waits for S(i, k) and S(j, k) (rows k+1, k+2: the chain's last-panel flags); its column k+1
+    //              counts into xp[(k T + i) 8] (rows >= k+3 have no other use for that word), its first row into rest[k]
+    hipStream_t ss = flagged_stream;
+    auto solve_params = [&](int k) {
+        GemmNTParams sv{};   // S(i, k) = A(i, k) W_kk' for i >= k+3
+        sv.A = g->dL + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; sv.lda = ld;
+        sv.B = g->dW + (int64_t)k * TILE * (ld + 1); sv.ldb = ld;
+        sv.C = g->dS + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; sv.ldc = ld;
+        sv.mt = T - (k + 3); sv.nt64 = 2; sv.kc = TILE / KC; sv.alpha = 1.0; sv.beta = 0.0;
+        if (k == 0) {
+            sv.wait_flag = fl.solved + k; sv.wait_val = 1u; sv.wait_stride_ti = 0;
+        } else {
+            sv.wait_flag = fl.xp + ((size_t)(k - 1) * T + (k + 3)) * CH_PANELS; sv.wait_val = 16u; sv.wait_stride_ti = CH_PANELS;
+            sv.wait_flag2 = fl.solved + k; sv.wait_val2 = 1u; sv.wait_stride_tj2 = 0;
+        }
+        sv.abort_flag = fl.abort;
+        sv.signal = fl.farall + k;         // (selects the agent-scope stores: the update beside it reads these tiles)
+        sv.signal_rows = fl.colr + (size_t)k * T + (k + 3); sv.signal_rows_ntj = 2; sv.signal_rows_stride = 1;
+        return sv;
+    };
+    auto update_params = [&](int k) {
+        const int c_hi = near_last_col(T, k, win);
+        GemmNTParams f{};    // tiles (i, j), i >= k+3, k+1 <= j <= c_hi:  -= S(i, k) S(j, k)'
+        f.A = g->dS + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; f.lda = ld;
+        f.B = g->dS + (int64_t)(k + 1) * TILE * ld + (int64_t)k * TILE; f.ldb = ld;
+        f.C = g->dL + (int64_t)(k + 3) * TILE * ld + (int64_t)(k + 1) * TILE; f.ldc = ld;
+        f.mt = T - (k + 3); f.nt64 = 2 * (c_hi - k); f.kc = TILE / KC; f.alpha = -1.0; f.beta = 1.0;
+        f.diag_skip = 1; f.row0 = (int64_t)(k + 3) * TILE; f.col0 = (int64_t)(k + 1) * TILE;
+        f.wait_flag = fl.colr + (size_t)k * T + (k + 3); f.wait_val = 16u; f.wait_stride_ti = 1;
+        f.wait_flag2 = fl.xp + ((size_t)k * T + (k + 1)) * CH_PANELS + (CH_PANELS - 1); f.wait_val2 = 1u; f.wait_stride_tj2 = CH_PANELS;
+        f.wait2_tj2_max = 2; f.wait2_rows = 1;
+        f.signal = fl.colall + k;          // (selects the agent-scope stores; nobody waits for the whole launch)
+        f.signal_row0 = fl.rest + k;       // row k+3: what the chain's followers and gated updates of block k+1 start from
+        f.signal_rows = fl.xp + ((size_t)k * T + (k + 3)) * CH_PANELS; f.signal_rows_ntj = 2; f.signal_rows_stride = CH_PANELS;
+        f.first_row_col = 1; f.abort_flag = fl.abort;
+        return f;
+    };
+    if (T > 3) CHK(launch_gemm_nt(g, solve_params(0), 1, ss, true));
+    for (int k = 0; k + 3 < T; ++k) {
+        const int m = k / 4;
+        if (k % 4 == 0 && m >= 1 && 4 * (m - 1) + win + 1 <= T - 1)   // columns 4m+3 .. 4m+6 carry group m-1 only after its first K = 512 launch
+            HIPCHK(hipStreamWaitEvent(ss, g->ev_tier[2 * (m - 1) + 1], 0));
+        const GemmNTParams f = update_params(k);
+        if (k + 4 < T) {
+            const GemmNTParams sv = solve_params(k + 1);
+            hipLaunchKernelGGL(k_gemm_nt_pair, dim3(f.mt * f.nt64 + sv.mt * sv.nt64), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), ss, f, sv,
+                               f.mt * f.nt64);
+            HIPCHK(hipGetLastError());
+        } else {
+            CHK(launch_gemm_nt(g, f, 1, ss, true));
+        }
+        if (k % 4 == 3 && 4 * m + win + 1 <= T - 1) {
+            // group m is solved for every row once this launch has finished (the update waited for every row of S(:, k))
+            HIPCHK(hipEventRecord(g->ev_tier[2 * m], ss));
+            HIPCHK(hipStreamWaitEvent(bulk_stream, g->ev_tier[2 * m], 0));
+            for (int part = 0; part < 2; ++part) {
+                const int c0 = part == 0 ? 4 * m + win + 1 : 4 * m + win + 5, c1 = part == 0 ? std::min(T - 1, 4 * m + win + 4) : T - 1;
+                if (c0 <= c1) {
+                    GemmNTParams q{};
+                    q.A = g->dS + (int64_t)c0 * TILE * ld + (int64_t)(4 * m) * TILE; q.lda = ld;
+                    q.B = q.A; q.ldb = ld;
+                    q.C = g->dL + (int64_t)c0 * TILE * (ld + 1); q.ldc = ld;
+                    q.mt = T - c0; q.nt64 = 2 * (c1 - c0 + 1); q.kc = 4 * (TILE / KC); q.alpha = -1.0; q.beta = 1.0;
+                    q.diag_skip = 1; q.row0 = (int64_t)c0 * TILE; q.col0 = (int64_t)c0 * TILE;
+                    CHK(launch_gemm_nt(g, q, 1, bulk_stream, g_chol_df2_hi != 0));
+                }
+                if (part == 0) HIPCHK(hipEventRecord(g->ev_tier[2 * m + 1], bulk_stream));
+            }
+        }
+    }
+    HIPCHK(hipEventRecord(g->ev_inv, ss));
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
+    HIPCHK(hipEventRecord(g->ev_blk, bulk_stream));
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_blk, 0));
+    hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
+    HIPCHK(hipGetLastError());
+    g->w_seeded = true;
+    return 0;
+}
+
 static int refit(bohip_gp* g) {
     CHK(one_time_kernel_setup());
     const int64_t N = g->n;
@@ -450,11 +579,14 @@ static int refit(bohip_gp* g) {
     t_end(g);
     t_begin(g, "cholesky");
     if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP)) {
-        CHK(cholesky_dataflow(g, T));
+        if (T >= g_chol_df2_min) CHK(cholesky_dataflow2(g, T));
+        else CHK(cholesky_dataflow(g, T));
         t_end(g);
         t_begin(g, "tri_inverse");
-        hipLaunchKernelGGL(k_inv128, dim3(T), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, g->dL, ld, g->dW, g->dWT, ld);
-        HIPCHK(hipGetLastError());
+        if (!g->w_seeded) {
+            hipLaunchKernelGGL(k_inv128, dim3(T), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, g->dL, ld, g->dW, g->dWT, ld);
+            HIPCHK(hipGetLastError());
+        }
         for (int h = 1; h < T; h *= 2) CHK(inverse_level(g, g->stream, 0, T, h));
         t_end(g);
         t_begin(g, "alpha");
@@ -1130,6 +1262,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->ev_bulk) hipEventDestroy(g->ev_bulk);
     if (g->inv_stream) { hipStreamSynchronize(g->inv_stream); hipStreamDestroy(g->inv_stream); }
     if (g->col_stream) { hipStreamSynchronize(g->col_stream); hipStreamDestroy(g->col_stream); }
+    for (hipEvent_t ev : g->ev_tier) hipEventDestroy(ev);
     if (g->ev_blk) hipEventDestroy(g->ev_blk);
     if (g->ev_inv) hipEventDestroy(g->ev_inv);
     if (g->ev_gate) hipEventDestroy(g->ev_gate);

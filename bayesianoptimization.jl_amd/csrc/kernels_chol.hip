@@ -50,7 +50,7 @@ static_assert(WK_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "worker arrays must fit inside
 
 struct CholFlags {
     unsigned* panel;      // [T * 8]   panel p of block k is published (columns of L_kk in L, 1/diag in idl_g)
-    unsigned* solved;     // [T]       L(k+1, k) is complete in S (written by the owner of row k+1)
+    unsigned* solved;     // [T]       mode2: W_kk = L_kk^-1 is in W / W' (k_chol_inverter)
     unsigned* crit;       // [T]       counter: waves of the update launch for row k+2 of block k that have finished
     unsigned* abort;      // [1]       set on a spin time-out: every wait returns at once
     double* w16_g;        // [T * 8][16][16] inverse of each 16 x 16 pivot block (lower, zeros above), published with its panel
@@ -62,6 +62,9 @@ struct CholFlags {
     unsigned* farall;     // [T]       storing waves of the first 128 columns (column k+2) of block k's far update
     unsigned* fol;        // [T]       bulk followers of block k that have finished
     unsigned* colall;     // [T]       (every storing wave of block k's column update; not waited on)
+    int mode2;            // > 0: large-T form, the value is the window `win` (6): block k's flagged update covers columns k+1 .. 4 (k / 4) + win -- (cholesky_dataflow2): no persistent followers beyond the chain -- rows >= k+3 are solved by
+                          // a launch against the inverse W_kk (k_chol_inverter raises solved[k]), block k's flagged update covers the
+                          // columns k+1 .. 4 (k / 4) + 6, the columns beyond get four blocks at a time from plain K = 512 launches
     unsigned crit_want;   // value of crit[k] when the whole row-(k+2) update launch of block k is in memory
     unsigned panel_want;  // value of panel[..] when every publishing wave has seen its stores land
 };
@@ -441,8 +444,13 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
     }
 }
 
-// waves of the first row tile of block k's far update (host: nt64 = 2 (T - k - 2); every workgroup adds 8)
-__device__ __forceinline__ unsigned rest_want(int T, int k) { return 8u * 2u * (unsigned)(T - k - 2); }
+// last column of block k's flagged update in mode2
+__host__ __device__ __forceinline__ int near_last_col(int T, int k, int win) { return min(T - 1, 4 * (k / 4) + win); }
+// waves of the first row tile (row k+3) of block k's flagged update: every workgroup of that row adds 8, with or without a tile
+// (host: nt64 = 2 (T - k - 2) columns k+2 ..; mode2: columns k+1 .. near_last_col)
+__device__ __forceinline__ unsigned rest_want(const CholFlags& fl, int k) {
+    return fl.mode2 ? 8u * 2u * (unsigned)(near_last_col(fl.T, k, fl.mode2) - k) : 8u * 2u * (unsigned)(fl.T - k - 2);
+}
 
 // ---- role 2 (workgroups 2, 3): critical followers.  Row r is followed twice -- as "row k+2" during block k = r-2 and as
 // "row k+1" during block k = r-1 -- always by the workgroup of its parity, so at any block the two rows next to the pivot
@@ -457,6 +465,7 @@ __device__ __forceinline__ void crit_follower(double* __restrict__ Lmat, int64_t
         if (k >= 1) {   // tile (r, k) must carry block k-1's update: row k+1 gets it from the gated update, row k+2 from the column launch
             if (tid == 0) {
                 if (r == k + 1) flag_wait_ge(fl.crit + (k - 1), fl.crit_want, fl.abort);
+                else if (fl.mode2) flag_wait_ge(fl.rest + (k - 1), rest_want(fl, k - 1), fl.abort);   // tile (k+2, k): first row of block k-1's launch
                 else flag_wait_ge(fl.colr + (size_t)(k - 1) * T + r, 8u, fl.abort);   // tile (k+2, k): its column updaters of block k-1
             }
             __syncthreads();
@@ -561,18 +570,61 @@ __device__ __forceinline__ void gated_worker(double* __restrict__ Lmat, int64_t 
         double* C = Lmat + (int64_t)(k + 2) * TILE * ld + (int64_t)(k + 1) * TILE + (int64_t)tj * CTILE;
         const unsigned* fa = xp_at(fl, k, k + 2);
         gated_tile(A, B, C, ld, (int64_t)(k + 2) * TILE, (int64_t)(k + 1) * TILE + (int64_t)tj * CTILE, fa,
-                   tj < 2 ? xp_at(fl, k, k + 1) : fa, k >= 1 ? fl.rest + (k - 1) : nullptr, k >= 1 ? rest_want(T, k - 1) : 0u,
+                   tj < 2 ? xp_at(fl, k, k + 1) : fa, k >= 1 ? fl.rest + (k - 1) : nullptr, k >= 1 ? rest_want(fl, k - 1) : 0u,
                    fl.crit + k, fl, sm);
         if (threadIdx.x == 0 && tj == 0) CH_MARK(3300 + 4 * k + 2);
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// mode2: one persistent workgroup of the chain kernel turns every finished diagonal block into its inverse W_kk (the inverse half of k_potf2_inv)
+// and raises solved[k]: the launch that solves the rows >= k+3 of L(:, k) as a product with W_kk' waits for it.  The same
+// blocks are the seeds of the triangular inverse W = L^-1, so k_inv128 is not needed afterwards.
+// ------------------------------------------------------------------------------------------------------------------------
+// ---- role 4 (workgroup 8, mode2 only; its upper four waves leave at once -- ended waves do not take part in barriers)
+__device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ W,
+                                              double* __restrict__ WT, int64_t ldw, int T, const CholFlags& fl, double* sm) {
+    if (threadIdx.x >= PF_THREADS) return;
+    double* a = sm;
+    double* idl = sm + TILE * PF_LD + TILE;
+    const int tid = threadIdx.x;
+    for (int k = 0; k < T; ++k) {
+        if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + (CH_PANELS - 1), fl.panel_want, fl.abort);
+        __syncthreads();
+        const int64_t off = (int64_t)k * TILE;
+        const double* Lblk = Lmat + off * (ld + 1);
+        {   // mirror image: a[c][r] = L[r][c] for c < r, the lower triangle is workspace for W (panels were published agent-scope)
+            const int j = tid & 127, ih = tid >> 7;
+#pragma unroll 1
+            for (int i0 = 0; i0 < TILE; i0 += 32) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = ld_agent(Lblk + (int64_t)(i0 + 2 * u + ih) * ld + j);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + 2 * u + ih;
+                    if (j < i) a[j * PF_LD + i] = v[u];
+                    else if (j == i) idl[i] = 1.0 / v[u];
+                }
+            }
+        }
+        __syncthreads();
+        inverse_phase<true>(a, idl, tid, W + off * (ldw + 1), WT + off * (ldw + 1), ldw);
+        release_wg();
+        __syncthreads();
+        if (tid == 0) flag_set(fl.solved + k, 1u);
+    }
+}
+
 // The persistent chain: 8 workgroups of 512 threads, one per CU (the owners' LDS image fills it).
 __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_chain(double* __restrict__ Lmat, int64_t ld, double* __restrict__ S,
-                                                           int T, CholFlags fl, int* __restrict__ info) {
+                                                           int T, CholFlags fl, int* __restrict__ info, double* __restrict__ W,
+                                                           double* __restrict__ WT) {
     extern __shared__ double sm[];
     const int b = blockIdx.x;
-    if (b < 2) {
+    if (b == 8) {
+        inverter_role(Lmat, ld, W, WT, ld, T, fl, sm);
+    } else if (b < 2) {
         if ((threadIdx.x >> 8) == 0) chain_owner<0>(Lmat, ld, S, T, fl, info, sm, b);
         else chain_owner<1>(Lmat, ld, S, T, fl, info, sm, b);
     } else if (b < 4) {

@@ -311,6 +311,7 @@ __device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int
 
 // B0 + B1 of the header above on an image whose strict upper triangle (mirror) holds L and whose idl[] holds 1 / L_ii:
 // W = L^-1 is built in the lower triangle and stored to Wblk (lower) and WTblk (upper).  Shared by k_potf2_inv and k_inv128.
+template <bool SC1 = false>   // SC1: the result is read by kernels that are already running (agent-scope stores)
 __device__ __forceinline__ void inverse_phase(double* a, const double* idl, int tid, double* __restrict__ Wblk,
                                               double* __restrict__ WTblk, int64_t ldw) {
     if (tid < TILE) {
@@ -337,14 +338,16 @@ __device__ __forceinline__ void inverse_phase(double* a, const double* idl, int 
             d2 v;
             v.x = a[i * PF_LD + c];
             v.y = (c + 1 <= i) ? a[i * PF_LD + c + 1] : 0.0;
-            *reinterpret_cast<d2*>(Wblk + (int64_t)i * ldw + c) = v;
+            if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(Wblk + (int64_t)i * ldw + c), "v"(v) : "memory");
+            else *reinterpret_cast<d2*>(Wblk + (int64_t)i * ldw + c) = v;
         }
         // W'[r][q] = W[q][r] for q >= r: row r = i, columns q = c, c + 1
         if (c + 1 >= i) {
             d2 v;
             v.x = (c >= i) ? a[c * PF_LD + i] : 0.0;
             v.y = a[(c + 1) * PF_LD + i];
-            *reinterpret_cast<d2*>(WTblk + (int64_t)i * ldw + c) = v;
+            if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTblk + (int64_t)i * ldw + c), "v"(v) : "memory");
+            else *reinterpret_cast<d2*>(WTblk + (int64_t)i * ldw + c) = v;
         }
     }
 }
@@ -492,6 +495,10 @@ struct GemmNTParams {
     const unsigned* wait_flag2;   // optional second flag, same rule
     unsigned wait_val2;
     int wait_stride_ti, wait_stride_tj2;   // this workgroup waits on wait_flag[ti * stride_ti] and wait_flag2[(tj / 2) * stride_tj2]
+    int wait2_tj2_max;            // > 0: the second flag only exists for tj / 2 < this; beyond, the B rows are rows of the A range:
+    int wait2_rows;               //      wait2_rows = 1: wait on wait_flag[(tj / 2 - wait2_tj2_max) * wait_stride_ti], 0: no wait
+    unsigned* signal_rows;        // per row tile: waves of the column tiles tj < signal_rows_ntj count into signal_rows[ti * signal_rows_stride]
+    int signal_rows_ntj, signal_rows_stride;
     unsigned* signal;
     unsigned* signal_row0;        // the workgroups of the first row tile (ti == 0, scheduled first) also count here
     unsigned* signal_col0;        // the workgroups of the first 128 columns (tj < 2) also count here
@@ -500,32 +507,38 @@ struct GemmNTParams {
     unsigned* abort_flag;
 };
 
-__global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bid, const int z, double* smem) {
     // klo_from_n: the contraction of column tile tj starts at 128 (tj/2) -> low tj = long jobs: issue them first
-    int ti = p.klo_from_n ? blockIdx.x % p.mt : blockIdx.x / p.nt64;
-    int tj = p.klo_from_n ? blockIdx.x / p.mt : blockIdx.x % p.nt64;
+    int ti = p.klo_from_n ? bid % p.mt : bid / p.nt64;
+    int tj = p.klo_from_n ? bid / p.mt : bid % p.nt64;
     if (p.first_row_col && p.nt64 > 2) {
-        const int b = blockIdx.x, edge = p.nt64 + 2 * (p.mt - 1);
+        const int b = bid, edge = p.nt64 + 2 * (p.mt - 1);
         if (b < p.nt64) { ti = 0; tj = b; }
         else if (b < edge) { ti = 1 + (b - p.nt64) / 2; tj = (b - p.nt64) & 1; }
         else { ti = 1 + (b - edge) / (p.nt64 - 2); tj = 2 + (b - edge) % (p.nt64 - 2); }
     }
-    const int z = blockIdx.y;
     const bool no_tile = (p.diag_skip && p.col0 + CTILE * (int64_t)tj >= p.row0 + (int64_t)TILE * (ti + 1)) ||
                          (p.total_t > 0 && (p.row_t0 + z * p.row_ts + ti >= p.total_t || p.col_t0 + z * p.col_ts + (tj >> 1) >= p.total_t));
     if (no_tile) {
         if (p.signal && threadIdx.x == 0) atomicAdd(p.signal, 8u);
         if (p.signal_row0 && ti == 0 && threadIdx.x == 0) atomicAdd(p.signal_row0, 8u);
         if (p.signal_col0 && tj < 2 && threadIdx.x == 0) atomicAdd(p.signal_col0, 8u);
+        if (p.signal_rows && tj < p.signal_rows_ntj && threadIdx.x == 0) atomicAdd(p.signal_rows + (int64_t)ti * p.signal_rows_stride, 8u);
         return;
     }
     if (p.wait_flag) {
         if (threadIdx.x == 0) {
             for (long it = 0;; ++it) {
-                if (__hip_atomic_load(p.wait_flag + (int64_t)ti * p.wait_stride_ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val &&
-                    (!p.wait_flag2 || __hip_atomic_load(p.wait_flag2 + (int64_t)(tj >> 1) * p.wait_stride_tj2, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val2)) break;
+                bool ok = __hip_atomic_load(p.wait_flag + (int64_t)ti * p.wait_stride_ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+                if (ok && p.wait_flag2) {
+                    const int tj2 = tj >> 1;
+                    if (p.wait2_tj2_max > 0 && tj2 >= p.wait2_tj2_max)
+                        ok = !p.wait2_rows || __hip_atomic_load(p.wait_flag + (int64_t)(tj2 - p.wait2_tj2_max) * p.wait_stride_ti, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+                    else
+                        ok = __hip_atomic_load(p.wait_flag2 + (int64_t)tj2 * p.wait_stride_tj2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val2;
+                }
+                if (ok) break;
                 if (p.abort_flag && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
                 if (it > 40000000L) { if (p.abort_flag) atomicExch(p.abort_flag, 1u); break; }
@@ -585,6 +598,7 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
             atomicAdd(p.signal, 1u);
             if (p.signal_row0 && ti == 0) atomicAdd(p.signal_row0, 1u);
             if (p.signal_col0 && tj < 2) atomicAdd(p.signal_col0, 1u);
+            if (p.signal_rows && tj < p.signal_rows_ntj) atomicAdd(p.signal_rows + (int64_t)ti * p.signal_rows_stride, 1u);
         }
         return;
     }
@@ -607,6 +621,26 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
             if (CT) CT[(int64_t)c * p.ldct + r] = v;
         }
     }
+}
+
+__global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    gemm_nt_body(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+// Two launches in one grid: blocks [0, na) run `a`, the rest run `b`.  cholesky_dataflow2 puts block k's update and block k+1's
+// row solve into one launch: the solve's workgroups wait (in-kernel) for counters the update's first workgroups raise -- those
+// have lower block numbers, are dispatched first and wait for nothing in this launch -- so both are resident when the inverse
+// of the next diagonal block arrives, and ONE in-order stream carries every flagged launch.
+// (these two are compiled for FOUR waves per SIMD = 128 VGPRs = two workgroups per CU: throughput launches.  k_gemm_nt itself
+// stays at 129 VGPRs / one workgroup per CU, which suits the small launches beside the first dataflow form's chain better.)
+__global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_gemm_nt_hi(GemmNTParams p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    gemm_nt_body(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+}
+__global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_gemm_nt_pair(GemmNTParams a, GemmNTParams b, int na) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if ((int)blockIdx.x < na) gemm_nt_body(a, (int)blockIdx.x, 0, smem);
+    else gemm_nt_body(b, (int)blockIdx.x - na, 0, smem);
 }
 
 // dst[i][j] = src[i][j] on every 128-tile strictly below the diagonal tiles (the factorisation parks the solved
