@@ -245,6 +245,8 @@ static int g_split = 1;   // split-K path for batches of a few hundred candidate
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
+static int g_inv_hi_h = 16;            // levels of the triangular inverse with half-size >= this many tiles run as throughput launches (BOHIP_INV_HI_H)
+static int g_chol_df2_coal = 1;        // its K = 512 launches store through LDS in 16-byte pieces (BOHIP_CHOL_DF2_COAL=0: from the MFMA layout)
 static int g_chol_df2_hi = 1;          // its K = 512 launches with two workgroups per CU (BOHIP_CHOL_DF2_HI=0: one)
 static int g_chol_df2_win = 6;         // its window: block k's flagged update reaches column 4 (k / 4) + win (BOHIP_CHOL_DF2_WIN, 6..10; 6 is the least that keeps the chain's next tiles inside)
 static int g_chol_df2_min = 47;  // cholesky_dataflow2 (large-T form) from this many row tiles on (BOHIP_CHOL_DF2_MIN): N=6000 5.13 vs 5.3 ms, N=8000 7.8
@@ -283,6 +285,8 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_MIN")) g_chol_df2_min = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_HI")) g_chol_df2_hi = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_DF2_COAL")) g_chol_df2_coal = atoi(e);
+    if (const char* e = getenv("BOHIP_INV_HI_H")) g_inv_hi_h = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_WIN")) g_chol_df2_win = std::min(10, std::max(6, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_DF_TMAX")) g_chol_df_tmax = atoi(e);
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
@@ -340,14 +344,17 @@ static int inverse_level(bohip_gp* g, hipStream_t st, int t0, int nt, int h) {
     a.zA = a.zB = a.zC = zs;
     a.mt = h; a.nt64 = 2 * h; a.kc = h * (TILE / KC); a.alpha = 1.0; a.beta = 0.0; a.klo_from_m = 1;
     a.row_t0 = 0; a.row_ts = 2 * h; a.col_t0 = h; a.col_ts = 2 * h; a.total_t = nt;
-    CHK(launch_gemm_nt(g, a, pairs, st));
+    const bool big = h >= g_inv_hi_h;   // large levels are throughput launches: two workgroups per CU, stores through LDS
+    a.coalesced = big ? 1 : 0;
+    CHK(launch_gemm_nt(g, a, pairs, st, big));
     GemmNTParams b{};
     b.A = g->dW + base + off22; b.lda = ld; b.B = g->dS + base + off12; b.ldb = ld; b.C = g->dW + base + off21; b.ldc = ld;
     b.CT = g->dWT + base + off12; b.ldct = ld;
     b.zA = b.zB = b.zC = b.zCT = zs;
     b.mt = h; b.nt64 = 2 * h; b.kc = h * (TILE / KC); b.alpha = -1.0; b.beta = 0.0; b.khi_from_m = 1;
     b.row_t0 = h; b.row_ts = 2 * h; b.col_t0 = 0; b.col_ts = 2 * h; b.total_t = nt;
-    CHK(launch_gemm_nt(g, b, pairs, st));
+    b.coalesced = big ? 1 : 0;
+    CHK(launch_gemm_nt(g, b, pairs, st, big));
     return 0;
 }
 // inverse_join: the leading P tiles are inverted, so are the nb tiles behind them: fill W[P:P+nb, 0:P] (and its transpose).
@@ -537,6 +544,7 @@ static int cholesky_dataflow2(bohip_gp* g, int T) {
                     q.C = g->dL + (int64_t)c0 * TILE * (ld + 1); q.ldc = ld;
                     q.mt = T - c0; q.nt64 = 2 * (c1 - c0 + 1); q.kc = 4 * (TILE / KC); q.alpha = -1.0; q.beta = 1.0;
                     q.diag_skip = 1; q.row0 = (int64_t)c0 * TILE; q.col0 = (int64_t)c0 * TILE;
+                    q.coalesced = g_chol_df2_coal;
                     CHK(launch_gemm_nt(g, q, 1, bulk_stream, g_chol_df2_hi != 0));
                 }
                 if (part == 0) HIPCHK(hipEventRecord(g->ev_tier[2 * m + 1], bulk_stream));

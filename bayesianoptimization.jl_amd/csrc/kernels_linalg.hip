@@ -499,6 +499,7 @@ struct GemmNTParams {
     int wait2_rows;               //      wait2_rows = 1: wait on wait_flag[(tj / 2 - wait2_tj2_max) * wait_stride_ti], 0: no wait
     unsigned* signal_rows;        // per row tile: waves of the column tiles tj < signal_rows_ntj count into signal_rows[ti * signal_rows_stride]
     int signal_rows_ntj, signal_rows_stride;
+    int coalesced;                // store C through LDS as 16-byte pieces by all eight waves (plain stores) instead of from the MFMA layout
     unsigned* signal;
     unsigned* signal_row0;        // the workgroups of the first row tile (ti == 0, scheduled first) also count here
     unsigned* signal_col0;        // the workgroups of the first 128 columns (tj < 2) also count here
@@ -564,7 +565,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
                                p.ldb, kb, ke, smem, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
     double* C = p.C ? p.C + z * p.zC + (int64_t)ti * TILE * p.ldc + (int64_t)tj * CTILE : nullptr;
-    if (p.signal && C) {
+    if ((p.signal || p.coalesced) && C && (!p.CT || (p.coalesced && !p.signal))) {
         // A running kernel reads this tile: the stores are agent-scope (write-through).  Issued straight from the MFMA
         // accumulator layout they are 8-byte pieces in 32-byte runs -- 15-25 us per tile, longer than the contraction.  So
         // the tile takes a turn through LDS and leaves as 16-byte pieces, 1 KB contiguous per wave instruction, by all 8 waves.
@@ -590,8 +591,28 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
                 v.x += p.beta * old.x;
                 v.y += p.beta * old.y;
             }
-            if (k1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
-            else __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!p.signal) {   // (coalesced only: nobody reads the tile before this kernel ends)
+                if (k1) *reinterpret_cast<d2*>(dst) = v;
+                else *dst = v.x;
+            } else if (k1) {
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+            } else {
+                __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (!p.signal) {
+            if (p.CT) {   // the transpose from the same LDS tile: CT[c][r], 16-byte pieces along r (no diag_skip / beta users)
+                double* CTt = p.CT + z * p.zCT + (int64_t)tj * CTILE * p.ldct + (int64_t)ti * TILE;
+#pragma unroll
+                for (int u = 0; u < (TILE * CTILE / 2) / GEMM_THREADS_8; ++u) {
+                    const int piece = threadIdx.x + GEMM_THREADS_8 * u, c = piece >> 6, r = (piece & 63) * 2;
+                    d2 v;
+                    v.x = Tl[r * TS + c];
+                    v.y = Tl[(r + 1) * TS + c];
+                    *reinterpret_cast<d2*>(CTt + (int64_t)c * p.ldct + r) = v;
+                }
+            }
+            return;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed (a workgroup-scope fence emits no such wait)
         if (lane == 0) {
