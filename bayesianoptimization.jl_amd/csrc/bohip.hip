@@ -246,6 +246,8 @@ static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wis
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
 static int g_inv_hi_h = 16;            // levels of the triangular inverse with half-size >= this many tiles run as throughput launches (BOHIP_INV_HI_H)
+static int g_chol_df2_ll = 1;          // left-looking window updates (cholesky_dataflow3) instead of cholesky_dataflow2's K = 128 ones: N=8000 7.46 vs
+                                       // 7.63 ms, N=10000 11.7 vs 11.9, N=12000 16.5 vs 18.9 (BOHIP_CHOL_DF2_LL=0: the latter)
 static int g_chol_df2_coal = 1;        // its K = 512 launches store through LDS in 16-byte pieces (BOHIP_CHOL_DF2_COAL=0: from the MFMA layout)
 static int g_chol_df2_hi = 1;          // its K = 512 launches with two workgroups per CU (BOHIP_CHOL_DF2_HI=0: one)
 static int g_chol_df2_win = 6;         // its window: block k's flagged update reaches column 4 (k / 4) + win (BOHIP_CHOL_DF2_WIN, 6..10; 6 is the least that keeps the chain's next tiles inside)
@@ -254,7 +256,7 @@ static int g_chol_df2_min = 47;  // cholesky_dataflow2 (large-T form) from this 
 static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <= T <= g_chol_df_tmax row tiles: N=3000 1.66 vs 2.71 ms, N=1000 0.57
                             // vs 0.82 ms.  Far beyond that its one-tier K=128 bulk updates lose to the two-tier launch chain, below 3 there is
                             // nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every 2 <= T <= CHOL_DF_TCAP.
-static int g_chol_df_tmax = 88;   // N <= ~11200 (N=12000: the launch chain is ahead again, 18.5 vs 18.9 ms)
+static int g_chol_df_tmax = 96;   // = CHOL_DF_TCAP, N <= ~12200 (N=12000: 16.5 vs 18.5 ms for the launch chain)
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int g_trigemm_pull = 0;  // BOHIP_TRIGEMM_PULL=1: persistent k_trigemm_sq_pull (512 workgroups pull jobs) instead of one workgroup per job -- measured slower (0.622 vs 0.596 ms at C2)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
@@ -282,10 +284,12 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_inv128, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_pair, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_hi, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_quad, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_MIN")) g_chol_df2_min = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_HI")) g_chol_df2_hi = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_COAL")) g_chol_df2_coal = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_DF2_LL")) g_chol_df2_ll = atoi(e);
     if (const char* e = getenv("BOHIP_INV_HI_H")) g_inv_hi_h = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_WIN")) g_chol_df2_win = std::min(10, std::max(6, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_DF_TMAX")) g_chol_df_tmax = atoi(e);
@@ -561,6 +565,117 @@ static int cholesky_dataflow2(bohip_gp* g, int T) {
     return 0;
 }
 
+// ---- the same with LEFT-LOOKING window updates (BOHIP_CHOL_DF2_LL=1).  In cholesky_dataflow2 a quarter of the flops run as
+// K = 128 read-modify-writes of the window columns (~15 TF/s).  Here a column receives its updates just in time and all at once:
+//   bulk      group m (blocks 4m..4m+3), K = 512, goes to the columns >= 4m+8 only: Qa(m) = columns 4m+8..4m+11 (counted into
+//             col[m]: the flagged launches that touch those columns wait for it in-kernel), Qb(m) = the rest
+//   block k   column c = k+1, rows >= k+3:  -= S(i, ks..k) S(c, ks..k)'  with ks = first block of the group BEFORE c's -- K up to 1024,
+//             one read-modify-write per tile; the two tiles (k+3, k+2), (k+3, k+3) the chain reads next the same way; Solve(k+1)
+//             -- all four in one grid (k_gemm_nt_quad) on the one flagged stream.
+static int cholesky_dataflow3(bohip_gp* g, int T) {
+    const int64_t ld = g->ld;
+    hipStream_t ss = g->col_stream, bulk_stream = g->side_stream;
+    CholFlags fl = chol_flags_layout(g, T);
+    fl.mode2 = 100;
+    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
+    HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
+    hipLaunchKernelGGL(k_chol_chain, dim3(9), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamWaitEvent(ss, g->ev_panels, 0));
+    HIPCHK(hipStreamWaitEvent(bulk_stream, g->ev_panels, 0));
+    while ((int)g->ev_tier.size() < 2 * (T / 4 + 1)) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        g->ev_tier.push_back(ev);
+    }
+    unsigned* qa_cnt = fl.col;   // [T] words, one per group used
+    auto qa_dims = [&](int m, int& mt, int& nt64) {   // Qa(m): columns 4m+8 .. 4m+11, rows >= 4m+8
+        const int c0 = 4 * m + 8, c1 = std::min(T - 1, 4 * m + 11);
+        mt = T - c0; nt64 = 2 * (c1 - c0 + 1);
+    };
+    auto bulk_wait = [&](GemmNTParams& f, int c) {    // column c carries the groups <= c/4 - 2 once Qa(c/4 - 2) has stored
+        const int m = c / 4 - 2;
+        if (m < 0) return;
+        int mt, nt64; qa_dims(m, mt, nt64);
+        f.wait_flag3 = qa_cnt + m; f.wait_val3 = 8u * (unsigned)(mt * nt64);
+    };
+    auto solve_params = [&](int k) {
+        GemmNTParams sv{};   // S(i, k) = A(i, k) W_kk' for i >= k+3
+        sv.A = g->dL + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; sv.lda = ld;
+        sv.B = g->dW + (int64_t)k * TILE * (ld + 1); sv.ldb = ld;
+        sv.C = g->dS + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE; sv.ldc = ld;
+        sv.mt = T - (k + 3); sv.nt64 = 2; sv.kc = TILE / KC; sv.alpha = 1.0; sv.beta = 0.0;
+        if (k == 0) {
+            sv.wait_flag = fl.solved + k; sv.wait_val = 1u; sv.wait_stride_ti = 0;
+        } else {
+            sv.wait_flag = fl.xp + ((size_t)(k - 1) * T + (k + 3)) * CH_PANELS; sv.wait_val = 16u; sv.wait_stride_ti = CH_PANELS;
+            sv.wait_flag2 = fl.solved + k; sv.wait_val2 = 1u; sv.wait_stride_tj2 = 0;
+        }
+        sv.abort_flag = fl.abort;
+        sv.signal = fl.farall + k;
+        sv.signal_rows = fl.colr + (size_t)k * T + (k + 3); sv.signal_rows_ntj = 2; sv.signal_rows_stride = 1;
+        return sv;
+    };
+    // tiles (i, c), i = r0 .. r0 + mt - 1, left-looking over the blocks ks .. k
+    auto ll_params = [&](int k, int c, int r0, int mt) {
+        const int ks = 4 * std::max(c / 4 - 1, 0), nb = k - ks + 1;
+        GemmNTParams f{};
+        f.A = g->dS + (int64_t)r0 * TILE * ld + (int64_t)ks * TILE; f.lda = ld;
+        f.B = g->dS + (int64_t)c * TILE * ld + (int64_t)ks * TILE; f.ldb = ld;
+        f.C = g->dL + (int64_t)r0 * TILE * ld + (int64_t)c * TILE; f.ldc = ld;
+        f.mt = mt; f.nt64 = 2; f.kc = nb * (TILE / KC); f.alpha = -1.0; f.beta = 1.0;
+        f.diag_skip = 1; f.row0 = (int64_t)r0 * TILE; f.col0 = (int64_t)c * TILE;
+        f.wait_flag = fl.colr + (size_t)k * T + r0; f.wait_val = 16u; f.wait_stride_ti = 1;   // S(i, k) from Solve(k)
+        if (c <= k + 2) {   // operand row c is one of the chain's two: its last-panel flag
+            f.wait_flag2 = fl.xp + ((size_t)k * T + c) * CH_PANELS + (CH_PANELS - 1); f.wait_val2 = 1u; f.wait_stride_tj2 = 0;
+        }
+        bulk_wait(f, c);
+        f.signal = fl.colall + k;          // (selects the agent-scope stores)
+        f.signal_row0 = fl.rest + k;       // only the launches whose FIRST row is row k+3 count there (all three per block do)
+        f.abort_flag = fl.abort;
+        return f;
+    };
+    if (T > 3) CHK(launch_gemm_nt(g, solve_params(0), 1, ss, true));
+    for (int k = 0; k + 3 < T; ++k) {
+        const int m = k / 4;
+        GemmNTParams r2 = ll_params(k, k + 2, k + 3, 1), r3 = ll_params(k, k + 3, k + 3, 1);
+        GemmNTParams col = ll_params(k, k + 1, k + 3, T - (k + 3));
+        col.signal_rows = fl.xp + ((size_t)k * T + (k + 3)) * CH_PANELS; col.signal_rows_ntj = 2; col.signal_rows_stride = CH_PANELS;
+        GemmNTParams sv{};
+        int n3 = 0;
+        if (k + 4 < T) { sv = solve_params(k + 1); n3 = sv.mt * sv.nt64; }
+        const int n0 = r2.mt * r2.nt64, n1 = r3.mt * r3.nt64, n2 = col.mt * col.nt64;
+        hipLaunchKernelGGL(k_gemm_nt_quad, dim3(n0 + n1 + n2 + n3), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), ss, r2, r3, col, sv, n0, n1, n2);
+        HIPCHK(hipGetLastError());
+        if (k % 4 == 2 && 4 * m + 8 <= T - 1) {
+            // this grid held Solve(4m+3): group m is solved for every row, its K = 512 update of the columns >= 4m+8 can go
+            HIPCHK(hipEventRecord(g->ev_tier[2 * m], ss));
+            HIPCHK(hipStreamWaitEvent(bulk_stream, g->ev_tier[2 * m], 0));
+            for (int part = 0; part < 2; ++part) {
+                const int c0 = part == 0 ? 4 * m + 8 : 4 * m + 12, c1 = part == 0 ? std::min(T - 1, 4 * m + 11) : T - 1;
+                if (c0 > c1) continue;
+                GemmNTParams q{};
+                q.A = g->dS + (int64_t)c0 * TILE * ld + (int64_t)(4 * m) * TILE; q.lda = ld;
+                q.B = q.A; q.ldb = ld;
+                q.C = g->dL + (int64_t)c0 * TILE * (ld + 1); q.ldc = ld;
+                q.mt = T - c0; q.nt64 = 2 * (c1 - c0 + 1); q.kc = 4 * (TILE / KC); q.alpha = -1.0; q.beta = 1.0;
+                q.diag_skip = 1; q.row0 = (int64_t)c0 * TILE; q.col0 = (int64_t)c0 * TILE;
+                if (part == 0) q.signal = qa_cnt + m;   // agent-scope stores + the counter the flagged launches wait for
+                else q.coalesced = g_chol_df2_coal;
+                CHK(launch_gemm_nt(g, q, 1, bulk_stream, g_chol_df2_hi != 0));
+            }
+        }
+    }
+    HIPCHK(hipEventRecord(g->ev_inv, ss));
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
+    HIPCHK(hipEventRecord(g->ev_blk, bulk_stream));
+    HIPCHK(hipStreamWaitEvent(g->stream, g->ev_blk, 0));
+    hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
+    HIPCHK(hipGetLastError());
+    g->w_seeded = true;
+    return 0;
+}
+
 static int refit(bohip_gp* g) {
     CHK(one_time_kernel_setup());
     const int64_t N = g->n;
@@ -587,7 +702,8 @@ static int refit(bohip_gp* g) {
     t_end(g);
     t_begin(g, "cholesky");
     if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP)) {
-        if (T >= g_chol_df2_min) CHK(cholesky_dataflow2(g, T));
+        if (T >= g_chol_df2_min && g_chol_df2_ll) CHK(cholesky_dataflow3(g, T));
+        else if (T >= g_chol_df2_min) CHK(cholesky_dataflow2(g, T));
         else CHK(cholesky_dataflow(g, T));
         t_end(g);
         t_begin(g, "tri_inverse");

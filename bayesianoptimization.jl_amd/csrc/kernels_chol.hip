@@ -449,6 +449,7 @@ __host__ __device__ __forceinline__ int near_last_col(int T, int k, int win) { r
 // waves of the first row tile (row k+3) of block k's flagged update: every workgroup of that row adds 8, with or without a tile
 // (host: nt64 = 2 (T - k - 2) columns k+2 ..; mode2: columns k+1 .. near_last_col)
 __device__ __forceinline__ unsigned rest_want(const CholFlags& fl, int k) {
+    if (fl.mode2 >= 100) return 48u;   // left-looking form: three launches of two workgroups each hold row k+3's tiles
     return fl.mode2 ? 8u * 2u * (unsigned)(near_last_col(fl.T, k, fl.mode2) - k) : 8u * 2u * (unsigned)(fl.T - k - 2);
 }
 

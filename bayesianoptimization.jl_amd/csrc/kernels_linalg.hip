@@ -500,6 +500,8 @@ struct GemmNTParams {
     unsigned* signal_rows;        // per row tile: waves of the column tiles tj < signal_rows_ntj count into signal_rows[ti * signal_rows_stride]
     int signal_rows_ntj, signal_rows_stride;
     int coalesced;                // store C through LDS as 16-byte pieces by all eight waves (plain stores) instead of from the MFMA layout
+    const unsigned* wait_flag3;   // optional third flag, the same for every workgroup (a whole earlier launch on another stream)
+    unsigned wait_val3;
     unsigned* signal;
     unsigned* signal_row0;        // the workgroups of the first row tile (ti == 0, scheduled first) also count here
     unsigned* signal_col0;        // the workgroups of the first 128 columns (tj < 2) also count here
@@ -527,10 +529,11 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
         if (p.signal_rows && tj < p.signal_rows_ntj && threadIdx.x == 0) atomicAdd(p.signal_rows + (int64_t)ti * p.signal_rows_stride, 8u);
         return;
     }
-    if (p.wait_flag) {
+    if (p.wait_flag || p.wait_flag3) {
         if (threadIdx.x == 0) {
             for (long it = 0;; ++it) {
-                bool ok = __hip_atomic_load(p.wait_flag + (int64_t)ti * p.wait_stride_ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+                bool ok = !p.wait_flag ||
+                          __hip_atomic_load(p.wait_flag + (int64_t)ti * p.wait_stride_ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
                 if (ok && p.wait_flag2) {
                     const int tj2 = tj >> 1;
                     if (p.wait2_tj2_max > 0 && tj2 >= p.wait2_tj2_max)
@@ -539,6 +542,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
                     else
                         ok = __hip_atomic_load(p.wait_flag2 + (int64_t)tj2 * p.wait_stride_tj2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val2;
                 }
+                if (ok && p.wait_flag3) ok = __hip_atomic_load(p.wait_flag3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val3;
                 if (ok) break;
                 if (p.abort_flag && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
@@ -662,6 +666,16 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_gemm_nt_pair(GemmNTParams
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if ((int)blockIdx.x < na) gemm_nt_body(a, (int)blockIdx.x, 0, smem);
     else gemm_nt_body(b, (int)blockIdx.x - na, 0, smem);
+}
+// the same with four parameter sets: blocks [0, n0) run p0, [n0, n0+n1) p1, [.., +n2) p2, the rest p3
+__global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_gemm_nt_quad(GemmNTParams p0, GemmNTParams p1, GemmNTParams p2, GemmNTParams p3,
+                                                                 int n0, int n1, int n2) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x;
+    if (b < n0) gemm_nt_body(p0, b, 0, smem);
+    else if (b < n0 + n1) gemm_nt_body(p1, b - n0, 0, smem);
+    else if (b < n0 + n1 + n2) gemm_nt_body(p2, b - n0 - n1, 0, smem);
+    else gemm_nt_body(p3, b - n0 - n1 - n2, 0, smem);
 }
 
 // dst[i][j] = src[i][j] on every 128-tile strictly below the diagonal tiles (the factorisation parks the solved
