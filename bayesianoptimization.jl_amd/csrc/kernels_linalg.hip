@@ -510,6 +510,7 @@ struct GemmNTParams {
     unsigned* abort_flag;
 };
 
+template <bool SWAVE = false>   // SWAVE: see gemm_tile_loop_glds3_ks (the throughput kernels below use it)
 __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bid, const int z, double* smem) {
     // klo_from_n: the contraction of column tile tj starts at 128 (tj/2) -> low tj = long jobs: issue them first
     int ti = p.klo_from_n ? bid % p.mt : bid / p.nt64;
@@ -565,9 +566,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    gemm_tile_loop_glds3_ks<4>(p.A + z * p.zA + (int64_t)ti * TILE * p.lda, p.lda, p.B + z * p.zB + (int64_t)tj * CTILE * p.ldb,
-                               p.ldb, kb, ke, smem, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    gemm_tile_loop_glds3_ks<4, 0, SWAVE>(p.A + z * p.zA + (int64_t)ti * TILE * p.lda, p.lda, p.B + z * p.zB + (int64_t)tj * CTILE * p.ldb,
+                                         p.ldb, kb, ke, smem, acc);
+    const int lane = threadIdx.x & 63, wave = SWAVE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6), wr = wave >> 1, wc = wave & 1;
     double* C = p.C ? p.C + z * p.zC + (int64_t)ti * TILE * p.ldc + (int64_t)tj * CTILE : nullptr;
     if ((p.signal || p.coalesced) && C && (!p.CT || (p.coalesced && !p.signal))) {
         // A running kernel reads this tile: the stores are agent-scope (write-through).  Issued straight from the MFMA
@@ -660,22 +661,22 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 2) void k_gemm_nt(GemmNTParams p) {
 // stays at 129 VGPRs / one workgroup per CU, which suits the small launches beside the first dataflow form's chain better.)
 __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_gemm_nt_hi(GemmNTParams p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    gemm_nt_body(p, (int)blockIdx.x, (int)blockIdx.y, smem);
+    gemm_nt_body<true>(p, (int)blockIdx.x, (int)blockIdx.y, smem);
 }
 __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_gemm_nt_pair(GemmNTParams a, GemmNTParams b, int na) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if ((int)blockIdx.x < na) gemm_nt_body(a, (int)blockIdx.x, 0, smem);
-    else gemm_nt_body(b, (int)blockIdx.x - na, 0, smem);
+    if ((int)blockIdx.x < na) gemm_nt_body<true>(a, (int)blockIdx.x, 0, smem);
+    else gemm_nt_body<true>(b, (int)blockIdx.x - na, 0, smem);
 }
 // the same with four parameter sets: blocks [0, n0) run p0, [n0, n0+n1) p1, [.., +n2) p2, the rest p3
 __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_gemm_nt_quad(GemmNTParams p0, GemmNTParams p1, GemmNTParams p2, GemmNTParams p3,
                                                                  int n0, int n1, int n2) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x;
-    if (b < n0) gemm_nt_body(p0, b, 0, smem);
-    else if (b < n0 + n1) gemm_nt_body(p1, b - n0, 0, smem);
-    else if (b < n0 + n1 + n2) gemm_nt_body(p2, b - n0 - n1, 0, smem);
-    else gemm_nt_body(p3, b - n0 - n1 - n2, 0, smem);
+    if (b < n0) gemm_nt_body<true>(p0, b, 0, smem);
+    else if (b < n0 + n1) gemm_nt_body<true>(p1, b - n0, 0, smem);
+    else if (b < n0 + n1 + n2) gemm_nt_body<true>(p2, b - n0 - n1, 0, smem);
+    else gemm_nt_body<true>(p3, b - n0 - n1 - n2, 0, smem);
 }
 
 // dst[i][j] = src[i][j] on every 128-tile strictly below the diagonal tiles (the factorisation parks the solved

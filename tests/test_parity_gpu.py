@@ -690,9 +690,11 @@ def test_device_ascent_against_scipy_lbfgsb_on_the_oracle(bohip, orc):
 
 
 def test_dataflow_cholesky_matches_the_launch_chained_one(bohip, orc):
-    """csrc/kernels_chol.hip (opt-in, BOHIP_CHOL_DATAFLOW=1): persistent chain workgroups + panel followers + flag-gated
-    updates.  Same factor as the default path to rounding, and against the oracle; run in a subprocess because the switch is
-    read once per process."""
+    """csrc/kernels_chol.hip: the three dataflow forms of the factorisation (persistent chain workgroups + flags) against the
+    launch-chained one -- form 1 (panel followers, T <= 46 by default), form 2 (flagged row solves + K = 128 window updates)
+    and form 2 with left-looking window updates (the default for 47..96 row tiles), each forced at sizes the test can afford.
+    Same factor to rounding, same alpha and posterior; BOHIP_CHOL_DF_STRICT turns a timed-out flag into an error instead of the
+    silent fall-back.  Subprocesses because the switches are read once per process."""
     import json
     import os
     import subprocess
@@ -716,15 +718,24 @@ for N, d in ((130, 2), (1000, 4), (3000, 8)):
                        alpha=m.alpha()[::113].tolist(), mu=mu.tolist(), var=var.tolist(), refits=m.info(2))
 print("RESULT" + json.dumps(out))
 ''' % ROOT
+    variants = {
+        "chained": dict(BOHIP_CHOL_DATAFLOW="0"),
+        "form1": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="999"),
+        "form2": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="4", BOHIP_CHOL_DF2_LL="0"),
+        "form2-left-looking": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="4", BOHIP_CHOL_DF2_LL="1"),
+    }
     res = {}
-    for flag in ("0", "1"):
-        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BOHIP_CHOL_DATAFLOW={"0": "0", "1": "2"}[flag]), capture_output=True,
+    for name, env in variants.items():
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BOHIP_CHOL_DF_STRICT="1", **env), capture_output=True,
                            text=True, timeout=600)
-        assert o.returncode == 0, o.stderr[-2000:]
-        res[flag] = json.loads([l for l in o.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
-    for N in res["0"]:
-        a, b = res["0"][N], res["1"][N]
-        assert a["Lsum"] == pytest.approx(b["Lsum"], rel=1e-12)
-        for k in ("Ldiag", "Llast", "alpha", "mu"):
-            np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-12)
-        np.testing.assert_allclose(b["var"], a["var"], rtol=1e-7, atol=1e-12)
+        assert o.returncode == 0, (name, o.stderr[-2000:])
+        res[name] = json.loads([l for l in o.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
+    for name in variants:
+        if name == "chained":
+            continue
+        for N in res["chained"]:
+            a, b = res["chained"][N], res[name][N]
+            assert a["Lsum"] == pytest.approx(b["Lsum"], rel=1e-12), (name, N)
+            for k in ("Ldiag", "Llast", "alpha", "mu"):
+                np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-12, err_msg=f"{name} N={N} {k}")
+            np.testing.assert_allclose(b["var"], a["var"], rtol=1e-7, atol=1e-12, err_msg=f"{name} N={N} var")
