@@ -165,8 +165,10 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
     emit(json.dumps(out))
 
 
-def timed(args, step, sync, barrier=None):
-    """W untimed steps were done by the caller; time exactly K steps between barrier + synchronise on both sides."""
+def timed(args, step, sync, barrier=None, barrier_after=True):
+    """W untimed steps were done by the caller; time exactly K steps between barrier + synchronise on both sides.
+    barrier_after=False: the steps themselves end in a collective, so after the last one + synchronise every rank has seen
+    every other rank finish; the closing barrier would only add its own cost to the bracket."""
     if barrier:
         barrier()
     sync()
@@ -175,7 +177,7 @@ def timed(args, step, sync, barrier=None):
     for _ in range(args.steps):
         last = step()
     sync()
-    if barrier:
+    if barrier and barrier_after:
         barrier()
     return time.perf_counter() - t0, last
 
@@ -356,7 +358,7 @@ def main():
     model.append_(X.T, y)  # every rank factors the same model redundantly (192 KB broadcast beats 36 MB of L)
     model.fit_()
     fit_ms = dict(model.timing())
-    in_library = backend == "nccl" and not share_gpu
+    in_library = not share_gpu and os.environ.get("BOHIP_BENCH_NO_INLIB") != "1"
     if in_library:
         # every rank must take the same path: agree on whether the in-library communicator came up everywhere, else fall back
         # to the torch.distributed exchange of dist.py (same records, same reduction, one all_gather + a host reduce)
@@ -368,7 +370,7 @@ def main():
         except Exception as e:                          # noqa: BLE001
             print(f"[rank {rank}] in-library RCCL unavailable ({e}); using the torch.distributed exchange", file=sys.stderr)
             ok = 0
-        t_ok = torch.tensor([ok], device=torch.device("cuda", local_rank))
+        t_ok = torch.tensor([ok], device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
         dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
         if int(t_ok.item()) == 0:
             if ok:
@@ -382,8 +384,14 @@ def main():
     d_best = torch.tensor([0, -1, lo], dtype=torch.int64, device=dev)
     h_best = torch.tensor([0, -1], dtype=torch.int64).pin_memory()
     h_best_np = h_best.numpy()
-    stream = torch.cuda.current_stream()
-    _lib.check(lib.bohip_gp_set_stream(model._h, C.c_void_p(stream.cuda_stream)))
+    if os.environ.get("BOHIP_BENCH_TORCH_STREAM") == "1":   # (test mode: run the library on torch's current stream)
+        stream = torch.cuda.current_stream()
+        _lib.check(lib.bohip_gp_set_stream(model._h, C.c_void_p(stream.cuda_stream)))
+    else:
+        # the handle keeps its own high-priority stream, as in the single-process run: on torch's current (= the legacy
+        # default) stream the same kernels measured 12 % slower (0.675 vs 0.600 ms for k_trigemm_sq).  The candidates were
+        # uploaded on torch's stream: make them visible first.
+        torch.cuda.synchronize()
     params = (C.c_double * 2)(tau, 0.0)
 
     def step():
@@ -394,18 +402,31 @@ def main():
             return (float(h_best_np[:1].view(np.float64)[0]), i) if i >= 0 else (-np.inf, -1)
         _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()),
                                           R_PER_GPU, None, C.c_void_p(d_best.data_ptr())))
+        _lib.check(lib.bohip_gp_synchronize(model._h))   # the record is written on the handle's stream, the collective runs on torch's
         val, idx = allgather_best(d_best, lo, world, force_collective=True)
-        _lib.check(lib.bohip_gp_synchronize(model._h))
         return val, idx
 
     info_ms = {}
+    dist.barrier()                  # (torch-level rendezvous; the device may idle for milliseconds here)
     for _ in range(args.warmup):
         step()
         info_ms = dict(model.timing())
     model.enable_timing(3)
-    step()
+    # The bracket around the K timed steps.  Every step ends in a collective (the all-gather of the records), so an untimed
+    # step IS a barrier -- no rank leaves it before all have entered -- and it keeps the GPU busy; torch's dist.barrier()
+    # costs ~3 ms of idle device, after which the kernels run ~12 % slower for some 20 ms (measured: 0.748 ms per step over
+    # 30 steps right behind it against 0.663 over 200).  So: rendezvous first, then the W warm-up steps plus enough further
+    # untimed steps to have the device at its working clocks (the single-process run does 33 host-buffer steps at this
+    # point), then the bracket with a collective step as its barrier.
+    for _ in range(max(0, 40 - args.warmup)):
+        step()
     model.timing(4096)
-    elapsed, (val, idx) = timed(args, step, torch.cuda.synchronize, dist.barrier)
+
+    def step_barrier():
+        step()
+        model.timing(4096)          # (drop the barrier step's event records)
+
+    elapsed, (val, idx) = timed(args, step, torch.cuda.synchronize, step_barrier, barrier_after=False)
     stage_sum = {}
     for name, ms in model.timing(4096):
         stage_sum[name] = stage_sum.get(name, 0.0) + ms
