@@ -17,6 +17,7 @@
 #include "../../include/bohip.h"
 #include "kernels_linalg.hip"
 #include "kernels_chol.hip"
+#include "kernels_exec.hip"
 #include "kernels_score.hip"
 #include "kernels_ascent.hip"
 
@@ -78,6 +79,9 @@ struct bohip_gp {
     hipEvent_t ev_gate = nullptr;                 // a diagonal-block kernel is about to start: release one piece of the pending bulk update
     std::vector<hipEvent_t> ev_tier;              // its cross-stream hand-overs (two per group of four blocks)
     bool w_seeded = false;                        // the diagonal blocks of W were produced during the factorisation (k_chol_inverter)
+    ExTask* dex_tasks = nullptr;                  // task records of the executor form (kernels_exec.hip), built once per (buffers, T)
+    size_t ex_cap = 0;
+    int ex_T = 0, ex_qbeg[EX_NQ + 1] = {0, 0, 0, 0};
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
@@ -194,6 +198,7 @@ static int free_model(bohip_gp* g) {
     for (double** p : {&g->dX, &g->dy, &g->dL, &g->dW, &g->dWT, &g->dS, &g->dalpha, &g->dr, &g->dt, &g->dApp, &g->dchol_idl})
         if (*p) { hipFree(*p); *p = nullptr; }
     if (g->dchol_flags) { hipFree(g->dchol_flags); g->dchol_flags = nullptr; }
+    g->ex_T = 0;   // the task records hold pointers into the buffers just freed
     return 0;
 }
 static size_t chol_flag_words(int T);
@@ -257,6 +262,10 @@ static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <=
                             // vs 0.82 ms.  Far beyond that its one-tier K=128 bulk updates lose to the two-tier launch chain, below 3 there is
                             // nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every 2 <= T <= CHOL_DF_TCAP.
 static int g_chol_df_tmax = 96;   // = CHOL_DF_TCAP, N <= ~12200 (N=12000: 16.5 vs 18.5 ms for the launch chain)
+static unsigned long long g_chol_spin_ticks = CH_SPIN_TICKS_DEFAULT;   // BOHIP_CHOL_SPIN_US: bound of every in-kernel wait of the dataflow forms
+static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_exec) from g_chol_exec_min row tiles on (BOHIP_CHOL_EXEC=0: the stream-based second form)
+static int g_chol_exec_min = 47;  // BOHIP_CHOL_EXEC_MIN
+static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int g_trigemm_pull = 0;  // BOHIP_TRIGEMM_PULL=1: persistent k_trigemm_sq_pull (512 workgroups pull jobs) instead of one workgroup per job -- measured slower (0.622 vs 0.596 ms at C2)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
@@ -285,6 +294,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_pair, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_hi, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_quad, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_chol_exec, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_MIN")) g_chol_df2_min = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_HI")) g_chol_df2_hi = atoi(e);
@@ -293,6 +303,10 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_INV_HI_H")) g_inv_hi_h = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_WIN")) g_chol_df2_win = std::min(10, std::max(6, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_DF_TMAX")) g_chol_df_tmax = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_SPIN_US")) g_chol_spin_ticks = 100ull * (unsigned long long)std::max(1, atoi(e));
+    if (const char* e = getenv("BOHIP_CHOL_EXEC")) g_chol_exec = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_MIN")) g_chol_exec_min = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_PULL")) g_trigemm_pull = atoi(e);
     if (const char* e = getenv("BOHIP_FUSE_FINISH")) g_fuse_finish = atoi(e);
@@ -382,10 +396,12 @@ static int inverse_join(bohip_gp* g, hipStream_t st, int P, int nb) {
 // flag-gated trailing updates of every block are enqueued up front on the side stream.  No host events inside the factorisation.
 static size_t chol_abort_word(int T) { return (size_t)T * (CH_PANELS + 7) + (size_t)T * T * (CH_PANELS + 1); }   // see the layout in cholesky_dataflow
 static size_t chol_flag_words(int T) { return chol_abort_word(T) + 4; }
-static CholFlags chol_flags_layout(bohip_gp* g, int T) {
+static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T);
+static CholFlags chol_flags_layout(bohip_gp* g, int T) { return chol_flags_layout_at(g->dchol_flags, g->dchol_idl, T); }
+static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T) {
     CholFlags fl{};
     fl.T = T;
-    fl.panel = g->dchol_flags;
+    fl.panel = base;
     fl.solved = fl.panel + (size_t)T * CH_PANELS;
     fl.crit = fl.solved + T;
     fl.rest = fl.crit + T;
@@ -396,7 +412,8 @@ static CholFlags chol_flags_layout(bohip_gp* g, int T) {
     fl.colr = fl.colall + T;
     fl.xp = fl.colr + (size_t)T * T;
     fl.abort = fl.xp + (size_t)T * T * CH_PANELS;
-    fl.w16_g = g->dchol_idl;
+    fl.w16_g = idl;
+    fl.spin_ticks = g_chol_spin_ticks;
     fl.crit_want = 16u;   // the row-(k+2) update: 4 workgroups x 4 storing waves
     fl.panel_want = 3u;   // three publishing waves per panel
     return fl;
@@ -434,7 +451,7 @@ static int cholesky_dataflow(bohip_gp* g, int T) {
         f.signal = fl.colall + k;          // (selects the agent-scope stores; nobody waits for the whole launch)
         f.signal_row0 = fl.rest + k;       // row k+3: what the gated update of block k+1 starts from
         f.signal_col0 = fl.farall + k;     // column k+2: what block k+1's column updaters write next
-        f.first_row_col = 1; f.abort_flag = fl.abort;
+        f.first_row_col = 1; f.abort_flag = fl.abort; f.spin_ticks = g_chol_spin_ticks;
         CHK(launch_gemm_nt(g, f, 1, g->inv_stream));
     }
     if (T > 3) {
@@ -499,7 +516,7 @@ static int cholesky_dataflow2(bohip_gp* g, int T) {
             sv.wait_flag = fl.xp + ((size_t)(k - 1) * T + (k + 3)) * CH_PANELS; sv.wait_val = 16u; sv.wait_stride_ti = CH_PANELS;
             sv.wait_flag2 = fl.solved + k; sv.wait_val2 = 1u; sv.wait_stride_tj2 = 0;
         }
-        sv.abort_flag = fl.abort;
+        sv.abort_flag = fl.abort; sv.spin_ticks = g_chol_spin_ticks;
         sv.signal = fl.farall + k;         // (selects the agent-scope stores: the update beside it reads these tiles)
         sv.signal_rows = fl.colr + (size_t)k * T + (k + 3); sv.signal_rows_ntj = 2; sv.signal_rows_stride = 1;
         return sv;
@@ -518,7 +535,7 @@ static int cholesky_dataflow2(bohip_gp* g, int T) {
         f.signal = fl.colall + k;          // (selects the agent-scope stores; nobody waits for the whole launch)
         f.signal_row0 = fl.rest + k;       // row k+3: what the chain's followers and gated updates of block k+1 start from
         f.signal_rows = fl.xp + ((size_t)k * T + (k + 3)) * CH_PANELS; f.signal_rows_ntj = 2; f.signal_rows_stride = CH_PANELS;
-        f.first_row_col = 1; f.abort_flag = fl.abort;
+        f.first_row_col = 1; f.abort_flag = fl.abort; f.spin_ticks = g_chol_spin_ticks;
         return f;
     };
     if (T > 3) CHK(launch_gemm_nt(g, solve_params(0), 1, ss, true));
@@ -611,7 +628,7 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
             sv.wait_flag = fl.xp + ((size_t)(k - 1) * T + (k + 3)) * CH_PANELS; sv.wait_val = 16u; sv.wait_stride_ti = CH_PANELS;
             sv.wait_flag2 = fl.solved + k; sv.wait_val2 = 1u; sv.wait_stride_tj2 = 0;
         }
-        sv.abort_flag = fl.abort;
+        sv.abort_flag = fl.abort; sv.spin_ticks = g_chol_spin_ticks;
         sv.signal = fl.farall + k;
         sv.signal_rows = fl.colr + (size_t)k * T + (k + 3); sv.signal_rows_ntj = 2; sv.signal_rows_stride = 1;
         return sv;
@@ -632,7 +649,7 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
         bulk_wait(f, c);
         f.signal = fl.colall + k;          // (selects the agent-scope stores)
         f.signal_row0 = fl.rest + k;       // only the launches whose FIRST row is row k+3 count there (all three per block do)
-        f.abort_flag = fl.abort;
+        f.abort_flag = fl.abort; f.spin_ticks = g_chol_spin_ticks;
         return f;
     };
     if (T > 3) CHK(launch_gemm_nt(g, solve_params(0), 1, ss, true));
@@ -676,6 +693,146 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
     return 0;
 }
 
+// ---- A2, executor form (kernels_exec.hip): the chain + ONE persistent kernel that pulls tile tasks from three in-order queues.
+// The records are a pure function of (buffer addresses, ld, T): built on the host at the first factorisation with this T,
+// then resident.  Layout of the counters inside the flag area (all zeroed per factorisation):
+//   tile (i, c), i >= c+2:  ver = xp[((c-1) T + i) 8 + 0], pver = xp[.. + 1]   (the chain uses xp[(k T + i) 8 + p] for i = k+1, k+2 only)
+//   tile (c+1, c):          ver = farall[c], pver = fol[c];      tile (c, c):  ver = colall[c], pver = col[c]
+//   sver(i, k) = colr[k T + i];   queue cursors = the three words behind the abort word
+static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_base, int64_t ld, int T, std::vector<ExTask>& all, int* qbeg) {
+    const CholFlags fl = chol_flags_layout_at(flag_base, nullptr, T);
+    auto widx = [&](const unsigned* p) { return (uint32_t)(p - flag_base); };
+    auto nb = [](int c) { return std::max(c / 4 - 1, 0); };         // bulk groups that touch column c
+    auto ks = [](int c) { return 4 * std::max(c / 4 - 1, 0); };     // first block of column c's window (= 4 nb)
+    auto ver = [&](int i, int c) {
+        return i >= c + 2 ? widx(fl.xp + ((size_t)(c - 1) * T + i) * CH_PANELS) : (i == c + 1 ? widx(fl.farall + c) : widx(fl.colall + c));
+    };
+    auto pver = [&](int i, int c) {
+        return i >= c + 2 ? widx(fl.xp + ((size_t)(c - 1) * T + i) * CH_PANELS + 1) : (i == c + 1 ? widx(fl.fol + c) : widx(fl.col + c));
+    };
+    auto sver = [&](int i, int k) { return widx(fl.colr + (size_t)k * T + i); };
+    auto Sp = [&](int i, int kb) { return dS + (int64_t)i * TILE * ld + (int64_t)kb * TILE; };
+    auto Ap = [&](int i, int c) { return dL + (int64_t)i * TILE * ld + (int64_t)c * TILE; };
+    // P(i, c): the mirror tile of the scratch matrix (its upper triangle and diagonal tiles are free during the factorisation)
+    auto Pp = [&](int i, int c) { return dS + (int64_t)c * TILE * ld + (int64_t)i * TILE; };
+    // last block the Early sum of tile (i, c) contains; Late adds the two blocks behind it
+    auto e_of = [](int i, int c) { return std::min(i, c + 2) - 5; };
+    std::vector<ExTask> q[EX_NQ];
+    struct Dep { uint32_t idx, want; };
+    auto add = [&](int qi, const double* A, const double* B, double* C, const double* P, int kc_h0, int kc_h1, bool diag, int rmw,
+                   std::initializer_list<Dep> deps, uint32_t s0, uint32_t s1) {
+        for (int h = 0; h < 2; ++h) {
+            ExTask t{};
+            t.A = A; t.B = B + (int64_t)h * CTILE * ld; t.C = C + h * CTILE; t.P = P ? P + h * CTILE : nullptr;
+            int nd = 0;
+            for (int d = 0; d < EX_NDEP; ++d) { t.dep_idx[d] = EX_NONE; t.dep_want[d] = 0; }
+            for (const Dep& d : deps) {
+                if (d.idx == EX_NONE || d.want == 0) continue;
+                t.dep_idx[nd] = d.idx; t.dep_want[nd] = d.want; ++nd;
+            }
+            t.sig_idx[0] = s0; t.sig_idx[1] = s1;
+            t.kc = h == 0 ? kc_h0 : kc_h1; t.diag_h = diag ? h : -1; t.rmw = rmw;
+            q[qi].push_back(t);
+        }
+    };
+    const int CPB = TILE / KC;   // contraction chunks per 128-block
+    for (int k = 0; k + 3 < T; ++k) {
+        // Solve(i, k) = A(i, k) W_kk'  (W_kk lower-triangular: the left half of the columns needs the first 64 contraction indices only)
+        const double* Wkk = dW + (int64_t)k * TILE * (ld + 1);
+        for (int i = k + 3; i < T; ++i)
+            add(0, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
+                {{widx(fl.solved + k), 1u}, {k >= 1 ? ver(i, k) : EX_NONE, 16u * (unsigned)(nb(k) + 1)}}, sver(i, k), EX_NONE);
+        // Late(k): blocks max(k-1, 0) .. k into the tiles read next; the three tiles of row k+3 (what the chain waits for) first
+        const int kb0 = std::max(k - 1, 0), kcl = (k - kb0 + 1) * CPB;
+        auto late = [&](int i, int c) {
+            const bool has_p = e_of(i, c) >= ks(c);
+            // rows of S on the B side: row c of the blocks kb0 .. k
+            Dep b0{EX_NONE, 0}, b1{EX_NONE, 0};
+            if (c <= k + 2) {   // row c of block k is one of the chain's two: its last-panel flag
+                b0 = {widx(fl.xp + ((size_t)k * T + c) * CH_PANELS + (CH_PANELS - 1)), 1u};
+                if (c == k + 2 && k >= 1) b1 = {sver(c, k - 1), 16u};
+            } else {
+                b0 = {sver(c, k), 16u};
+            }
+            add(0, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
+                {{sver(i, k), 16u}, b0, b1, {has_p ? pver(i, c) : EX_NONE, 16u}, {ver(i, c), 16u * (unsigned)nb(c)}}, ver(i, c),
+                i == k + 3 ? widx(fl.rest + k) : EX_NONE);
+        };
+        late(k + 3, k + 1);
+        late(k + 3, k + 2);
+        late(k + 3, k + 3);
+        for (int i = k + 4; i < T; ++i) late(i, k + 1);
+    }
+    for (int kp = 0; kp + 5 < T; ++kp) {
+        // Early(kp): P(i, c) = sum_{b = ks(c)}^{kp} S(i, b) S(c, b)'  for the tiles Late(kp + 2) finishes
+        auto early = [&](int i, int c) {
+            if (i >= T || c >= T || ks(c) > kp) return;
+            add(1, Sp(i, ks(c)), Sp(c, ks(c)), const_cast<double*>(Pp(i, c)), nullptr, (kp - ks(c) + 1) * CPB, (kp - ks(c) + 1) * CPB, i == c, 0,
+                {{sver(i, kp), 16u}, {sver(c, kp), 16u}}, pver(i, c), EX_NONE);
+        };
+        early(kp + 5, kp + 3);
+        early(kp + 5, kp + 4);
+        early(kp + 5, kp + 5);
+        for (int i = kp + 6; i < T; ++i) early(i, kp + 3);
+    }
+    for (int m = 0; 4 * m + 8 <= T - 1; ++m)
+        for (int c = 4 * m + 8; c < T; ++c)
+            for (int i = c; i < T; ++i)
+                add(2, Sp(i, 4 * m), Sp(c, 4 * m), Ap(i, c), nullptr, 4 * CPB, 4 * CPB, i == c, 1,
+                    {{sver(i, 4 * m + 3), 16u}, {sver(c, 4 * m + 3), 16u}, {ver(i, c), 16u * (unsigned)m}}, ver(i, c), EX_NONE);
+    all.clear();
+    qbeg[0] = 0;
+    for (int qi = 0; qi < EX_NQ; ++qi) {
+        all.insert(all.end(), q[qi].begin(), q[qi].end());
+        qbeg[qi + 1] = (int)all.size();
+    }
+}
+static int build_exec_tasks(bohip_gp* g, int T) {
+    if (g->ex_T == T && g->dex_tasks) return 0;
+    std::vector<ExTask> all;
+    exec_task_list(g->dL, g->dS, g->dW, g->dchol_flags, g->ld, T, all, g->ex_qbeg);
+    if (all.size() > g->ex_cap) {
+        if (g->dex_tasks) hipFree(g->dex_tasks);
+        g->dex_tasks = nullptr; g->ex_cap = 0;
+        HIPCHK(hipMalloc(&g->dex_tasks, all.size() * sizeof(ExTask)));
+        g->ex_cap = all.size();
+    }
+    HIPCHK(hipMemcpyAsync(g->dex_tasks, all.data(), all.size() * sizeof(ExTask), hipMemcpyHostToDevice, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));   // `all` is pageable host memory that dies with this frame
+    g->ex_T = T;
+    return 0;
+}
+
+static int cholesky_exec(bohip_gp* g, int T) {
+    const int64_t ld = g->ld;
+    CHK(build_exec_tasks(g, T));
+    CholFlags fl = chol_flags_layout(g, T);
+    fl.mode2 = 100;   // the chain's view: rest[k] = 48 once the three tiles of row k+3 are in, inverter workgroup on
+    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
+    HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
+    hipLaunchKernelGGL(k_chol_chain, dim3(9), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
+    HIPCHK(hipGetLastError());
+    if (T > 3) {
+        ExQueues q{};
+        q.tasks = g->dex_tasks;
+        for (int i = 0; i <= EX_NQ; ++i) q.qbeg[i] = g->ex_qbeg[i];
+        q.flags = g->dchol_flags;
+        q.abort = g->dchol_flags + chol_abort_word(T);
+        q.heads = q.abort + 1;
+        q.ld = ld;
+        q.spin_ticks = g_chol_spin_ticks;
+        HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
+        hipLaunchKernelGGL(k_chol_exec, dim3(g_chol_exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(g->ev_inv, g->col_stream));
+        HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
+    }
+    hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
+    HIPCHK(hipGetLastError());
+    g->w_seeded = true;
+    return 0;
+}
+
 static int refit(bohip_gp* g) {
     CHK(one_time_kernel_setup());
     const int64_t N = g->n;
@@ -702,7 +859,8 @@ static int refit(bohip_gp* g) {
     t_end(g);
     t_begin(g, "cholesky");
     if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP)) {
-        if (T >= g_chol_df2_min && g_chol_df2_ll) CHK(cholesky_dataflow3(g, T));
+        if (g_chol_exec && T >= std::max(4, g_chol_exec_min)) CHK(cholesky_exec(g, T));
+        else if (T >= g_chol_df2_min && g_chol_df2_ll) CHK(cholesky_dataflow3(g, T));
         else if (T >= g_chol_df2_min) CHK(cholesky_dataflow2(g, T));
         else CHK(cholesky_dataflow(g, T));
         t_end(g);
@@ -1361,6 +1519,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     free_model(g);
     for (double** p : {&g->dKsT, &g->dq, &g->dmu_raw, &g->dXs, &g->dmu, &g->dvar, &g->dscore, &g->dmll, &g->dVT, &g->dUT})
         if (*p) hipFree(*p);
+    if (g->dex_tasks) hipFree(g->dex_tasks);
     if (g->dblock_best) hipFree(g->dblock_best);
     if (g->dbest) hipFree(g->dbest);
     if (g->dfz_cnt) hipFree(g->dfz_cnt);
@@ -1934,6 +2093,23 @@ int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {
 }  // extern "C"
 #include "multigpu.hip"
 extern "C" {
+// test hook (tests/test_exec_tasks.py): the executor's task records for T row tiles with the three matrices at the fake
+// addresses base_L/S/W (bytes) and flag word 0 at index 0 -- the CPU test replays them against a model of the chain.
+// out: n x 16 uint64 words (the 128-byte records); returns the number of records, qbeg[0..3] the queue boundaries,
+// layout[0..9] the word offsets of panel, solved, crit, rest, col, farall, fol, colall, colr, xp inside the flag area.
+int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base_S, uint64_t base_W, uint64_t* out, int64_t cap,
+                               int* qbeg, int64_t* layout) {
+    std::vector<bohip::ExTask> all;
+    int qb[bohip::EX_NQ + 1];
+    unsigned* fb = reinterpret_cast<unsigned*>(uintptr_t(1) << 40);
+    exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W), fb, ld, T, all, qb);
+    for (int i = 0; i <= bohip::EX_NQ; ++i) qbeg[i] = qb[i];
+    const bohip::CholFlags fl = chol_flags_layout_at(fb, nullptr, T);
+    const unsigned* ptrs[10] = {fl.panel, fl.solved, fl.crit, fl.rest, fl.col, fl.farall, fl.fol, fl.colall, fl.colr, fl.xp};
+    for (int i = 0; i < 10; ++i) layout[i] = ptrs[i] - fb;
+    if ((int64_t)all.size() <= cap && out) std::memcpy(out, all.data(), all.size() * sizeof(bohip::ExTask));
+    return (int64_t)all.size();
+}
 #if BOHIP_CHOL_TRACE
 int bohip_debug_chol_trace_read(unsigned long long* out, int64_t n_words) {   // tools only
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_chol_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -3;

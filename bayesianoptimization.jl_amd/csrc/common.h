@@ -30,6 +30,9 @@ struct KernelHyper {
     double il2[DMAX];  // exp(-2 loglen_k)
 };
 
+// bound of every in-kernel wait of the dataflow factorisation, in ticks of wall_clock64() (100 MHz): 200 ms (kernels_chol.hip)
+constexpr unsigned long long CH_SPIN_TICKS_DEFAULT = 20000000ull;
+
 struct Best {
     double val;
     long long idx;

@@ -67,15 +67,22 @@ struct CholFlags {
                           // columns k+1 .. 4 (k / 4) + 6, the columns beyond get four blocks at a time from plain K = 512 launches
     unsigned crit_want;   // value of crit[k] when the whole row-(k+2) update launch of block k is in memory
     unsigned panel_want;  // value of panel[..] when every publishing wave has seen its stores land
+    unsigned long long spin_ticks;   // bound of every in-kernel wait (wall_clock64 ticks), see flag_wait_ge
 };
 
-__device__ __forceinline__ void flag_wait_ge(const unsigned* flag, unsigned want, unsigned* abort) {
-    // one thread spins; callers put a barrier + __threadfence() behind it
-    for (long it = 0;; ++it) {
+// Bound of every in-kernel wait, in ticks of wall_clock64() (100 MHz constant clock): 200 ms by default.  The longest legitimate
+// wait of a whole factorisation is a few milliseconds, so a wait this long means a producer is not on the chip (another
+// process holds the CUs, two streams share a hardware queue, ...): the waiter sets the abort word, every other wait returns
+// at once, and the host falls back to the launch-chained form.  BOHIP_CHOL_SPIN_US overrides (tests force the time-out path).
+__device__ __forceinline__ void flag_wait_ge(const unsigned* flag, unsigned want, unsigned* abort, unsigned long long spin_ticks) {
+    // one thread spins; callers put a barrier behind it
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return;
         if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
         __builtin_amdgcn_s_sleep(4);
-        if (it > 40000000L) {   // ~ seconds: something upstream never arrived
+        if (wall_clock64() - t0 > spin_ticks) {   // something upstream never arrived
             __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
@@ -147,7 +154,7 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
     const double* Lkk = Lmat + (int64_t)k_blk * TILE * (ld + 1);
     const int ty = (t & 255) >> 4, tx = t & 15;
     for (int p = 0; p < CH_PANELS; ++p) {
-        if (t == 0) { flag_wait_ge(fl.panel + k_blk * CH_PANELS + p, fl.panel_want, fl.abort); if (WITH_D1) CH_MARK(1024 + k_blk * CH_PANELS + p); }
+        if (t == 0) { flag_wait_ge(fl.panel + k_blk * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks); if (WITH_D1) CH_MARK(1024 + k_blk * CH_PANELS + p); }
         __syncthreads();
         {   // stage the published panel: rows 16p..127 of L_kk, columns 16p..16p+15 (4 threads per 128-B row segment)
             const int i = t >> 2, mq = t & 3;
@@ -411,7 +418,7 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             __syncthreads();
         } else {
             if (r >= 2) {   // tile (r, r) carries every update from blocks <= r-2 once the gated update of block r-2 is in memory
-                if (tid == 0) { CH_MARK(3300 + 4 * (r - 2) + 3); flag_wait_ge(fl.crit + (r - 2), fl.crit_want, fl.abort); CH_MARK(3400 + r); }
+                if (tid == 0) { CH_MARK(3300 + 4 * (r - 2) + 3); flag_wait_ge(fl.crit + (r - 2), fl.crit_want, fl.abort, fl.spin_ticks); CH_MARK(3400 + r); }
                 __syncthreads();
             }
             d1_load<H>(Lmat, ld, r, d);
@@ -419,7 +426,7 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             const unsigned* xf = xp_at(fl, r - 1, r);
             const double* Sx = S + ((int64_t)r * TILE + (tid >> 2)) * ld + (int64_t)(r - 1) * TILE + 4 * (tid & 3);
             for (int p = 0; p < CH_PANELS; ++p) {
-                if (tid == 0) { flag_wait_ge(xf + p, 1u, fl.abort); CH_MARK(1024 + (r - 1) * CH_PANELS + p); }
+                if (tid == 0) { flag_wait_ge(xf + p, 1u, fl.abort, fl.spin_ticks); CH_MARK(1024 + (r - 1) * CH_PANELS + p); }
                 __syncthreads();
                 {   // panel p of L(r, r-1): 128 rows x 16 columns, 32 B per thread
                     d2 v0, v1;
@@ -465,9 +472,9 @@ __device__ __forceinline__ void crit_follower(double* __restrict__ Lmat, int64_t
         if (r >= T) continue;
         if (k >= 1) {   // tile (r, k) must carry block k-1's update: row k+1 gets it from the gated update, row k+2 from the column launch
             if (tid == 0) {
-                if (r == k + 1) flag_wait_ge(fl.crit + (k - 1), fl.crit_want, fl.abort);
-                else if (fl.mode2) flag_wait_ge(fl.rest + (k - 1), rest_want(fl, k - 1), fl.abort);   // tile (k+2, k): first row of block k-1's launch
-                else flag_wait_ge(fl.colr + (size_t)(k - 1) * T + r, 8u, fl.abort);   // tile (k+2, k): its column updaters of block k-1
+                if (r == k + 1) flag_wait_ge(fl.crit + (k - 1), fl.crit_want, fl.abort, fl.spin_ticks);
+                else if (fl.mode2) flag_wait_ge(fl.rest + (k - 1), rest_want(fl, k - 1), fl.abort, fl.spin_ticks);   // tile (k+2, k): first row of block k-1's launch
+                else flag_wait_ge(fl.colr + (size_t)(k - 1) * T + r, 8u, fl.abort, fl.spin_ticks);   // tile (k+2, k): its column updaters of block k-1
             }
             __syncthreads();
         }
@@ -503,7 +510,7 @@ __device__ __forceinline__ void gated_tile(const double* __restrict__ A, const d
     // the launch that writes it finishes early in the block, and the read then overlaps the wait for the panels (read in the
     // epilogue it added ~10 us of scattered agent-scope round trips to the hand-over).
     if (pre) {
-        if (tid == 0) flag_wait_ge(pre, pre_want, fl.abort);
+        if (tid == 0) flag_wait_ge(pre, pre_want, fl.abort, fl.spin_ticks);
         __syncthreads();
     }
     double acc[8][4];   // holds  -C  so that the contraction adds A B' and the store writes  -(acc)
@@ -519,7 +526,7 @@ __device__ __forceinline__ void gated_tile(const double* __restrict__ A, const d
         }
     }
     for (int c = 0; c < TILE / KC; ++c) {
-        if (tid == 0) { flag_wait_ge(fa + c, 1u, fl.abort); flag_wait_ge(fb + c, 1u, fl.abort); }
+        if (tid == 0) { flag_wait_ge(fa + c, 1u, fl.abort, fl.spin_ticks); flag_wait_ge(fb + c, 1u, fl.abort, fl.spin_ticks); }
         __syncthreads();   // (also: the previous chunk's fragments have been read)
         if (act) {
             // LDS[row][slot] holds the 16-B segment slot ^ (row & 7) of the row's 128-B chunk (the swizzle of gemm_core.h)
@@ -590,7 +597,7 @@ __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, i
     double* idl = sm + TILE * PF_LD + TILE;
     const int tid = threadIdx.x;
     for (int k = 0; k < T; ++k) {
-        if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + (CH_PANELS - 1), fl.panel_want, fl.abort);
+        if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + (CH_PANELS - 1), fl.panel_want, fl.abort, fl.spin_ticks);
         __syncthreads();
         const int64_t off = (int64_t)k * TILE;
         const double* Lblk = Lmat + off * (ld + 1);
@@ -647,7 +654,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_rows(const double* __res
     double ar[32], d[18];
     for (int k = 0; k + 3 <= i_tile; ++k) {
         if (k >= 1) {   // tile (i, k) carries block k-1's update once its two column updaters have stored
-            if (threadIdx.x == 0) flag_wait_ge(fl.colr + (size_t)(k - 1) * T + i_tile, 8u, fl.abort);
+            if (threadIdx.x == 0) flag_wait_ge(fl.colr + (size_t)(k - 1) * T + i_tile, 8u, fl.abort, fl.spin_ticks);
             __syncthreads();
         }
         load_row_piece(Lmat, ld, i_tile, k, ar);

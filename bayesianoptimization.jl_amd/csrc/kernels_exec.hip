@@ -1,0 +1,217 @@
+// kernels_exec.hip -- the tile-task executor of the blocked Cholesky factorisation for LARGE T (row A2 of SURVEY.md section 8;
+// reference call sites: update!/fit! at src/models/gp.jl:11-18, i.e. the LAPACK potrf behind ElasticPDMats).
+//
+// Why.  The second dataflow form (cholesky_dataflow2/3 in bohip.hip) feeds the persistent chain (k_chol_chain) from ~4 launches
+// per 128-block on three streams: every flagged launch parks hundreds of workgroups that spin on flags inside the kernel (at
+// N = 10^4 about 300 of the chip's 512 workgroup slots, which is why the K = 512 bulk updates beside them ran at 37 TF/s), the
+// in-order streams put a 1 ms bulk launch in front of the 0.1 ms one the chain needs next, and the left-looking column update
+// (K up to 1024, one workgroup per tile) sat on the critical path of every block: 11.7 ms for 333 GF.
+//
+// Here everything outside the chain is a TASK = one 128 x 64 half tile  C = beta C + alpha A B' (- P)  on the contraction engine
+// of gemm_core.h, described by an immutable 128-byte record the host writes once per (handle, T).  ONE persistent kernel
+// (k_chol_exec, 512 workgroups = two per CU) executes them: a workgroup that is free looks at the heads of three in-order
+// queues, highest priority first, CLAIMS the first head whose dependencies are met (compare-and-swap on the queue cursor)
+// and runs it.  Nobody ever holds a task it cannot run, so no workgroup slot is spent spinning, no launch boundary and no host
+// event sits between dependent tasks, and progress does not depend on how many executor workgroups are resident.
+//
+//   queue 0  per block k:  Solve(i, k) = A(i, k) W_kk'  for the rows i >= k+3 (W_kk: the chain's inverter workgroup), then
+//            Late(k): the tiles the chain and Solve(k+1) read next -- (k+3, k+2), (k+3, k+3) and column k+1 (rows >= k+3) --
+//            receive the blocks k-1 and k (K = 256) and the pre-summed older blocks P of the current window
+//   queue 1  Early(k): P(i, c) = sum over the window's blocks up to k of S(i, b) S(c, b)' for the tiles Late(k+2) will finish
+//            (K = 128 .. 640; depends on S only, two blocks of slack) -- takes the long contraction off the critical path
+//   queue 2  bulk: group m (blocks 4m .. 4m+3, K = 512) applied to every tile of the columns >= 4m+8, column-major, so that
+//            the four columns the chain reaches next are done first
+//
+// Dependencies are counters in the flag area (one word per producer granule, each finished task adds 8 = its waves):
+//   ver(i, c)   read-modify-write rounds completed on tile (i, c): bulk group m needs 16 m, Late needs 16 (number of groups)
+//   pver(i, c)  P(i, c) is complete (16)
+//   sver(i, k)  S(i, k) is complete (16)          [the words colr[k T + i] of CholFlags]
+//   solved[k], xp[..][7]   raised by the chain (inverse of the diagonal block; rows k+1, k+2 of L(:, k))
+//   rest[k]     48 = the three first-row tiles of Late(k): what the chain's followers and gated updates of block k+1 wait for
+// Every datum a running kernel reads is written with agent-scope (sc1, write-through) 16-byte stores behind an explicit
+// s_waitcnt vmcnt(0); the read-modify-write operands (old tile value, P) are fetched with sc1 loads, which bypass the CU's
+// vector L1 -- the executor lives for the whole factorisation, so no kernel boundary ever invalidates that cache.  Operand
+// tiles that go through LDS-DMA (S, the finished A(i, k), W_kk) are written exactly once before anybody reads them.
+#include "gemm_core.h"
+
+namespace bohip {
+
+constexpr unsigned EX_NONE = 0xffffffffu;
+constexpr int EX_NDEP = 6;
+constexpr int EX_NQ = 3;
+
+struct ExTask {                 // 128 bytes, written by the host once per (handle, T), never modified on the device
+    const double* A;            // [128][16 kc]  K-major, row stride ld
+    const double* B;            // [64][16 kc]
+    double* C;                  // [128][64]
+    const double* P;            // optional: C -= P as well
+    uint32_t dep_idx[EX_NDEP];  // word index into the flag area, EX_NONE = unused
+    uint32_t dep_want[EX_NDEP];
+    uint32_t sig_idx[2];        // counters every wave adds 1 to once its stores have landed
+    int32_t kc;                 // 16-deep contraction chunks
+    int32_t diag_h;             // -1, or this task is half `diag_h` of a DIAGONAL tile: entries with 64 h + c > r stay untouched
+    int32_t rmw;                // 1: C = C - A B' - P;  0: C = A B'
+    int32_t pad[7];
+};
+static_assert(sizeof(ExTask) == 128, "task record layout");
+
+struct ExQueues {
+    const ExTask* tasks;
+    int qbeg[EX_NQ + 1];        // queue q = tasks[qbeg[q] .. qbeg[q+1])
+    unsigned* flags;            // the flag area of the factorisation (CholFlags arrays live in it)
+    unsigned* heads;            // [EX_NQ] queue cursors (zeroed with the flags)
+    unsigned* abort;
+    int64_t ld;
+    unsigned long long spin_ticks;   // a workgroup that finds no runnable task for this long gives up (see flag_wait_ge)
+};
+
+// Claim the next task.  Run by the 64 lanes of wave 0: lane 8 q + d looks at dependency d of the head of queue q, so the heads
+// of all three queues are examined in one round of parallel loads (a one-lane version walked ~20 dependent memory round trips
+// per look, and as every free workgroup looked at the SAME head and only one compare-and-swap could win, the claims were
+// serialised at ~0.2 per microsecond: first light of this kernel ran at 1.2 TF/s).  A queue whose head is runnable is claimed
+// with ONE fetch-and-add; under contention the claimer gets a task a little behind the head it looked at and then waits for
+// THAT task's counters (tasks are claimed in queue order, so everything a claimed task depends on is already claimed by a
+// running workgroup or belongs to the chain: the wait is bounded and cannot dead-lock).  Returns -1 when every queue is
+// exhausted, or on abort.
+__device__ __forceinline__ bool ex_dep_pending(const ExTask* t, int d, const unsigned* flags) {
+    const uint32_t idx = t->dep_idx[d];
+    return idx != EX_NONE && __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t->dep_want[d];
+}
+__device__ __forceinline__ int ex_pick(const ExQueues& q, int lane) {
+    const int qi = lane >> 3, d = lane & 7;
+    const unsigned long long t_idle = wall_clock64();
+    int backoff = 1;
+    for (;;) {
+        unsigned h = 0, n = 0;
+        if (qi < EX_NQ) {
+            n = (unsigned)(q.qbeg[qi + 1] - q.qbeg[qi]);
+            h = __hip_atomic_load(q.heads + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool live = qi < EX_NQ && h < n;
+        const bool pending = live && d < EX_NDEP && ex_dep_pending(q.tasks + q.qbeg[qi] + h, d, q.flags);
+        const unsigned long long lv = __ballot(live), pd = __ballot(pending);
+        if (lv == 0ull) return -1;
+        int pickq = -1;
+#pragma unroll
+        for (int c = EX_NQ - 1; c >= 0; --c)
+            if (((lv >> (8 * c)) & 1ull) && ((pd >> (8 * c)) & 0xffull) == 0ull) pickq = c;
+        if (pickq >= 0) {
+            unsigned c = 0;
+            if (lane == 0) c = atomicAdd(q.heads + pickq, 1u);
+            c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+            const unsigned nq = (unsigned)(q.qbeg[pickq + 1] - q.qbeg[pickq]);
+            if (c >= nq) continue;   // the queue ran dry between the look and the claim
+            const ExTask* t = q.tasks + q.qbeg[pickq] + c;
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {   // usually c is the head that was just seen runnable; otherwise a task a little behind it
+                const bool p2 = lane < EX_NDEP && ex_dep_pending(t, lane, q.flags);
+                if (__ballot(p2) == 0ull) break;
+                if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
+                if (wall_clock64() - t0 > q.spin_ticks) {
+                    if (lane == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return -1;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            return q.qbeg[pickq] + (int)c;
+        }
+        if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
+        if (wall_clock64() - t_idle > q.spin_ticks) {   // no runnable task for this long: something upstream never arrived
+            if (lane == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return -1;
+        }
+        for (int s_ = 0; s_ < backoff; ++s_) __builtin_amdgcn_s_sleep(16);
+        if (backoff < 8) backoff *= 2;
+    }
+}
+
+__device__ __forceinline__ void ex_run(const ExTask& t, int64_t ld, unsigned* flags, double* smem, int tid) {
+    double acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    gemm_tile_loop_glds3_ks<4, 0, true>(t.A, ld, t.B, ld, 0, t.kc, smem, acc, TILE, 1 << 30, tid);
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = (wave & 3) >> 1, wc = wave & 1;
+    // the tile takes a turn through LDS and leaves as 16-byte agent-scope pieces, 1 KB contiguous per wave instruction
+    constexpr int TS = CTILE + 2;
+    double* Tl = smem;   // [128][66]: the staging buffers are free (the loop ended on a barrier)
+    if (wave < 4) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) Tl[acc_row(lane, wr, mi) * TS + acc_col<4>(lane, wc, nj)] = acc[mi][nj];
+    }
+    __syncthreads();
+    constexpr int NP = (TILE * CTILE / 2) / GEMM_THREADS_8;   // 8 pieces per thread
+    const int rmw = t.rmw, dh = t.diag_h;
+    const double* P = t.P;
+    double* C = t.C;
+    d2 oldv[NP], pv[NP];
+    if (rmw) {
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int piece = tid + GEMM_THREADS_8 * u, r = piece >> 5, c = (piece & 31) * 2;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(oldv[u]) : "v"(C + (int64_t)r * ld + c) : "memory");
+        }
+        if (P) {
+#pragma unroll
+            for (int u = 0; u < NP; ++u) {
+                const int piece = tid + GEMM_THREADS_8 * u, r = piece >> 5, c = (piece & 31) * 2;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[u]) : "v"(P + (int64_t)r * ld + c) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]), "+v"(pv[7])
+                         :
+                         : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(oldv[0]), "+v"(oldv[1]), "+v"(oldv[2]), "+v"(oldv[3]), "+v"(oldv[4]), "+v"(oldv[5]), "+v"(oldv[6]), "+v"(oldv[7])
+                     :
+                     : "memory");
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int piece = tid + GEMM_THREADS_8 * u, r = piece >> 5, c = (piece & 31) * 2;
+        double* dst = C + (int64_t)r * ld + c;
+        const bool k0 = !(dh >= 0 && CTILE * dh + c > r), k1 = !(dh >= 0 && CTILE * dh + c + 1 > r);
+        if (!k0) continue;   // (k1 implies k0): the strict upper triangle of a diagonal tile stays zero
+        d2 v = *reinterpret_cast<const d2*>(Tl + r * TS + c);
+        if (rmw) {
+            v.x = oldv[u].x - v.x;
+            v.y = oldv[u].y - v.y;
+            if (P) {
+                v.x -= pv[u].x;
+                v.y -= pv[u].y;
+            }
+        }
+        if (k1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+        else __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed (a workgroup-scope fence emits no such wait)
+    if (lane == 0) {
+        if (t.sig_idx[0] != EX_NONE) atomicAdd(flags + t.sig_idx[0], 1u);
+        if (t.sig_idx[1] != EX_NONE) atomicAdd(flags + t.sig_idx[1], 1u);
+    }
+}
+
+__global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ int s_task;
+    for (;;) {
+        if (threadIdx.x < 64) {
+            const int tk = ex_pick(q, (int)threadIdx.x);
+            if (threadIdx.x == 0) s_task = tk;
+        }
+        __syncthreads();
+        const int ti = __builtin_amdgcn_readfirstlane(s_task);
+        __syncthreads();
+        if (ti < 0) break;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));   // opaque per task: nothing lane-dependent is hoisted out of this loop
+        ex_run(q.tasks[ti], q.ld, q.flags, smem, tid);
+        __syncthreads();   // the LDS tile is rewritten by the next task's DMA
+    }
+}
+
+}  // namespace bohip

@@ -508,6 +508,7 @@ struct GemmNTParams {
     int first_row_col;            // dispatch order: first row tile, then the first 128 columns of the other rows, then the rest
                                   // (the chain waits for exactly those tiles; the bulk of the launch follows)
     unsigned* abort_flag;
+    unsigned long long spin_ticks;   // bound of the in-kernel wait (wall_clock64 ticks)
 };
 
 template <bool SWAVE = false>   // SWAVE: see gemm_tile_loop_glds3_ks (the throughput kernels below use it)
@@ -532,7 +533,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
     }
     if (p.wait_flag || p.wait_flag3) {
         if (threadIdx.x == 0) {
-            for (long it = 0;; ++it) {
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
                 bool ok = !p.wait_flag ||
                           __hip_atomic_load(p.wait_flag + (int64_t)ti * p.wait_stride_ti, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
                 if (ok && p.wait_flag2) {
@@ -547,7 +549,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
                 if (ok) break;
                 if (p.abort_flag && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
-                if (it > 40000000L) { if (p.abort_flag) atomicExch(p.abort_flag, 1u); break; }
+                if (wall_clock64() - t0 > (p.spin_ticks ? p.spin_ticks : CH_SPIN_TICKS_DEFAULT)) { if (p.abort_flag) atomicExch(p.abort_flag, 1u); break; }   // see flag_wait_ge
             }
         }
         __syncthreads();   // what the flag guards was written with agent-scope stores (kernels_chol.hip): no cache maintenance here

@@ -1,0 +1,204 @@
+"""CPU replay of the executor form of the blocked Cholesky (csrc/kernels_exec.hip, `cholesky_exec` in csrc/bohip.hip).
+
+The task records are built on the HOST (a pure function of addresses, ld and T) and executed on the device by k_chol_exec.
+Here the real builder is called through its test hook with fake base addresses, and the records are replayed with NumPy
+against a model of the persistent chain kernel (k_chol_chain in its mode2 = 100 view):
+
+  * every queue is consumed strictly in order, a task only when all of its dependency counters have reached their value
+    -- exactly the device's claim rule -- under several adversarial interleavings (tasks as early as possible / chain as
+    early as possible / random);
+  * the replay must never dead-lock, every record must be consumed, and the factor must equal numpy's Cholesky.
+
+A dependency the builder forgot shows up as a wrong factor in the "tasks first" order; a circular or mis-indexed one as a
+dead-lock.  (No GPU needed: this is host logic.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+TILE, CT, KC, NONE = 128, 64, 16, 0xFFFFFFFF
+BASE_L, BASE_S, BASE_W = 1 << 44, 2 << 44, 3 << 44
+
+
+def get_tasks(T, ld):
+    from bohip import _lib
+
+    lib = C.CDLL(_lib.LIB_PATH)
+    f = lib.bohip_debug_exec_tasks
+    f.restype = C.c_int64
+    f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+    qbeg = (C.c_int * 4)()
+    layout = (C.c_int64 * 10)()
+    n = f(T, ld, BASE_L, BASE_S, BASE_W, None, 0, qbeg, layout)
+    buf = np.zeros((n, 16), dtype=np.uint64)
+    assert f(T, ld, BASE_L, BASE_S, BASE_W, buf.ctypes.data_as(C.c_void_p), n, qbeg, layout) == n
+    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp"]
+    return buf, list(qbeg), dict(zip(names, layout))
+
+
+def decode(rec):
+    w = rec.view(np.uint32)
+    t = dict(A=int(rec[0]), B=int(rec[1]), C=int(rec[2]), P=int(rec[3]))
+    t["dep"] = [(int(w[8 + d]), int(w[14 + d])) for d in range(6) if int(w[8 + d]) != NONE]
+    t["sig"] = [int(w[20 + s]) for s in range(2) if int(w[20 + s]) != NONE]
+    i32 = rec.view(np.int32)
+    t["kc"], t["diag_h"], t["rmw"] = int(i32[22]), int(i32[23]), int(i32[24])
+    return t
+
+
+def replay(T, order, seed=0):
+    ld = TILE * T + 16
+    N = TILE * T
+    rng = np.random.default_rng(seed)
+    recs, qbeg, lay = get_tasks(T, ld)
+    tasks = [decode(r) for r in recs]
+    # a well-conditioned SPD matrix (kernel matrix of random points + noise), lower triangle only -- as k_build_cov leaves it
+    X = rng.random((N, 3))
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    K = np.exp(-0.5 * d2 / 0.09) + 0.05 * np.eye(N)
+    mats = {BASE_L: np.zeros((ld, ld)), BASE_S: np.zeros((ld, ld)), BASE_W: np.zeros((ld, ld))}
+    mats[BASE_L][:N, :N] = np.tril(K)
+    # poison what must be written before it is read
+    mats[BASE_S][:] = np.nan
+    flags = np.zeros(lay["xp"] + 8 * T * T + 8, dtype=np.int64)
+
+    def view(addr, rows, cols):
+        base = addr & ~((1 << 44) - 1)
+        off = (addr - base) // 8
+        r, c = divmod(off, ld)
+        assert (addr - base) % 8 == 0 and base in mats and r + rows <= ld and c + cols <= ld, hex(addr)
+        return mats[base][r:r + rows, c:c + cols]
+
+    def tile(base, i, j):
+        return mats[base][i * TILE:(i + 1) * TILE, j * TILE:(j + 1) * TILE]
+
+    def run_task(t):
+        K_ = KC * t["kc"]
+        A = view(t["A"], TILE, K_)
+        B = view(t["B"], CT, K_)
+        Cv = view(t["C"], TILE, CT)
+        assert not np.isnan(A).any() and not np.isnan(B).any(), "operand read before it was written"
+        prod = A @ B.T
+        keep = np.ones((TILE, CT), dtype=bool)
+        if t["diag_h"] >= 0:   # half of a diagonal tile: the strict upper triangle is never written (nor meaningful when read)
+            keep = (CT * t["diag_h"] + np.arange(CT)[None, :]) <= np.arange(TILE)[:, None]
+        if t["rmw"]:
+            new = Cv - prod
+            if t["P"]:
+                Pv = view(t["P"], TILE, CT)
+                assert not np.isnan(Pv[keep]).any(), "P read before it was written"
+                new = new - Pv
+        else:
+            assert t["P"] == 0
+            new = prod
+        Cv[keep] = new[keep]
+        for s in t["sig"]:
+            flags[s] += 8   # eight waves add one each
+
+    def ready(t):
+        return all(flags[i] >= w for i, w in t["dep"])
+
+    heads = [qbeg[q] for q in range(3)]
+    chain_k = 0   # next block of the chain
+
+    def chain_can_run():
+        return chain_k < T and (chain_k == 0 or flags[lay["rest"] + chain_k - 1] >= 48 or chain_k + 2 >= T)
+
+    def chain_step():
+        nonlocal chain_k
+        k = chain_k
+        L = mats[BASE_L]
+        S = mats[BASE_S]
+        if k >= 1 and k + 2 < T:
+            assert flags[lay["rest"] + k - 1] >= 48
+        Lkk = np.linalg.cholesky(np.tril(tile(BASE_L, k, k)) + np.tril(tile(BASE_L, k, k), -1).T)
+        tile(BASE_L, k, k)[:, :] = Lkk
+        tile(BASE_W, k, k)[:, :] = np.linalg.inv(Lkk)
+        flags[lay["solved"] + k] = 1
+        for r in (k + 1, k + 2):
+            if r < T:
+                tile(BASE_S, r, k)[:, :] = np.linalg.solve(Lkk, tile(BASE_L, r, k).T).T
+                flags[lay["xp"] + (k * T + r) * 8 + 7] = 1
+        if k + 1 < T:
+            s1 = tile(BASE_S, k + 1, k)
+            tile(BASE_L, k + 1, k + 1)[:, :] -= np.tril(s1 @ s1.T)
+        if k + 2 < T:
+            s1, s2 = tile(BASE_S, k + 1, k), tile(BASE_S, k + 2, k)
+            tile(BASE_L, k + 2, k + 1)[:, :] -= s2 @ s1.T
+            tile(BASE_L, k + 2, k + 2)[:, :] -= np.tril(s2 @ s2.T)
+        chain_k += 1
+
+    steps = 0
+    while True:
+        runnable = [q for q in range(3) if heads[q] < qbeg[q + 1] and ready(tasks[heads[q]])]
+        can_chain = chain_can_run()
+        if not runnable and not can_chain:
+            break
+        if order == "tasks_first":
+            pick = runnable[0] if runnable else "chain"
+        elif order == "low_priority_first":
+            pick = runnable[-1] if runnable else "chain"
+        elif order == "chain_first":
+            pick = "chain" if can_chain else runnable[0]
+        else:
+            opts = runnable + (["chain"] if can_chain else [])
+            pick = opts[rng.integers(len(opts))]
+        if pick == "chain":
+            chain_step()
+        else:
+            run_task(tasks[heads[pick]])
+            heads[pick] += 1
+        steps += 1
+    assert chain_k == T, f"dead-lock: chain stopped at block {chain_k} of {T}, queue heads {heads} of {qbeg}"
+    assert heads == qbeg[1:], f"records left over: heads {heads}, queues {qbeg}"
+    # k_copy_offdiag_tiles: the solved panels go home
+    L = mats[BASE_L]
+    for i in range(T):
+        for j in range(i):
+            tile(BASE_L, i, j)[:, :] = tile(BASE_S, i, j)
+    ref = np.linalg.cholesky(K)
+    got = np.tril(L[:N, :N])
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 1e-12, err
+    return len(tasks)
+
+
+@pytest.mark.parametrize("order", ["tasks_first", "low_priority_first", "chain_first", "random"])
+@pytest.mark.parametrize("T", [4, 5, 9, 14])
+def test_executor_records_replay_to_the_cholesky_factor(T, order):
+    replay(T, order)
+
+
+def test_executor_records_random_orders_mid_size():
+    for seed in range(3):
+        replay(18, "random", seed=seed)
+
+
+def test_every_tile_gets_every_block_once():
+    """Pure bookkeeping at the largest supported size: per tile, the contraction ranges of bulk + Early + Late are disjoint,
+    contiguous from block 0 and end where the chain takes over; per-tile read-modify-write rounds are ordered by `ver`."""
+    T = 96
+    ld = TILE * T + 16
+    recs, qbeg, lay = get_tasks(T, ld)
+    cover = {}
+    for q in range(3):
+        for r in recs[qbeg[q]:qbeg[q + 1]]:
+            t = decode(r)
+            if t["C"] >> 44 == BASE_L >> 44 and t["rmw"]:        # a trailing-matrix tile: which blocks does this record subtract?
+                off = (t["C"] - BASE_L) // 8
+                i, c = (off // ld) // TILE, (off % ld) // TILE
+                kb = (((t["A"] - BASE_S) // 8) % ld) // TILE
+                half = ((off % ld) % TILE) // CT
+                blocks = list(range(kb, kb + t["kc"] * KC // TILE))
+                cover.setdefault((i, c, half), []).extend(blocks)
+            elif t["C"] >> 44 == BASE_S >> 44 and (((t["C"] - BASE_S) // 8) // ld) // TILE <= (((t["C"] - BASE_S) // 8) % ld) // TILE and t["rmw"] == 0 \
+                    and t["A"] >> 44 == BASE_S >> 44:            # an Early record: P(i, c) lives at the mirror tile (c, i)
+                off = (t["C"] - BASE_S) // 8
+                c, i = (off // ld) // TILE, (off % ld) // TILE
+                kb = (((t["A"] - BASE_S) // 8) % ld) // TILE
+                half = ((off % ld) % TILE) // CT
+                cover.setdefault((i, c, half), []).extend(range(kb, kb + t["kc"] * KC // TILE))
+    assert cover
+    for (i, c, half), blocks in cover.items():
+        want_last = c - 1 if i >= c + 2 else (c - 2 if i == c + 1 else c - 3)   # the chain applies the remaining blocks itself
+        assert sorted(blocks) == list(range(0, want_last + 1)), ((i, c, half), sorted(blocks), want_last)

@@ -690,9 +690,10 @@ def test_device_ascent_against_scipy_lbfgsb_on_the_oracle(bohip, orc):
 
 
 def test_dataflow_cholesky_matches_the_launch_chained_one(bohip, orc):
-    """csrc/kernels_chol.hip: the three dataflow forms of the factorisation (persistent chain workgroups + flags) against the
-    launch-chained one -- form 1 (panel followers, T <= 46 by default), form 2 (flagged row solves + K = 128 window updates)
-    and form 2 with left-looking window updates (the default for 47..96 row tiles), each forced at sizes the test can afford.
+    """csrc/kernels_chol.hip, csrc/kernels_exec.hip: the dataflow forms of the factorisation (persistent chain workgroups +
+    flags) against the launch-chained one -- form 1 (panel followers, T <= 46 by default), form 2 (flagged row solves + K = 128
+    window updates), form 2 with left-looking window updates, and the executor form (one persistent kernel pulling tile tasks;
+    the default for 47..96 row tiles), each forced at sizes the test can afford.
     Same factor to rounding, same alpha and posterior; BOHIP_CHOL_DF_STRICT turns a timed-out flag into an error instead of the
     silent fall-back.  Subprocesses because the switches are read once per process."""
     import json
@@ -720,9 +721,11 @@ print("RESULT" + json.dumps(out))
 ''' % ROOT
     variants = {
         "chained": dict(BOHIP_CHOL_DATAFLOW="0"),
-        "form1": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="999"),
-        "form2": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="4", BOHIP_CHOL_DF2_LL="0"),
-        "form2-left-looking": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="4", BOHIP_CHOL_DF2_LL="1"),
+        "form1": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="999", BOHIP_CHOL_EXEC="0"),
+        "form2": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="4", BOHIP_CHOL_DF2_LL="0", BOHIP_CHOL_EXEC="0"),
+        "form2-left-looking": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="4", BOHIP_CHOL_DF2_LL="1", BOHIP_CHOL_EXEC="0"),
+        # csrc/kernels_exec.hip: the chain + one persistent task-executor kernel (the default from 47 row tiles on)
+        "executor": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4"),
     }
     res = {}
     for name, env in variants.items():
