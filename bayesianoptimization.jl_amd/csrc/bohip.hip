@@ -81,7 +81,7 @@ struct bohip_gp {
     bool w_seeded = false;                        // the diagonal blocks of W were produced during the factorisation (k_chol_inverter)
     ExTask* dex_tasks = nullptr;                  // task records of the executor form (kernels_exec.hip), built once per (buffers, T)
     size_t ex_cap = 0;
-    int ex_T = 0, ex_qbeg[EX_NQ + 1] = {0, 0, 0, 0};
+    int ex_T = 0, ex_nsf = 0, ex_qbeg[EX_NQ + 1] = {0, 0, 0, 0};
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
@@ -264,7 +264,9 @@ static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <=
 static int g_chol_df_tmax = 96;   // = CHOL_DF_TCAP, N <= ~12200 (N=12000: 16.5 vs 18.5 ms for the launch chain)
 static unsigned long long g_chol_spin_ticks = CH_SPIN_TICKS_DEFAULT;   // BOHIP_CHOL_SPIN_US: bound of every in-kernel wait of the dataflow forms
 static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_exec) from g_chol_exec_min row tiles on (BOHIP_CHOL_EXEC=0: the stream-based second form)
-static int g_chol_exec_min = 47;  // BOHIP_CHOL_EXEC_MIN
+static int g_chol_exec_min = 32;  // BOHIP_CHOL_EXEC_MIN: N=4000 2.42 vs 2.49 ms for the first dataflow form, N=5000 3.23 vs 3.75; below (N=3000) the first form wins (1.67 vs 1.78)
+static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
+static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
 static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int g_trigemm_pull = 0;  // BOHIP_TRIGEMM_PULL=1: persistent k_trigemm_sq_pull (512 workgroups pull jobs) instead of one workgroup per job -- measured slower (0.622 vs 0.596 ms at C2)
@@ -306,6 +308,8 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_SPIN_US")) g_chol_spin_ticks = 100ull * (unsigned long long)std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_EXEC")) g_chol_exec = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_MIN")) g_chol_exec_min = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_PAIRS")) g_chol_exec_pairs = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(CH_NSF_MAX, std::max(1, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_PULL")) g_trigemm_pull = atoi(e);
@@ -699,7 +703,7 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
 //   tile (i, c), i >= c+2:  ver = xp[((c-1) T + i) 8 + 0], pver = xp[.. + 1]   (the chain uses xp[(k T + i) 8 + p] for i = k+1, k+2 only)
 //   tile (c+1, c):          ver = farall[c], pver = fol[c];      tile (c, c):  ver = colall[c], pver = col[c]
 //   sver(i, k) = colr[k T + i];   queue cursors = the three words behind the abort word
-static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_base, int64_t ld, int T, std::vector<ExTask>& all, int* qbeg) {
+static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_base, int64_t ld, int T, int CH_NSF, std::vector<ExTask>& all, int* qbeg) {
     const CholFlags fl = chol_flags_layout_at(flag_base, nullptr, T);
     auto widx = [&](const unsigned* p) { return (uint32_t)(p - flag_base); };
     auto nb = [](int c) { return std::max(c / 4 - 1, 0); };         // bulk groups that touch column c
@@ -720,7 +724,8 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
     std::vector<ExTask> q[EX_NQ];
     struct Dep { uint32_t idx, want; };
     auto add = [&](int qi, const double* A, const double* B, double* C, const double* P, int kc_h0, int kc_h1, bool diag, int rmw,
-                   std::initializer_list<Dep> deps, uint32_t s0, uint32_t s1) {
+                   std::initializer_list<Dep> deps, uint32_t s0, uint32_t s1, int kc_split = 0, Dep d2a = Dep{EX_NONE, 0},
+                   Dep d2b = Dep{EX_NONE, 0}) {
         for (int h = 0; h < 2; ++h) {
             ExTask t{};
             t.A = A; t.B = B + (int64_t)h * CTILE * ld; t.C = C + h * CTILE; t.P = P ? P + h * CTILE : nullptr;
@@ -731,7 +736,9 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
                 t.dep_idx[nd] = d.idx; t.dep_want[nd] = d.want; ++nd;
             }
             t.sig_idx[0] = s0; t.sig_idx[1] = s1;
-            t.kc = h == 0 ? kc_h0 : kc_h1; t.diag_h = diag ? h : -1; t.rmw = rmw;
+            t.kc = h == 0 ? kc_h0 : kc_h1; t.diag_h = diag ? h : -1; t.rmw = rmw; t.prio = qi == 0 ? 2 : (qi == 1 ? 1 : 0);
+            t.kc_split = kc_split;
+            t.dep2_idx[0] = d2a.idx; t.dep2_want[0] = d2a.want; t.dep2_idx[1] = d2b.idx; t.dep2_want[1] = d2b.want;
             q[qi].push_back(t);
         }
     };
@@ -739,29 +746,46 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
     for (int k = 0; k + 3 < T; ++k) {
         // Solve(i, k) = A(i, k) W_kk'  (W_kk lower-triangular: the left half of the columns needs the first 64 contraction indices only)
         const double* Wkk = dW + (int64_t)k * TILE * (ld + 1);
-        for (int i = k + 3; i < T; ++i)
-            add(0, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
-                {{widx(fl.solved + k), 1u}, {k >= 1 ? ver(i, k) : EX_NONE, 16u * (unsigned)(nb(k) + 1)}}, sver(i, k), EX_NONE);
+        auto solve_rows = [&]() {   // (the rows k+3 .. k+2+CH_NSF are solved panel by panel inside the chain kernel: solve_follower)
+            for (int i = k + 3 + CH_NSF; i < T; ++i)
+                add(0, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
+                    {{widx(fl.solved + k), 1u}, {k >= 1 ? ver(i, k) : EX_NONE, 16u * (unsigned)(nb(k) + 1)}}, sver(i, k), EX_NONE);
+        };
         // Late(k): blocks max(k-1, 0) .. k into the tiles read next; the three tiles of row k+3 (what the chain waits for) first
         const int kb0 = std::max(k - 1, 0), kcl = (k - kb0 + 1) * CPB;
         auto late = [&](int i, int c) {
             const bool has_p = e_of(i, c) >= ks(c);
+            auto chain_row = [&](int kk, int r) { return Dep{widx(fl.xp + ((size_t)kk * T + r) * CH_PANELS + (CH_PANELS - 1)), 1u}; };
+            const Dep p_dep{has_p ? pver(i, c) : EX_NONE, 16u}, v_dep{ver(i, c), 16u * (unsigned)nb(c)};
+            if (i < k + 3 + CH_NSF && k >= 1) {
+                // a tile whose row of S(:, k) comes from the chain kernel's solve followers -- the three tiles the chain waits for, and
+                // the tiles the later followers read next: the block k-1 half of the contraction needs nothing of block k, so the task
+                // is claimed and starts while block k is still being factored, and waits for S(i, k) (and the chain's row c) inside
+                const Dep b_prev = c == k + 1 ? chain_row(k - 1, c) : Dep{sver(c, k - 1), 16u};
+                add(0, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
+                    {{sver(i, k - 1), 16u}, b_prev, p_dep, v_dep}, ver(i, c), i == k + 3 ? widx(fl.rest + k) : EX_NONE, CPB,
+                    Dep{sver(i, k), 16u}, c <= k + 2 ? chain_row(k, c) : Dep{EX_NONE, 0});
+                return;
+            }
             // rows of S on the B side: row c of the blocks kb0 .. k
             Dep b0{EX_NONE, 0}, b1{EX_NONE, 0};
             if (c <= k + 2) {   // row c of block k is one of the chain's two: its last-panel flag
-                b0 = {widx(fl.xp + ((size_t)k * T + c) * CH_PANELS + (CH_PANELS - 1)), 1u};
+                b0 = chain_row(k, c);
                 if (c == k + 2 && k >= 1) b1 = {sver(c, k - 1), 16u};
             } else {
                 b0 = {sver(c, k), 16u};
             }
             add(0, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
-                {{sver(i, k), 16u}, b0, b1, {has_p ? pver(i, c) : EX_NONE, 16u}, {ver(i, c), 16u * (unsigned)nb(c)}}, ver(i, c),
-                i == k + 3 ? widx(fl.rest + k) : EX_NONE);
+                {{sver(i, k), 16u}, b0, b1, p_dep, v_dep}, ver(i, c), i == k + 3 ? widx(fl.rest + k) : EX_NONE);
         };
+        // the three tiles the chain waits for come FIRST: they are claimed while block k is still being factored (their first
+        // piece needs block k-1 only) and finish a few microseconds after the chain's solve_follower has delivered S(k+3, k)
         late(k + 3, k + 1);
         late(k + 3, k + 2);
         late(k + 3, k + 3);
-        for (int i = k + 4; i < T; ++i) late(i, k + 1);
+        for (int i = k + 4; i < std::min(T, k + 3 + CH_NSF); ++i) late(i, k + 1);
+        solve_rows();
+        for (int i = k + 3 + CH_NSF; i < T; ++i) late(i, k + 1);
     }
     for (int kp = 0; kp + 5 < T; ++kp) {
         // Early(kp): P(i, c) = sum_{b = ks(c)}^{kp} S(i, b) S(c, b)'  for the tiles Late(kp + 2) finishes
@@ -788,9 +812,9 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
     }
 }
 static int build_exec_tasks(bohip_gp* g, int T) {
-    if (g->ex_T == T && g->dex_tasks) return 0;
+    if (g->ex_T == T && g->dex_tasks && g->ex_nsf == g_chol_nsf) return 0;
     std::vector<ExTask> all;
-    exec_task_list(g->dL, g->dS, g->dW, g->dchol_flags, g->ld, T, all, g->ex_qbeg);
+    exec_task_list(g->dL, g->dS, g->dW, g->dchol_flags, g->ld, T, g_chol_nsf, all, g->ex_qbeg);
     if (all.size() > g->ex_cap) {
         if (g->dex_tasks) hipFree(g->dex_tasks);
         g->dex_tasks = nullptr; g->ex_cap = 0;
@@ -800,6 +824,7 @@ static int build_exec_tasks(bohip_gp* g, int T) {
     HIPCHK(hipMemcpyAsync(g->dex_tasks, all.data(), all.size() * sizeof(ExTask), hipMemcpyHostToDevice, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));   // `all` is pageable host memory that dies with this frame
     g->ex_T = T;
+    g->ex_nsf = g_chol_nsf;
     return 0;
 }
 
@@ -810,7 +835,8 @@ static int cholesky_exec(bohip_gp* g, int T) {
     fl.mode2 = 100;   // the chain's view: rest[k] = 48 once the three tiles of row k+3 are in, inverter workgroup on
     HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
     HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
-    hipLaunchKernelGGL(k_chol_chain, dim3(9), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
+    fl.nsf = g_chol_nsf;
+    hipLaunchKernelGGL(k_chol_chain, dim3(9 + g_chol_nsf), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
     HIPCHK(hipGetLastError());
     if (T > 3) {
         ExQueues q{};
@@ -821,6 +847,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
         q.heads = q.abort + 1;
         q.ld = ld;
         q.spin_ticks = g_chol_spin_ticks;
+        q.stride[0] = 1; q.stride[1] = g_chol_exec_pairs ? 2 : 1; q.stride[2] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
         HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
         hipLaunchKernelGGL(k_chol_exec, dim3(g_chol_exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
         HIPCHK(hipGetLastError());
@@ -2096,23 +2123,29 @@ extern "C" {
 // test hook (tests/test_exec_tasks.py): the executor's task records for T row tiles with the three matrices at the fake
 // addresses base_L/S/W (bytes) and flag word 0 at index 0 -- the CPU test replays them against a model of the chain.
 // out: n x 16 uint64 words (the 128-byte records); returns the number of records, qbeg[0..3] the queue boundaries,
-// layout[0..9] the word offsets of panel, solved, crit, rest, col, farall, fol, colall, colr, xp inside the flag area.
+// layout[0..9] the word offsets of panel, solved, crit, rest, col, farall, fol, colall, colr, xp inside the flag area;
+// layout[10] the number of solve-follower workgroups of the chain kernel (CH_NSF).
 int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base_S, uint64_t base_W, uint64_t* out, int64_t cap,
                                int* qbeg, int64_t* layout) {
     std::vector<bohip::ExTask> all;
     int qb[bohip::EX_NQ + 1];
     unsigned* fb = reinterpret_cast<unsigned*>(uintptr_t(1) << 40);
-    exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W), fb, ld, T, all, qb);
+    exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W), fb, ld, T, g_chol_nsf, all, qb);
     for (int i = 0; i <= bohip::EX_NQ; ++i) qbeg[i] = qb[i];
     const bohip::CholFlags fl = chol_flags_layout_at(fb, nullptr, T);
     const unsigned* ptrs[10] = {fl.panel, fl.solved, fl.crit, fl.rest, fl.col, fl.farall, fl.fol, fl.colall, fl.colr, fl.xp};
     for (int i = 0; i < 10; ++i) layout[i] = ptrs[i] - fb;
+    if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(bohip::CH_NSF_MAX, std::max(1, atoi(e)));
+    layout[10] = g_chol_nsf;
     if ((int64_t)all.size() <= cap && out) std::memcpy(out, all.data(), all.size() * sizeof(bohip::ExTask));
     return (int64_t)all.size();
 }
 #if BOHIP_CHOL_TRACE
 int bohip_debug_chol_trace_read(unsigned long long* out, int64_t n_words) {   // tools only
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_chol_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -3;
+}
+int bohip_debug_exec_trace_read(unsigned long long* out, int64_t n_words) {   // tools only
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_ex_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -3;
 }
 #endif
 #if BOHIP_TRACE

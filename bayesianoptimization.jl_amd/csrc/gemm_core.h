@@ -233,7 +233,9 @@ __device__ unsigned long long g_phase[8192 * 8 * 4];   // [block][wave]{issue+mf
 // SWAVE: keep the wave index in an SGPR (readfirstlane).  k_trigemm_sq: 128 VGPRs without a spill and scalar branches on the
 // wave's role, +2 %.  k_gemm_nt keeps the vector form: with it it needs 129 VGPRs = ONE workgroup per CU, and the launches
 // that run beside the factorisation's chain (and the inverse's small levels) are faster that way than with two.
-template <int NJ, int ABL = 0, bool SWAVE = false>  // ABL: ablation switches (tools only): 1 no DMA, 2 no LDS reads, 4 no barriers
+// FOLD = false: leave the two partial accumulator sets as they are (a caller that runs the loop in two pieces -- with a
+// wait for the second piece's operands in between, kernels_exec.hip -- folds once, after the last piece)
+template <int NJ, int ABL = 0, bool SWAVE = false, bool FOLD = true>  // ABL: ablation switches (tools only): 1 no DMA, 2 no LDS reads, 4 no barriers
 __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict__ A, int64_t lda,
                                                         const double* __restrict__ B, int64_t ldb, int kc_begin,
                                                         int kc_end, double* smem, double (&acc)[8][NJ],
@@ -333,6 +335,7 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
     if (xy == 0) run(std::integral_constant<int, 0>{});
     else if (xy == 1) run(std::integral_constant<int, 1>{});
     else run(std::integral_constant<int, 2>{});
+    if constexpr (!FOLD) return;
     // add the second half's partial accumulators into the first half's (through LDS: 32 doubles per lane)
     double* xch = smem;  // 256 lanes x 32 doubles = 64 KB <= staging area
     if (khalf == 1) {

@@ -44,8 +44,9 @@ constexpr int CH_THREADS = 512;
 constexpr int CH_PANELS = TILE / 16;          // 8 panels of 16 columns per 128-block
 constexpr int WK_LPS = 16;                    // worker LDS: published panel LP[128][16]
 constexpr int WK_XS = 17;                     //             solved rows   XB[128][17]
-constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + 2 * TILE * WK_XS + 256;   // LPt[16][130] | XB[128][17] | XS[128][17] | W16[16][16]
-constexpr int CH_LDS_BYTES = (TILE * PF_LD + 2 * TILE + 256) * 8;   // the potf2 image + dl + idl + W16 scratch; the worker arrays alias its start
+constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + 2 * TILE * WK_XS + 256 + 2;   // LPt[16][130] | XB[128][17] | XS[128][17] | W16[16][16] | next-panel-ready word
+constexpr int INV_LDS_DOUBLES = TILE * TILE + 16 * (TILE - 16) + 8 * TILE + 256;   // the inverter workgroup's image (inverter_role)
+constexpr int CH_LDS_BYTES = (INV_LDS_DOUBLES > TILE * PF_LD + 2 * TILE + 256 ? INV_LDS_DOUBLES : TILE * PF_LD + 2 * TILE + 256) * 8;   // the potf2 image + dl + idl + W16 scratch (the worker arrays alias its start), or the inverter's
 static_assert(WK_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "worker arrays must fit inside the diagonal-block image");
 
 struct CholFlags {
@@ -68,6 +69,7 @@ struct CholFlags {
     unsigned crit_want;   // value of crit[k] when the whole row-(k+2) update launch of block k is in memory
     unsigned panel_want;  // value of panel[..] when every publishing wave has seen its stores land
     unsigned long long spin_ticks;   // bound of every in-kernel wait (wall_clock64 ticks), see flag_wait_ge
+    int nsf;              // executor form: solve-follower workgroups of the chain kernel (rows k+3 .. k+2+nsf of block k)
 };
 
 // Bound of every in-kernel wait, in ticks of wall_clock64() (100 MHz constant clock): 200 ms by default.  The longest legitimate
@@ -92,8 +94,9 @@ __device__ __forceinline__ void flag_wait_ge(const unsigned* flag, unsigned want
 #define BOHIP_CHOL_TRACE 0
 #endif
 #if BOHIP_CHOL_TRACE
-__device__ unsigned long long g_chol_trace[4 * 1024];   // [0,1024): panel published; [1024,2048): owner saw panel; [2048,3072): owner finished panel; [3072..): block marks
-#define CH_MARK(slot) g_chol_trace[(slot) & 4095] = wall_clock64()
+__device__ unsigned long long g_chol_trace[8 * 1024];   // [4096, 4352): inverse of block k published; [4352, 4608): row k+2 of block k saw rest[k-1]; [4608, 4864): S(k+3, k) complete;
+// [4864, 5120): owner of row r starts waiting for crit[r-2]; [5120, 5376): sees it; [5376, 5632): owner saw the last panel of L(r, r-1); [5632, 5888): follower of row k+1 sees crit[k-1]   // [0,1024): panel published; [1024,2048): owner saw panel; [2048,3072): owner finished panel; [3072..): block marks
+#define CH_MARK(slot) g_chol_trace[(slot) & 8191] = wall_clock64()
 #else
 #define CH_MARK(slot) do {} while (0)
 #endif
@@ -153,19 +156,42 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
     double* W16s = XS + TILE * WK_XS;        // [16][16]
     const double* Lkk = Lmat + (int64_t)k_blk * TILE * (ld + 1);
     const int ty = (t & 255) >> 4, tx = t & 15;
+    // A follower that is BEHIND the pivot (its tile arrived late) finds the next panel already published: its staging loads are then
+    // issued before this panel's arithmetic and land beside it -- one memory round trip per panel less while catching up (the
+    // pivot publishes a panel every ~7 us, a follower needed ~6 us per panel, so a late start was never made up)
+    int* nready = reinterpret_cast<int*>(W16s + 256);
+    double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0, pv3 = 0.0, pw = 0.0;
+    bool have = false;
     for (int p = 0; p < CH_PANELS; ++p) {
-        if (t == 0) { flag_wait_ge(fl.panel + k_blk * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks); if (WITH_D1) CH_MARK(1024 + k_blk * CH_PANELS + p); }
+        if (t == 0) {
+            if (!have) flag_wait_ge(fl.panel + k_blk * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
+            if (WITH_D1) CH_MARK(1024 + k_blk * CH_PANELS + p);
+            *nready = (p + 1 < CH_PANELS && __hip_atomic_load(fl.panel + k_blk * CH_PANELS + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= fl.panel_want) ? 1 : 0;
+        }
         __syncthreads();
+        const bool nxt = *nready != 0;
         {   // stage the published panel: rows 16p..127 of L_kk, columns 16p..16p+15 (4 threads per 128-B row segment)
             const int i = t >> 2, mq = t & 3;
             if (i >= 16 * p) {
-                const double* src = Lkk + (int64_t)i * ld + 16 * p + 4 * mq;
-                const double v0 = ld_agent(src), v1 = ld_agent(src + 1), v2 = ld_agent(src + 2), v3 = ld_agent(src + 3);
+                double v0 = pv0, v1 = pv1, v2 = pv2, v3 = pv3;
+                if (!have) {
+                    const double* src = Lkk + (int64_t)i * ld + 16 * p + 4 * mq;
+                    v0 = ld_agent(src); v1 = ld_agent(src + 1); v2 = ld_agent(src + 2); v3 = ld_agent(src + 3);
+                }
                 double* dst = LPt + (4 * mq) * WK_LS + i;
                 dst[0] = v0; dst[WK_LS] = v1; dst[2 * WK_LS] = v2; dst[3 * WK_LS] = v3;
             }
-            if (t < 256) W16s[t] = ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p) * 256 + t);
+            if (t < 256) W16s[t] = have ? pw : ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p) * 256 + t);
         }
+        if (nxt) {   // the next panel's staging loads: in flight during this panel's solve and update
+            const int i = t >> 2, mq = t & 3;
+            if (i >= 16 * (p + 1)) {
+                const double* src = Lkk + (int64_t)i * ld + 16 * (p + 1) + 4 * mq;
+                pv0 = ld_agent(src); pv1 = ld_agent(src + 1); pv2 = ld_agent(src + 2); pv3 = ld_agent(src + 3);
+            }
+            if (t < 256) pw = ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p + 1) * 256 + t);
+        }
+        have = nxt;
         if (w == p) {   // the wave that holds the panel's columns hands them to the row solvers
 #pragma unroll
             for (int i = 0; i < 8; ++i)
@@ -418,7 +444,7 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             __syncthreads();
         } else {
             if (r >= 2) {   // tile (r, r) carries every update from blocks <= r-2 once the gated update of block r-2 is in memory
-                if (tid == 0) { CH_MARK(3300 + 4 * (r - 2) + 3); flag_wait_ge(fl.crit + (r - 2), fl.crit_want, fl.abort, fl.spin_ticks); CH_MARK(3400 + r); }
+                if (tid == 0) { CH_MARK(3300 + 4 * (r - 2) + 3); CH_MARK(4864 + r); flag_wait_ge(fl.crit + (r - 2), fl.crit_want, fl.abort, fl.spin_ticks); CH_MARK(3400 + r); CH_MARK(5120 + r); }
                 __syncthreads();
             }
             d1_load<H>(Lmat, ld, r, d);
@@ -426,7 +452,7 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             const unsigned* xf = xp_at(fl, r - 1, r);
             const double* Sx = S + ((int64_t)r * TILE + (tid >> 2)) * ld + (int64_t)(r - 1) * TILE + 4 * (tid & 3);
             for (int p = 0; p < CH_PANELS; ++p) {
-                if (tid == 0) { flag_wait_ge(xf + p, 1u, fl.abort, fl.spin_ticks); CH_MARK(1024 + (r - 1) * CH_PANELS + p); }
+                if (tid == 0) { flag_wait_ge(xf + p, 1u, fl.abort, fl.spin_ticks); CH_MARK(1024 + (r - 1) * CH_PANELS + p); if (p == CH_PANELS - 1) CH_MARK(5376 + r); }
                 __syncthreads();
                 {   // panel p of L(r, r-1): 128 rows x 16 columns, 32 B per thread
                     d2 v0, v1;
@@ -477,6 +503,8 @@ __device__ __forceinline__ void crit_follower(double* __restrict__ Lmat, int64_t
                 else flag_wait_ge(fl.colr + (size_t)(k - 1) * T + r, 8u, fl.abort, fl.spin_ticks);   // tile (k+2, k): its column updaters of block k-1
             }
             __syncthreads();
+            if (tid == 0 && r == k + 2) CH_MARK(4352 + k);
+            if (tid == 0 && r == k + 1) CH_MARK(5632 + k);
         }
         load_row_piece(Lmat, ld, r, k, ar);
         if (tid == 0 && k < 24) CH_MARK(3648 + (k * 2 + (r - k - 1)) * 9 + 8);
@@ -589,38 +617,145 @@ __device__ __forceinline__ void gated_worker(double* __restrict__ Lmat, int64_t 
 // and raises solved[k]: the launch that solves the rows >= k+3 of L(:, k) as a product with W_kk' waits for it.  The same
 // blocks are the seeds of the triangular inverse W = L^-1, so k_inv128 is not needed afterwards.
 // ------------------------------------------------------------------------------------------------------------------------
-// ---- role 4 (workgroup 8, mode2 only; its upper four waves leave at once -- ended waves do not take part in barriers)
+// ---- role 4 (workgroup 8, mode2 only; its upper four waves leave at once -- ended waves do not take part in barriers).
+// INCREMENTAL: the first version waited for the block's last panel and then ran the recursive-doubling inverse of k_potf2_inv
+// (25-30 us behind the pivot block -- on the critical path of every block: pivot -> inverse -> row solve -> update -> chain).
+// W = L^-1 can follow the pivot chain row panel by row panel instead:
+//     W[p, q] = -W16_p  sum_{q <= m < p} L[p, m] W[m, q]      (16-row panels p, q;  W[p, p] = W16_p, published by the pivot)
+// T = L[p, 0:p] W[0:p, 0:p] needs only panels < p (the rows of L behind the pivot arrive with the earlier column panels), so
+// it is computed BEFORE panel p's flag arrives; what is left behind the last panel is one 16 x 16 product and the stores:
+// solved[k] rises ~3 us after the pivot block ends.  Image: Wimg[m][c] = W[m][c] for the rows m < 112 (zero above the diagonal).
+constexpr int INV_WROWS = TILE - 16;
+static_assert(INV_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "inverter image must fit the chain's LDS");
 __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ W,
                                               double* __restrict__ WT, int64_t ldw, int T, const CholFlags& fl, double* sm) {
     if (threadIdx.x >= PF_THREADS) return;
-    double* a = sm;
-    double* idl = sm + TILE * PF_LD + TILE;
-    const int tid = threadIdx.x;
+    double* Wimg = sm;                         // [128][128]  W_kk (zero above the diagonal)
+    double* Lrow = sm + TILE * TILE;           // [16][112]   rows 16p .. 16p+15 of L_kk, columns < 16p
+    double* Tl = Lrow + 16 * INV_WROWS;        // [8][128]    rows 0..7 of T for the threads that build the rows 8..15
+    double* W16s = Tl + 8 * TILE;              // [16][16]
+    const int tid = threadIdx.x, c = tid & 127, rh = tid >> 7;
+    for (int e = tid; e < TILE * TILE; e += PF_THREADS) Wimg[e] = 0.0;   // the strict upper triangle is never written again
+    __syncthreads();
     for (int k = 0; k < T; ++k) {
-        if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + (CH_PANELS - 1), fl.panel_want, fl.abort, fl.spin_ticks);
-        __syncthreads();
         const int64_t off = (int64_t)k * TILE;
         const double* Lblk = Lmat + off * (ld + 1);
-        {   // mirror image: a[c][r] = L[r][c] for c < r, the lower triangle is workspace for W (panels were published agent-scope)
-            const int j = tid & 127, ih = tid >> 7;
-#pragma unroll 1
-            for (int i0 = 0; i0 < TILE; i0 += 32) {
-                double v[16];
+        double* Wb = W + off * (ldw + 1);
+        double* WTb = WT + off * (ldw + 1);
+        for (int p = 0; p < CH_PANELS; ++p) {
+            const int R0 = 16 * p;
+            double t[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = ld_agent(Lblk + (int64_t)(i0 + 2 * u + ih) * ld + j);
+            for (int j = 0; j < 8; ++j) t[j] = 0.0;
+            if (p > 0) {   // (panel p-1's flag was seen in the previous round: the rows behind the pivot are published)
+                {
+                    const int r = tid >> 4, mm = tid & 15;
+                    const double* src = Lblk + (int64_t)(R0 + r) * ld + mm;
+                    for (int u = 0; u < p; ++u) Lrow[r * INV_WROWS + 16 * u + mm] = ld_agent(src + 16 * u);
+                }
+                __syncthreads();
+                if (c < R0) {   // thread (c, rh): rows 8 rh .. 8 rh + 7 of T = L[p, 0:p] W[0:p, 0:p], column c
+                    // 8 contraction indices per round: 8 + 32 LDS reads (the L rows as 16-byte pieces) for 64 FMAs, all issued
+                    // before the first use (one read per FMA in a dependent loop took ~10 us per panel: behind the 7 us pivot cadence)
+                    const double* lr = Lrow + 8 * rh * INV_WROWS;
+                    for (int m0 = 0; m0 < R0; m0 += 8) {
+                        double w[8];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int i = i0 + 2 * u + ih;
-                    if (j < i) a[j * PF_LD + i] = v[u];
-                    else if (j == i) idl[i] = 1.0 / v[u];
+                        for (int q = 0; q < 8; ++q) w[q] = Wimg[(m0 + q) * TILE + c];
+#pragma unroll
+                        for (int jh = 0; jh < 2; ++jh) {
+                            d2 l[4][4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) l[j][q] = *reinterpret_cast<const d2*>(lr + (4 * jh + j) * INV_WROWS + m0 + 2 * q);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    t[4 * jh + j] += l[j][q].x * w[2 * q];
+                                    t[4 * jh + j] += l[j][q].y * w[2 * q + 1];
+                                }
+                        }
+                    }
+                    if (rh == 0) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) Tl[j * TILE + c] = t[j];
+                    }
+                }
+            }
+            if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
+            __syncthreads();
+            W16s[tid] = ld_agent(fl.w16_g + ((size_t)k * CH_PANELS + p) * 256 + tid);
+            __syncthreads();
+            if (p > 0 && c < R0) {   // rows 8 rh .. 8 rh + 7 of the new row panel: -W16 T
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 8 * rh + rr;
+                    double sacc = 0.0;
+                    if (rh == 0) {
+#pragma unroll
+                        for (int j = 0; j <= rr; ++j) sacc += W16s[r * 16 + j] * t[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sacc += W16s[r * 16 + j] * Tl[j * TILE + c];
+#pragma unroll
+                        for (int j = 0; j <= rr; ++j) sacc += W16s[r * 16 + 8 + j] * t[j];
+                    }
+                    Wimg[(R0 + r) * TILE + c] = -sacc;
+                }
+            }
+            Wimg[(R0 + (tid >> 4)) * TILE + R0 + (tid & 15)] = W16s[tid];   // the diagonal block is W16 itself (zeros above its diagonal)
+            __syncthreads();
+            {   // row panel p out: W rows (16-byte pieces along the row) and the same entries as columns of W'
+                const int r = tid >> 4, q = tid & 15;
+                for (int u = q >> 3; u <= p; u += 2) {
+                    const int col = 16 * u + 2 * (q & 7);
+                    const d2 v = *reinterpret_cast<const d2*>(Wimg + (R0 + r) * TILE + col);
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(Wb + (int64_t)(R0 + r) * ldw + col), "v"(v) : "memory");
+                }
+                if (c < R0 + 16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int rr = 2 * (4 * rh + e);
+                        d2 v;
+                        v.x = Wimg[(R0 + rr) * TILE + c];
+                        v.y = Wimg[(R0 + rr + 1) * TILE + c];
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTb + (int64_t)c * ldw + R0 + rr), "v"(v) : "memory");
+                    }
                 }
             }
         }
-        __syncthreads();
-        inverse_phase<true>(a, idl, tid, W + off * (ldw + 1), WT + off * (ldw + 1), ldw);
         release_wg();
         __syncthreads();
-        if (tid == 0) flag_set(fl.solved + k, 1u);
+        if (tid == 0) { flag_set(fl.solved + k, 1u); CH_MARK(4096 + k); }
+    }
+}
+
+// ---- role 5 (workgroups 9 .. 9 + nsf - 1, executor form only): the row solves of the tiles (k+3, k) .. (k+2+nsf, k), panel
+// by panel behind the pivot chain like the critical followers, so that S(k+3, k) -- the operand of the three tiles the chain
+// waits for next -- is complete ~3 us after the pivot block instead of one inverse (~20 us) + one solve task (~20-40 us) later.
+// Follower f needs tile (k+3+f, k) final, i.e. a row of the executor's Late(k-1), which in turn needs S(k+3+f, k-1): for all
+// but the last follower that is the NEXT follower's output of the block before -- also chain-internal and early -- so only the
+// last follower's input hangs on the executor's inverse -> Solve -> Late path, and that one has nsf blocks of slack (a late
+// start is caught up within the block: a panel takes a follower ~3 us, the pivot ~7 us).
+constexpr int CH_NSF_MAX = 6;   // (the number in use is CholFlags::nsf, BOHIP_CHOL_NSF)
+__device__ __forceinline__ void solve_follower(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ S, int T,
+                                               const CholFlags& fl, double* sm, int f) {
+    const int tid = threadIdx.x;
+    double ar[32], dd[18];
+    for (int k = 0; k + 3 + f < T; ++k) {
+        const int r = k + 3 + f;
+        if (k >= 1) {   // ver(r, k) of kernels_exec.hip: every read-modify-write round of the tile is in memory
+            const int nb = k / 4 - 1 > 0 ? k / 4 - 1 : 0;
+            if (tid == 0) flag_wait_ge(fl.xp + ((size_t)(k - 1) * T + r) * CH_PANELS, 16u * (unsigned)(nb + 1), fl.abort, fl.spin_ticks);
+            __syncthreads();
+        }
+        load_row_piece(Lmat, ld, r, k, ar);
+        follow_block<false, 0>(Lmat, ld, S, r, k, fl, sm, ar, dd, nullptr);
+        release_wg();
+        __syncthreads();
+        if (tid == 0) { flag_set(fl.colr + (size_t)k * T + r, 16u); if (f == 0) CH_MARK(4608 + k); }   // sver(r, k)
     }
 }
 
@@ -630,7 +765,9 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_chain(double* __restrict
                                                            double* __restrict__ WT) {
     extern __shared__ double sm[];
     const int b = blockIdx.x;
-    if (b == 8) {
+    if (b >= 9) {
+        solve_follower(Lmat, ld, S, T, fl, sm, b - 9);
+    } else if (b == 8) {
         inverter_role(Lmat, ld, W, WT, ld, T, fl, sm);
     } else if (b < 2) {
         if ((threadIdx.x >> 8) == 0) chain_owner<0>(Lmat, ld, S, T, fl, info, sm, b);

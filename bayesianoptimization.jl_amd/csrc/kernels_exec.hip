@@ -51,7 +51,11 @@ struct ExTask {                 // 128 bytes, written by the host once per (hand
     int32_t kc;                 // 16-deep contraction chunks
     int32_t diag_h;             // -1, or this task is half `diag_h` of a DIAGONAL tile: entries with 64 h + c > r stay untouched
     int32_t rmw;                // 1: C = C - A B' - P;  0: C = A B'
-    int32_t pad[7];
+    int32_t prio;               // s_setprio of the task's waves: the chain waits for queue 0, so its tasks win the matrix pipe of a shared CU
+    int32_t kc_split;           // > 0: the contraction runs in two pieces, chunks [0, kc_split) at once and [kc_split, kc) once the
+    uint32_t dep2_idx[2];       //      counters dep2 have arrived (waited for INSIDE the task: the three tiles the chain waits for start on
+    uint32_t dep2_want[2];      //      the previous block's half of their K = 256 while the row solve of the current block is still running)
+    int32_t pad[1];
 };
 static_assert(sizeof(ExTask) == 128, "task record layout");
 
@@ -63,6 +67,8 @@ struct ExQueues {
     unsigned* abort;
     int64_t ld;
     unsigned long long spin_ticks;   // a workgroup that finds no runnable task for this long gives up (see flag_wait_ge)
+    int stride[EX_NQ];          // records per claim: 1, or 2 = both halves of a tile run back to back by one workgroup (the look and
+                                // claim between two tasks cost ~12 us against ~70 us of work: queues 1 and 2 are claimed in pairs)
 };
 
 // Claim the next task.  Run by the 64 lanes of wave 0: lane 8 q + d looks at dependency d of the head of queue q, so the heads
@@ -76,6 +82,34 @@ struct ExQueues {
 __device__ __forceinline__ bool ex_dep_pending(const ExTask* t, int d, const unsigned* flags) {
     const uint32_t idx = t->dep_idx[d];
     return idx != EX_NONE && __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t->dep_want[d];
+}
+// wait until every counter of a claimed task has arrived (wave 0).  false: abort / time-out.
+// `ntile` tiles = 2 ntile consecutive records (the two halves of a tile share their counters): lane 8 j + d looks at tile j
+__device__ __forceinline__ bool ex_wait_task(const ExQueues& q, const ExTask* t, int ntile, int lane) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const bool p2 = (lane >> 3) < ntile && (lane & 7) < EX_NDEP && ex_dep_pending(t + 2 * (lane >> 3), lane & 7, q.flags);
+        if (__ballot(p2) == 0ull) return true;
+        if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if (wall_clock64() - t0 > q.spin_ticks) {
+            if (lane == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+// claim from queue qi (its head was seen runnable): the task index, -1 on abort, -2 if the queue ran dry meanwhile
+__device__ __forceinline__ int ex_claim(const ExQueues& q, int qi, unsigned h_seen, int lane) {
+    unsigned c = 0;
+    if (lane == 0) c = atomicAdd(q.heads + qi, (unsigned)q.stride[qi]);
+    c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+    const unsigned nq = (unsigned)(q.qbeg[qi + 1] - q.qbeg[qi]);
+    if (c >= nq) return -2;
+    // usually c is a task a little behind the head that was seen runnable: wait for ITS counters (and, when a claim covers
+    // several tiles, for those of every tile of the claim: the look only saw the first)
+    const int ntile = q.stride[qi] <= 2 ? 1 : (int)((nq - c < (unsigned)q.stride[qi] ? nq - c : (unsigned)q.stride[qi]) + 1u) / 2;
+    if ((c != h_seen || ntile > 1) && !ex_wait_task(q, q.tasks + q.qbeg[qi] + c, ntile, lane)) return -1;
+    return q.qbeg[qi] + (int)c;
 }
 __device__ __forceinline__ int ex_pick(const ExQueues& q, int lane) {
     const int qi = lane >> 3, d = lane & 7;
@@ -96,24 +130,10 @@ __device__ __forceinline__ int ex_pick(const ExQueues& q, int lane) {
         for (int c = EX_NQ - 1; c >= 0; --c)
             if (((lv >> (8 * c)) & 1ull) && ((pd >> (8 * c)) & 0xffull) == 0ull) pickq = c;
         if (pickq >= 0) {
-            unsigned c = 0;
-            if (lane == 0) c = atomicAdd(q.heads + pickq, 1u);
-            c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
-            const unsigned nq = (unsigned)(q.qbeg[pickq + 1] - q.qbeg[pickq]);
-            if (c >= nq) continue;   // the queue ran dry between the look and the claim
-            const ExTask* t = q.tasks + q.qbeg[pickq] + c;
-            const unsigned long long t0 = wall_clock64();
-            for (;;) {   // usually c is the head that was just seen runnable; otherwise a task a little behind it
-                const bool p2 = lane < EX_NDEP && ex_dep_pending(t, lane, q.flags);
-                if (__ballot(p2) == 0ull) break;
-                if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
-                if (wall_clock64() - t0 > q.spin_ticks) {
-                    if (lane == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return -1;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            return q.qbeg[pickq] + (int)c;
+            const unsigned hs = (unsigned)__builtin_amdgcn_readlane((int)h, 8 * pickq);
+            const int r = ex_claim(q, pickq, hs, lane);
+            if (r != -2) return r;
+            continue;   // the queue ran dry between the look and the claim
         }
         if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
         if (wall_clock64() - t_idle > q.spin_ticks) {   // no runnable task for this long: something upstream never arrived
@@ -125,14 +145,64 @@ __device__ __forceinline__ int ex_pick(const ExQueues& q, int lane) {
     }
 }
 
-__device__ __forceinline__ void ex_run(const ExTask& t, int64_t ld, unsigned* flags, double* smem, int tid) {
+#if BOHIP_CHOL_TRACE
+__device__ unsigned long long g_ex_trace[65536 * 8];   // per task: looking since | claimed and runnable | finished | workgroup | second-stage counters in | main loop done
+#endif
+// The look for the NEXT task rides on this task's epilogue (do_look): wave 0 reads the queue heads while the tile goes through
+// LDS, the head records' counters' names while the old tile value is fetched, the counters while the stores drain -- three
+// dependent memory round trips that used to sit between two tasks.  What comes out is a few microseconds stale, which is
+// harmless: a head seen runnable stays runnable, and one that became runnable meanwhile is seen by the next free workgroup
+// (one frees up every ~0.1 us).  Returns 8 * queue + ... packed as (queue << 24) | head, or -1 if no head was runnable.
+__device__ __forceinline__ int ex_run(const ExTask& t, const ExQueues& q, double* smem, int tid, bool do_look, int trace_slot = -1) {
+    const int64_t ld = q.ld;
+    unsigned* flags = q.flags;
+    unsigned* abort = q.abort;
+    const unsigned long long spin_ticks = q.spin_ticks;
     double acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    gemm_tile_loop_glds3_ks<4, 0, true>(t.A, ld, t.B, ld, 0, t.kc, smem, acc, TILE, 1 << 30, tid);
+    {
+        const int pr = t.prio;   // (s_setprio takes an immediate)
+        if (pr >= 2) __builtin_amdgcn_s_setprio(3);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+    const int ksp = t.kc_split;
+    if (ksp > 0) {
+        gemm_tile_loop_glds3_ks<4, 0, true, false>(t.A, ld, t.B, ld, 0, ksp, smem, acc, TILE, 1 << 30, tid);
+        if (tid == 0) {   // (tasks are claimed in queue order: what this waits for is already claimed by a running workgroup, or the chain's)
+            const unsigned long long t0 = wall_clock64();
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+                    if (t.dep2_idx[d] != EX_NONE && __hip_atomic_load(flags + t.dep2_idx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t.dep2_want[d]) ok = false;
+                if (ok || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+                if (wall_clock64() - t0 > spin_ticks) { __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+#if BOHIP_CHOL_TRACE
+        if (tid == 0 && trace_slot >= 0 && trace_slot < 65536) g_ex_trace[8 * trace_slot + 4] = wall_clock64();
+#endif
+    }
+    gemm_tile_loop_glds3_ks<4, 0, true>(t.A, ld, t.B, ld, ksp, t.kc, smem, acc, TILE, 1 << 30, tid);
+#if BOHIP_CHOL_TRACE
+    if (tid == 0 && trace_slot >= 0 && trace_slot < 65536) g_ex_trace[8 * trace_slot + 5] = wall_clock64();
+#endif
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = (wave & 3) >> 1, wc = wave & 1;
+    const bool looker = do_look && tid < 64;
+    const int lqi = tid >> 3, ldp = tid & 7;
+    unsigned lk_h = 0, lk_n = 0, lk_f = 0;
+    uint32_t lk_idx = EX_NONE, lk_want = 0;
+    bool lk_live = false;
+    if (looker && lqi < EX_NQ) {
+        lk_n = (unsigned)(q.qbeg[lqi + 1] - q.qbeg[lqi]);
+        lk_h = __hip_atomic_load(q.heads + lqi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // the tile takes a turn through LDS and leaves as 16-byte agent-scope pieces, 1 KB contiguous per wave instruction
     constexpr int TS = CTILE + 2;
     double* Tl = smem;   // [128][66]: the staging buffers are free (the loop ended on a barrier)
@@ -143,6 +213,14 @@ __device__ __forceinline__ void ex_run(const ExTask& t, int64_t ld, unsigned* fl
             for (int nj = 0; nj < 4; ++nj) Tl[acc_row(lane, wr, mi) * TS + acc_col<4>(lane, wc, nj)] = acc[mi][nj];
     }
     __syncthreads();
+    if (looker) {
+        lk_live = lqi < EX_NQ && lk_h < lk_n;
+        if (lk_live && ldp < EX_NDEP) {
+            const ExTask* nt = q.tasks + q.qbeg[lqi] + lk_h;
+            lk_idx = nt->dep_idx[ldp];
+            lk_want = nt->dep_want[ldp];
+        }
+    }
     constexpr int NP = (TILE * CTILE / 2) / GEMM_THREADS_8;   // 8 pieces per thread
     const int rmw = t.rmw, dh = t.diag_h;
     const double* P = t.P;
@@ -170,6 +248,7 @@ __device__ __forceinline__ void ex_run(const ExTask& t, int64_t ld, unsigned* fl
                      :
                      : "memory");
     }
+    if (looker && lk_idx != EX_NONE) lk_f = __hip_atomic_load(flags + lk_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
         const int piece = tid + GEMM_THREADS_8 * u, r = piece >> 5, c = (piece & 31) * 2;
@@ -193,24 +272,56 @@ __device__ __forceinline__ void ex_run(const ExTask& t, int64_t ld, unsigned* fl
         if (t.sig_idx[0] != EX_NONE) atomicAdd(flags + t.sig_idx[0], 1u);
         if (t.sig_idx[1] != EX_NONE) atomicAdd(flags + t.sig_idx[1], 1u);
     }
+    int res = -1;
+    if (looker) {
+        const bool pending = lk_live && lk_idx != EX_NONE && lk_f < lk_want;
+        const unsigned long long lv = __ballot(lk_live), pd = __ballot(pending);
+        int pickq = -1;
+#pragma unroll
+        for (int c = EX_NQ - 1; c >= 0; --c)
+            if (((lv >> (8 * c)) & 1ull) && ((pd >> (8 * c)) & 0xffull) == 0ull) pickq = c;
+        if (pickq >= 0) res = (pickq << 24) | (int)((unsigned)__builtin_amdgcn_readlane((int)lk_h, 8 * pickq) & 0xffffffu);
+    }
+    return res;
 }
 
 __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_task;
+    int look = -1;   // wave 0: what the look during the previous task's epilogue found ((queue << 24) | head), -1 nothing
     for (;;) {
+#if BOHIP_CHOL_TRACE
+        const unsigned long long tr0 = wall_clock64();
+#endif
         if (threadIdx.x < 64) {
-            const int tk = ex_pick(q, (int)threadIdx.x);
-            if (threadIdx.x == 0) s_task = tk;
+            int pl = threadIdx.x;
+            asm volatile("" : "+v"(pl));   // opaque: the look's lane arithmetic must not be kept alive across the task
+            int tk = -2;
+            if (look >= 0) tk = ex_claim(q, look >> 24, (unsigned)(look & 0xffffff), pl);
+            if (tk == -2) tk = ex_pick(q, pl);
+            if (pl == 0) s_task = tk;
         }
         __syncthreads();
         const int ti = __builtin_amdgcn_readfirstlane(s_task);
         __syncthreads();
         if (ti < 0) break;
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));   // opaque per task: nothing lane-dependent is hoisted out of this loop
-        ex_run(q.tasks[ti], q.ld, q.flags, smem, tid);
-        __syncthreads();   // the LDS tile is rewritten by the next task's DMA
+        const int qi_ = ti >= q.qbeg[1] ? (ti >= q.qbeg[2] ? 2 : 1) : 0;
+        const int pair = min(q.stride[qi_], q.qbeg[qi_ + 1] - ti);
+        for (int u = 0; u < pair; ++u) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));   // opaque per task: nothing lane-dependent is hoisted out of this loop
+#if BOHIP_CHOL_TRACE
+            const unsigned long long tr1 = wall_clock64();
+#endif
+            look = ex_run(q.tasks[ti + u], q, smem, tid, u == pair - 1, ti + u);
+            __syncthreads();   // the LDS tile is rewritten by the next task's DMA
+#if BOHIP_CHOL_TRACE
+            if (threadIdx.x == 0 && ti + u < 65536) {
+                g_ex_trace[8 * (ti + u)] = u == 0 ? tr0 : tr1; g_ex_trace[8 * (ti + u) + 1] = tr1; g_ex_trace[8 * (ti + u) + 2] = wall_clock64();
+                g_ex_trace[8 * (ti + u) + 3] = blockIdx.x;
+            }
+#endif
+        }
     }
 }
 

@@ -2,7 +2,8 @@
 
 The task records are built on the HOST (a pure function of addresses, ld and T) and executed on the device by k_chol_exec.
 Here the real builder is called through its test hook with fake base addresses, and the records are replayed with NumPy
-against a model of the persistent chain kernel (k_chol_chain in its mode2 = 100 view):
+against a model of the persistent chain kernel (k_chol_chain in its mode2 = 100 view, with its solve_follower workgroup that
+delivers S(k+3, k)):
 
   * every queue is consumed strictly in order, a task only when all of its dependency counters have reached their value
     -- exactly the device's claim rule -- under several adversarial interleavings (tasks as early as possible / chain as
@@ -28,11 +29,11 @@ def get_tasks(T, ld):
     f.restype = C.c_int64
     f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     qbeg = (C.c_int * 4)()
-    layout = (C.c_int64 * 10)()
+    layout = (C.c_int64 * 11)()
     n = f(T, ld, BASE_L, BASE_S, BASE_W, None, 0, qbeg, layout)
     buf = np.zeros((n, 16), dtype=np.uint64)
     assert f(T, ld, BASE_L, BASE_S, BASE_W, buf.ctypes.data_as(C.c_void_p), n, qbeg, layout) == n
-    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp"]
+    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp", "nsf"]
     return buf, list(qbeg), dict(zip(names, layout))
 
 
@@ -43,6 +44,10 @@ def decode(rec):
     t["sig"] = [int(w[20 + s]) for s in range(2) if int(w[20 + s]) != NONE]
     i32 = rec.view(np.int32)
     t["kc"], t["diag_h"], t["rmw"] = int(i32[22]), int(i32[23]), int(i32[24])
+    t["kc_split"] = int(i32[26])
+    t["dep2"] = [(int(w[27 + s]), int(w[29 + s])) for s in range(2) if int(w[27 + s]) != NONE]
+    if t["kc_split"] == 0:
+        assert not t["dep2"]
     return t
 
 
@@ -78,6 +83,11 @@ def replay(T, order, seed=0):
         B = view(t["B"], CT, K_)
         Cv = view(t["C"], TILE, CT)
         assert not np.isnan(A).any() and not np.isnan(B).any(), "operand read before it was written"
+        if t["kc_split"]:   # the first piece ran on what was there when the task became claimable: must be the final operands
+            K1 = KC * t["kc_split"]
+            assert id(t) in snap, "two-piece task ran without ever having been claimable on its first-stage counters alone"
+            a1, b1 = snap[id(t)]
+            assert np.array_equal(a1, A[:, :K1]) and np.array_equal(b1, B[:, :K1]), "first-piece operand changed after the claim"
         prod = A @ B.T
         keep = np.ones((TILE, CT), dtype=bool)
         if t["diag_h"] >= 0:   # half of a diagonal tile: the strict upper triangle is never written (nor meaningful when read)
@@ -96,8 +106,11 @@ def replay(T, order, seed=0):
             flags[s] += 8   # eight waves add one each
 
     def ready(t):
-        return all(flags[i] >= w for i, w in t["dep"])
+        # the second-stage counters are waited for inside the task after its first `kc_split` chunks; the replay runs a task
+        # in one piece, so it takes them as ordinary dependencies (and checks below that the first piece would not have needed them)
+        return all(flags[i] >= w for i, w in t["dep"] + t["dep2"])
 
+    snap = {}
     heads = [qbeg[q] for q in range(3)]
     chain_k = 0   # next block of the chain
 
@@ -128,28 +141,62 @@ def replay(T, order, seed=0):
             tile(BASE_L, k + 2, k + 2)[:, :] -= np.tril(s2 @ s2.T)
         chain_k += 1
 
+    NSF = lay["nsf"]
+    tf_k = [0] * NSF   # next block of each of the chain kernel's solve_follower workgroups (follower f: row k+3+f of block k)
+
+    def tf_can_run(f):
+        k = tf_k[f]
+        r = k + 3 + f
+        if r >= T or k >= chain_k:
+            return False
+        if k == 0:
+            return True
+        nb = max(k // 4 - 1, 0)
+        return flags[lay["xp"] + ((k - 1) * T + r) * 8] >= 16 * (nb + 1)
+
+    def tf_step(f):
+        k = tf_k[f]
+        r = k + 3 + f
+        Lkk = tile(BASE_L, k, k)
+        tile(BASE_S, r, k)[:, :] = np.linalg.solve(Lkk, tile(BASE_L, r, k).T).T
+        flags[lay["colr"] + k * T + r] = 16
+        tf_k[f] += 1
+
     steps = 0
     while True:
+        for q in range(3):   # a two-piece task at a queue head whose first-stage counters are in: the device would start its first piece now
+            if heads[q] < qbeg[q + 1]:
+                t = tasks[heads[q]]
+                if t["kc_split"] and id(t) not in snap and all(flags[i] >= w for i, w in t["dep"]):
+                    K1 = KC * t["kc_split"]
+                    assert 0 < t["kc_split"] < t["kc"]
+                    a1, b1 = view(t["A"], TILE, K1).copy(), view(t["B"], CT, K1).copy()
+                    assert not np.isnan(a1).any() and not np.isnan(b1).any(), "first piece would read an operand before it was written"
+                    snap[id(t)] = (a1, b1)
         runnable = [q for q in range(3) if heads[q] < qbeg[q + 1] and ready(tasks[heads[q]])]
         can_chain = chain_can_run()
-        if not runnable and not can_chain:
+        tfs = [("tf", f) for f in range(NSF) if tf_can_run(f)]
+        if not runnable and not can_chain and not tfs:
             break
         if order == "tasks_first":
-            pick = runnable[0] if runnable else "chain"
+            pick = runnable[0] if runnable else ("chain" if can_chain else tfs[-1])
         elif order == "low_priority_first":
-            pick = runnable[-1] if runnable else "chain"
+            pick = runnable[-1] if runnable else (tfs[0] if tfs else "chain")
         elif order == "chain_first":
-            pick = "chain" if can_chain else runnable[0]
+            pick = "chain" if can_chain else (tfs[0] if tfs else runnable[0])
         else:
-            opts = runnable + (["chain"] if can_chain else [])
+            opts = runnable + (["chain"] if can_chain else []) + tfs
             pick = opts[rng.integers(len(opts))]
         if pick == "chain":
             chain_step()
+        elif isinstance(pick, tuple):
+            tf_step(pick[1])
         else:
             run_task(tasks[heads[pick]])
             heads[pick] += 1
         steps += 1
     assert chain_k == T, f"dead-lock: chain stopped at block {chain_k} of {T}, queue heads {heads} of {qbeg}"
+    assert tf_k == [max(T - 3 - f, 0) for f in range(NSF)]
     assert heads == qbeg[1:], f"records left over: heads {heads}, queues {qbeg}"
     # k_copy_offdiag_tiles: the solved panels go home
     L = mats[BASE_L]
