@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_OBS, DIM, R_PER_GPU = 3000, 8, 4096
+STRONG_R_TOTAL = 32768   # --strong: BASELINE configs[2] (R = 32768 restarts in total) at every --gpus
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = vector peak (256 CU x 4 SIMD x 2.4 GHz x 32 FLOP/clk); the
 #                          MICROARCH guide lists no FP64 row; tools/ubench_fp64b.hip measures 73 TF/s sustained.
 
@@ -66,6 +67,30 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
     L = orc.cholesky(cK)                                   # cpu-chol: row-by-row restatement, one thread
     t_chol = time.perf_counter() - t0
     alpha = orc.alpha(L, y, 0.0)
+    # what the reference itself runs for this step is LAPACK potrf (ElasticPDMats -> LinearAlgebra.cholesky!):
+    # the same factorisation through SciPy's LAPACK on one thread and on all of them, beside the scalar restatement
+    lapack = {}
+    try:
+        import scipy.linalg as sl
+        from threadpoolctl import threadpool_limits
+
+        def potrf_time(nthreads, reps):
+            best = float("inf")
+            with threadpool_limits(limits=nthreads):
+                for _ in range(reps):
+                    t0_ = time.perf_counter()
+                    Ll = sl.cholesky(cK, lower=True, check_finite=False)
+                    best = min(best, time.perf_counter() - t0_)
+            return best, Ll
+
+        t1t, Ll = potrf_time(1, 2)
+        tall, _ = potrf_time(None, 3)
+        lapack = {"lapack_potrf_1_thread_gflops": (N_OBS ** 3 / 3.0) / t1t / 1e9,
+                  "lapack_potrf_all_threads_gflops": (N_OBS ** 3 / 3.0) / tall / 1e9,
+                  "lapack_sample": f"scipy.linalg.cholesky (LAPACK dpotrf), N={N_OBS}: {t1t * 1e3:.0f} ms on 1 thread, {tall * 1e3:.0f} ms on all "
+                                   f"threads ({os.cpu_count()} logical cores); max |L - L_port| = {float(np.abs(Ll - L).max()):.1e}"}
+    except Exception as e:   # noqa: BLE001  (reported, never fatal: the port's figure stays)
+        lapack = {"lapack_sample": f"unavailable: {e}"}
     sample = Xs[:budget_candidates]
     t0 = time.perf_counter()
     orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], sample, nthreads=1)
@@ -95,7 +120,7 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
         "allcores": {"value": len(big) / tn, "cores": ncores, "sample": f"{len(big)} candidates, {tn:.1f} s"},
         "with_gradient": {"value": len(gsample) / tg, "cores": 1, "sample": f"{len(gsample)} candidates, {tg:.1f} s "
                           "(the reference's default :LD_LBFGS path evaluates value and gradient)"},
-        "cholesky": {"gflops": (N_OBS ** 3 / 3.0) / t_chol / 1e9, "cores": 1, "sample": f"N={N_OBS}, {t_chol:.1f} s"},
+        "cholesky": {"gflops": (N_OBS ** 3 / 3.0) / t_chol / 1e9, "cores": 1, "sample": f"N={N_OBS}, {t_chol:.1f} s (row-by-row scalar port)", **lapack},
         "cpu_model": cpu_model, "host_cores": os.cpu_count(),
     }
 
@@ -125,13 +150,33 @@ def emit(line):
         os.write(_OUT_FD, (line + "\n").encode())
 
 
-def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, extra=None):
+def r_per_gpu(args, world):
+    """weak scaling (default): R = 4096 per GPU; --strong: R_total = 32768 (BASELINE configs[2]) cut into `world` shards"""
+    return (STRONG_R_TOTAL // world) if args.strong else R_PER_GPU
+
+
+def median_refit_ms(model, reps=7):
+    """model_update_ms: median over `reps` full refits (a single refit right after the first allocation is a poor sample)"""
+    runs = []
+    for _ in range(reps):
+        model.set_params_(logNoise=-2.0)
+        model.fit_()
+        runs.append(dict(model.timing()))
+    keys = runs[0].keys()
+    return {k: float(np.median([r[k] for r in runs if k in r])) for k in keys}
+
+
+def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, extra=None, n_devices=None):
     ms_per_step = elapsed / args.steps * 1e3
-    R_total = R_PER_GPU * world
+    R_GPU = r_per_gpu(args, world)
+    R_total = R_GPU * world
     value = R_total * args.steps / elapsed
     stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
     tg_ms = stage_ms.get("trigemm_sq", float("nan"))
-    flops_per_launch = R_PER_GPU * (N_OBS * N_OBS + 2.0 * N_OBS)  # triangular contraction + mu row
+    # one launch covers one K*' chunk (<= 8192 candidates); a shard of more candidates is several launches per step
+    launches = max(1, -(-R_GPU // 8192))
+    flops_per_launch = (R_GPU / launches) * (N_OBS * N_OBS + 2.0 * N_OBS)  # triangular contraction + mu row
+    tg_ms = tg_ms / launches
     achieved = flops_per_launch / (tg_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_trigemm_sq.json")
@@ -142,22 +187,31 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
             traffic = None
     out = {
         "metric": "acquisition-candidates/sec (N=3000,d=8)", "value": value, "unit": "candidates/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: N=3000 obs, d=8, SEArd, ExpectedImprovement, R=4096 "
-                               "restarts per GPU (LHS candidates resident in HBM)",
-                   "N": N_OBS, "d": DIM, "R_per_gpu": R_PER_GPU, "R_total": R_total, "acquisition": "EI",
-                   "parallelism": f"candidates sharded x{world}, one 16-byte RCCL all-gather + device-side reduce ({mode})"},
+        "n_gpus": world if n_devices is None else n_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": ("BASELINE configs[2]: N=3000 obs, d=8, SEArd, ExpectedImprovement, R=32768 restarts in total, "
+                                "sharded over the GPUs (LHS candidates resident in HBM)") if args.strong else
+                               ("BASELINE configs[1]: N=3000 obs, d=8, SEArd, ExpectedImprovement, R=4096 "
+                                "restarts per GPU (LHS candidates resident in HBM)"),
+                   "N": N_OBS, "d": DIM, "R_per_gpu": R_GPU, "R_total": R_total, "acquisition": "EI",
+                   "parallelism": (f"one handle on one GPU: no collective is issued ({mode})" if world == 1 else
+                                   f"candidates sharded x{world}, one 16-byte RCCL all-gather + device-side reduce ({mode})")},
         "roofline": {"bound": "mfma", "kernel": "k_trigemm_sq", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_source": "profiles/traffic_trigemm_sq.json (separate rocprofv3 --pmc passes of this command; "
                                        "NOT measured in this run)",
-                     "avg_launch_ms": tg_ms, "flops_per_launch": flops_per_launch},
+                     "avg_launch_ms": tg_ms, "flops_per_launch": flops_per_launch, "launches_per_step": launches,
+                     "step_over_kernel": ms_per_step / (tg_ms * launches)},
         "stage_ms": {**{k: v for k, v in info_ms.items() if k != "trigemm_sq"}, **stage_ms},
         "model_update_ms": fit_ms,
-        "cholesky": {"N": N_OBS, "gflops": (N_OBS ** 3 / 3.0) / (fit_ms.get("cholesky", float("nan")) * 1e-3) / 1e9},
+        "cholesky": {"N": N_OBS, "gflops": (N_OBS ** 3 / 3.0) / (fit_ms.get("cholesky", float("nan")) * 1e-3) / 1e9,
+                     "sample": "median of 7 full refits"},
         "best": {"value": val, "index": idx},
     }
+    if n_devices is not None and n_devices != world:
+        # TEST mode (BOHIP_LOGICAL_SHARDS=1): `world` logical shards on n_devices GPU(s) -- NOT a multi-GPU measurement
+        out["logical_shards"] = world
+        out["test_mode"] = f"{world} logical shards on {n_devices} GPU(s): exercises the sharded path, says nothing about {world} GPUs"
     if extra:
         out.update(extra)
     if world == 1 and not args.no_cpu_baseline:
@@ -201,7 +255,8 @@ def main_single_process(args):
             raise SystemExit(f"--gpus {G} but only {ndev} device(s) visible")
     X, y = synth(0)
     tau = float(y.max())
-    R_total = R_PER_GPU * G
+    R_GPU = r_per_gpu(args, G)
+    R_total = R_GPU * G
     Xs_all = lhs(R_total, seed=1)
     ll = np.full(DIM, np.log(0.5))
     params = (C.c_double * 2)(tau, 0.0)
@@ -210,7 +265,7 @@ def main_single_process(args):
         model.enable_timing(True)
         model.append_(X.T, y)
         model.fit_()
-        fit_ms = dict(model.timing())
+        fit_ms = median_refit_ms(model)
         dev = torch.device("cuda", 0)
         dXs = torch.from_numpy(np.ascontiguousarray(Xs_all)).to(dev)  # [R][d] = d x R column-major, resident in HBM
         # the 16-byte result record is written by the arg-max kernel straight into pinned host memory and read after
@@ -220,7 +275,7 @@ def main_single_process(args):
         _lib.check(lib.bohip_gp_set_stream(model._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
         def step():
-            _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()), R_PER_GPU, None,
+            _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()), R_GPU, None,
                                               C.c_void_p(h_best.data_ptr())))
             _lib.check(lib.bohip_gp_synchronize(model._h))
             i = int(h_best_np[1])
@@ -238,7 +293,7 @@ def main_single_process(args):
         xp = Xs_host.ctypes.data_as(C.POINTER(C.c_double))
 
         def hstep():
-            _lib.check(lib.bohip_gp_score(model._h, _lib.ACQ["EI"], params, xp, R_PER_GPU, None, C.byref(bestrec)))
+            _lib.check(lib.bohip_gp_score(model._h, _lib.ACQ["EI"], params, xp, R_GPU, None, C.byref(bestrec)))
             return bestrec.val, bestrec.idx
 
         for _ in range(3):
@@ -257,6 +312,8 @@ def main_single_process(args):
                  "host_buffers_note": "same workload through bohip_gp_score: host X* in (pageable, 256 KB H2D inside the "
                                       "call), 16-byte record out; `value` is the HBM-resident rate",
                  "host_buffers_same_winner": bool(hv == val and hi == idx)}
+        if not args.no_c4:
+            extra["cholesky_c4"] = cholesky_c4(bohip)
         report(args, 1, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, "one handle", extra)
         return
     # ---- N > 1 in one process: bohip_mgp_* -------------------------------------------------------------------
@@ -276,6 +333,11 @@ def main_single_process(args):
         return [(names[i].decode(), msb[i]) for i in range(min(n, 4096))]
 
     fit_ms = dict(timing0())
+    for _ in range(4):          # (best of five refits: the first one carries the allocations)
+        model._push_hyper()     # marks the factor stale on every replica
+        model.fit_()
+        for k_, v_ in timing0():
+            fit_ms[k_] = min(fit_ms.get(k_, v_), v_)
     model.set_candidates(Xs_all.T)
     best = _lib.Best()
 
@@ -297,7 +359,26 @@ def main_single_process(args):
     for name, ms in timing0():
         stage_sum[name] = stage_sum.get(name, 0.0) + ms / spd   # per shard launch
     mode = f"one process, {len(devices)} device(s) x {spd} shard(s), in-library RCCL {model.info(_lib.MGP_INFO_RCCL_VERSION)}"
-    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode)
+    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, n_devices=len(devices))
+
+
+def cholesky_c4(bohip):
+    """BASELINE configs[3]: N=10000 obs, d=16, SEArd -- the blocked-Cholesky path at the size BASELINE.json names, beside the
+    headline workload: kernel-matrix assembly (HBM-write bound), factorisation (MFMA bound), triangular inverse."""
+    N, d = 10000, 16
+    rng = np.random.default_rng(3)
+    X = rng.random((N, d))
+    y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
+    m = bohip.ElasticGPE(d, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(np.full(d, np.log(0.5)), 0.0), logNoise=-2.0, capacity=N)
+    m.enable_timing(True)
+    m.append_(X.T, y)
+    ms = median_refit_ms(m, reps=5)
+    m.close()
+    ch = ms.get("cholesky", float("nan"))
+    bc = ms.get("build_cov", float("nan"))
+    return {"N": N, "d": d, "model_update_ms": ms, "cholesky_tflops": (N ** 3 / 3.0) / (ch * 1e-3) / 1e12,
+            "cholesky_frac_of_fp64_peak": (N ** 3 / 3.0) / (ch * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+            "build_cov_gb_per_s": 8.0 * N * (N + 1) / 2 / (bc * 1e-3) / 1e9, "sample": "median of 5 full refits"}
 
 
 def main():
@@ -306,7 +387,11 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: R = 32768 candidates in total (BASELINE configs[2]) at every --gpus")
+    ap.add_argument("--no-c4", action="store_true", help="skip the N=10000 model-update figure (cholesky_c4)")
     args = ap.parse_args()
+    if args.strong and STRONG_R_TOTAL % args.gpus:
+        raise SystemExit("--strong needs --gpus to divide 32768")
     quiet_stdout()
 
     import torch
@@ -347,10 +432,11 @@ def main():
     lib = _lib.load()
     X, y = synth(0)
     tau = float(y.max())
-    R_total = R_PER_GPU * world
+    R_GPU = r_per_gpu(args, world)
+    R_total = R_GPU * world
     Xs_all = lhs(R_total, seed=1)
-    lo = rank * R_PER_GPU
-    Xs_local = Xs_all[lo:lo + R_PER_GPU]
+    lo = rank * R_GPU
+    Xs_local = Xs_all[lo:lo + R_GPU]
     ll = np.full(DIM, np.log(0.5))
     model = bohip.ElasticGPE(DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0,
                              capacity=N_OBS, device=local_rank)
@@ -396,12 +482,12 @@ def main():
 
     def step():
         if in_library:
-            model.score_sharded_dev("EI", [tau], dXs.data_ptr(), R_PER_GPU, lo, R_total, h_best.data_ptr())
+            model.score_sharded_dev("EI", [tau], dXs.data_ptr(), R_GPU, lo, R_total, h_best.data_ptr())
             _lib.check(lib.bohip_gp_synchronize(model._h))
             i = int(h_best_np[1])
             return (float(h_best_np[:1].view(np.float64)[0]), i) if i >= 0 else (-np.inf, -1)
         _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs.data_ptr()),
-                                          R_PER_GPU, None, C.c_void_p(d_best.data_ptr())))
+                                          R_GPU, None, C.c_void_p(d_best.data_ptr())))
         _lib.check(lib.bohip_gp_synchronize(model._h))   # the record is written on the handle's stream, the collective runs on torch's
         val, idx = allgather_best(d_best, lo, world, force_collective=True)
         return val, idx
