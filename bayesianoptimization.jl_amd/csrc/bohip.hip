@@ -22,6 +22,7 @@
 #include "kernels_ascent.hip"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -94,6 +95,7 @@ struct bohip_gp {
     unsigned* dfz_cnt = nullptr;   // fused finish of k_trigemm_sq: [tiles] arrivals per candidate tile + [1] finished tiles (kept at zero)
     Best* dfz_best = nullptr;      // [tiles] per-tile arg-max records
     int64_t fz_cap = 0;
+    bool fz_dirty = false;         // a fused call failed between its launches: clear the counters before the next one
     double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
     double asc_maxtime = 0.0;    // bohip_gp_set_maxtime: wall-clock budget of one acquire_max call in seconds (NLopt maxtime), 0 = none
     int64_t batch_hint = 0;      // bohip_gp_set_batch_hint: choose the scoring path as if the batch had at least this many candidates
@@ -126,6 +128,14 @@ struct bohip_gp {
     int64_t crec_cap = 0;
     // bookkeeping
     int64_t pivot = 0, refits = 0, appends = 0;
+    int chol_form_last = 0;            // BOHIP_INFO_CHOL_FORM: 0 launch chain, 1 dataflow form 1, 2 form 2, 3 form 2 left-looking, 4 executor
+    int64_t chol_fallbacks = 0;        // BOHIP_INFO_CHOL_FALLBACKS: refits of this handle that timed out on a dependency and were redone launch-chained
+    int chol_abort_T = 0;              // BOHIP_INFO_CHOL_ABORT_TILES: row tiles of the last factorisation that timed out (0: never)
+    // jitter escalation on a failed factorisation (GaussianProcesses.jl make_posdef!, UPSTREAM-UNVERIFIED: off by default)
+    double jitter_rel = 0.0;           // first jitter = jitter_rel x mean(diag cK), x10 per further try
+    int jitter_tries = 0;              // 0 = report BOHIP_E_NOTPD at once (the default)
+    int jitter_steps_last = 0;         // BOHIP_INFO_JITTER_STEPS: tries the last refit needed (0: none)
+    double jitter_last = 0.0;          // what it added to the diagonal
     int q_tiles = 0;  // number of q_part rows the last posterior pass produced (T, or 1 on the small-batch path)
     bool timing = false;
     bool t_open = false;
@@ -157,6 +167,11 @@ static void t_begin(bohip_gp* g, const char* name) {
     if (!g->timing) return;
     g->t_open = !t_skip(g, name);
     if (!g->t_open) return;
+    if (g->timing_accumulate && g->tused >= 8192) {   // nobody reads them: keep the newest (mode 3 piles pairs up until get_timing)
+        std::rotate(g->tpool.begin(), g->tpool.begin() + 4096, g->tpool.begin() + g->tused);
+        g->tlabel.erase(g->tlabel.begin(), g->tlabel.begin() + 4096);
+        g->tused -= 4096;
+    }
     if (g->tused == g->tpool.size()) {
         hipEvent_t a, b;
         hipEventCreate(&a);
@@ -262,6 +277,7 @@ static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <=
                             // vs 0.82 ms.  Far beyond that its one-tier K=128 bulk updates lose to the two-tier launch chain, below 3 there is
                             // nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every 2 <= T <= CHOL_DF_TCAP.
 static int g_chol_df_tmax = 96;   // = CHOL_DF_TCAP, N <= ~12200 (N=12000: 16.5 vs 18.5 ms for the launch chain)
+static std::atomic<int> g_chol_df_disabled{0};   // set when a dataflow factorisation timed out on a dependency: launch chain from then on (process-wide)
 static unsigned long long g_chol_spin_ticks = CH_SPIN_TICKS_DEFAULT;   // BOHIP_CHOL_SPIN_US: bound of every in-kernel wait of the dataflow forms
 static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_exec) from g_chol_exec_min row tiles on (BOHIP_CHOL_EXEC=0: the stream-based second form)
 static int g_chol_exec_min = 32;  // BOHIP_CHOL_EXEC_MIN: N=4000 2.42 vs 2.49 ms for the first dataflow form, N=5000 3.23 vs 3.75; below (N=3000) the first form wins (1.67 vs 1.78)
@@ -860,7 +876,36 @@ static int cholesky_exec(bohip_gp* g, int T) {
     return 0;
 }
 
+// multiprocessors of the current device (the dataflow forms need their persistent workgroups resident at the same time)
+static int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int& c = cus[dev & 63];
+    if (c == 0 && hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = 0;
+    return c;
+}
+static int refit_once(bohip_gp* g, double jitter);
+// Full rebuild.  A factorisation that fails (BOHIP_E_NOTPD) is reported as such unless jitter escalation was asked for
+// (bohip_gp_set_jitter / BOHIP_JITTER): then the diagonal gets jitter_rel x mean(diag) more, x10 per further try -- the shape
+// of GaussianProcesses.jl's make_posdef! (UPSTREAM-UNVERIFIED, hence off by default; oracle twin: oracle.py fit_with_jitter).
 static int refit(bohip_gp* g) {
+    g->jitter_steps_last = 0;
+    g->jitter_last = 0.0;
+    int rc = refit_once(g, 0.0);
+    if (rc != BOHIP_E_NOTPD || g->jitter_tries <= 0 || !(g->jitter_rel > 0.0)) return rc;
+    const double mean_diag = std::exp(2.0 * g->logsig) + std::exp(2.0 * g->lognoise);   // stationary kernels: every diagonal entry
+    double jit = g->jitter_rel * mean_diag;
+    for (int t = 1; t <= g->jitter_tries; ++t, jit *= 10.0) {
+        rc = refit_once(g, jit);
+        if (rc != BOHIP_E_NOTPD) {
+            if (rc == 0) { g->jitter_steps_last = t; g->jitter_last = jit; }
+            return rc;
+        }
+    }
+    return rc;
+}
+static int refit_once(bohip_gp* g, double jitter) {
     CHK(one_time_kernel_setup());
     const int64_t N = g->n;
     if (N == 0) {
@@ -871,7 +916,7 @@ static int refit(bohip_gp* g) {
     const int64_t Npad = round_up(N + 1, TILE), ld = g->ld;
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
-    const double noise = std::exp(2.0 * g->lognoise) + std::numeric_limits<double>::epsilon();
+    const double noise = std::exp(2.0 * g->lognoise) + std::numeric_limits<double>::epsilon() + jitter;
     HIPCHK(hipMemsetAsync(g->dinfo, 0, sizeof(int), g->stream));
     t_begin(g, "build_cov");
     {
@@ -885,11 +930,20 @@ static int refit(bohip_gp* g) {
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "cholesky");
-    if ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP)) {
-        if (g_chol_exec && T >= std::max(4, g_chol_exec_min)) CHK(cholesky_exec(g, T));
-        else if (T >= g_chol_df2_min && g_chol_df2_ll) CHK(cholesky_dataflow3(g, T));
-        else if (T >= g_chol_df2_min) CHK(cholesky_dataflow2(g, T));
-        else CHK(cholesky_dataflow(g, T));
+    // Which form.  The dataflow forms make progress only while their persistent workgroups are resident TOGETHER, one per CU
+    // (the chain's fill the LDS): the chain's 8-9 (+ solve followers), form 1's T - 3 row followers and 2 (T - 3) column
+    // updaters.  On a device (or partition: CPX mode exposes 32 CUs) that cannot hold them the launch chain is used.
+    const int cus = device_cus();
+    const bool want_df = !g_chol_df_disabled.load(std::memory_order_relaxed) &&
+                         ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP));
+    const bool exec_ok = g_chol_exec && T >= std::max(4, g_chol_exec_min) && cus >= 9 + g_chol_nsf + 8;
+    const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
+    const bool form1_ok = cus >= 8 + 3 * std::max(0, T - 3) + 8;
+    if (want_df && (exec_ok || form2_ok || form1_ok)) {
+        if (exec_ok) { g->chol_form_last = 4; CHK(cholesky_exec(g, T)); }
+        else if (form2_ok && g_chol_df2_ll) { g->chol_form_last = 3; CHK(cholesky_dataflow3(g, T)); }
+        else if (form2_ok) { g->chol_form_last = 2; CHK(cholesky_dataflow2(g, T)); }
+        else { g->chol_form_last = 1; CHK(cholesky_dataflow(g, T)); }
         t_end(g);
         t_begin(g, "tri_inverse");
         if (!g->w_seeded) {
@@ -909,11 +963,14 @@ static int refit(bohip_gp* g) {
             // persistent workgroup off the chip): every wait has returned, nothing hangs; the factor -- and any pivot failure it
             // reports, hence this check BEFORE check_info -- is garbage.  Fall back to the launch-chained form for the rest of
             // the process (BOHIP_CHOL_DF_STRICT=1: report it instead, for tests and tools).
-            fprintf(stderr, "libbohip: dataflow factorisation timed out on a dependency; using the launch-chained form from now on\n");
+            g->chol_fallbacks++;
+            g->chol_abort_T = T;
+            fprintf(stderr, "libbohip: dataflow factorisation (form %d, %d row tiles) timed out on a dependency; using the launch-chained form from now on\n",
+                    g->chol_form_last, T);
             if (getenv("BOHIP_CHOL_DF_STRICT")) return fail(BOHIP_E_HIP, "dataflow factorisation timed out on a dependency (BOHIP_CHOL_DF_STRICT)");
-            g_chol_df = 0;
+            g_chol_df_disabled.store(1, std::memory_order_relaxed);
             g->stale = true;
-            return refit(g);
+            return refit_once(g, jitter);
         }
         CHK(check_info(g));
         g->stale = false;
@@ -921,6 +978,7 @@ static int refit(bohip_gp* g) {
         g->refits++;
         return 0;
     }
+    g->chol_form_last = 0;
     // Right-looking on 128-column panels, with the trailing update applied in two tiers: inside an outer block
     // of OB panels only the block's own remaining columns are updated after every panel (K = 128); everything to
     // the right of the outer block is updated ONCE per outer block with K = 128 * OB.  The C tiles of the bulk
@@ -1375,7 +1433,14 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
         fz.tiles_total = (int)((R + CTILE - 1) / CTILE); fz.R_total = R;
         fz.sigma2 = std::exp(2.0 * g->logsig); fz.beta = g->beta; fz.ap = ap;
         fz.mu_out = d_mu; fz.var_out = d_var; fz.score_out = d_score; fz.best_out = d_best; fz.best_off = best_off;
-        return posterior_pass(g, dXs, R, fz);
+        // The fused finish counts arrivals in counters its last waves leave at zero.  If an earlier call failed between two of
+        // its launches they are not: every later call would then miss its "last arrival" and write no result.  So a call that
+        // did not enqueue all of its launches marks the counters dirty, and the next one clears them first.
+        if (g->fz_dirty) HIPCHK(hipMemsetAsync(g->dfz_cnt, 0, (size_t)(g->fz_cap + 1 + 16) * sizeof(unsigned), g->stream));
+        g->fz_dirty = true;
+        const int rc = posterior_pass(g, dXs, R, fz);
+        if (rc == 0) g->fz_dirty = false;
+        return rc;
     } else {
         CHK(posterior_pass(g, dXs, R));
     }
@@ -1533,6 +1598,11 @@ int bohip_gp_create(int64_t d, int64_t capacity, int kernel_id, int device, bohi
     }
     int rc = alloc_model(g, capacity);
     if (rc != 0) { bohip_gp_destroy(g); return rc; }
+    if (const char* e = getenv("BOHIP_JITTER")) {   // "rel[,tries]": jitter escalation for every handle of the process (default: off)
+        double rel = 0.0;
+        int tries = 10;
+        if (sscanf(e, "%lf,%d", &rel, &tries) >= 1 && rel > 0.0) { g->jitter_rel = rel; g->jitter_tries = std::min(32, std::max(1, tries)); }
+    }
     *out = g;
     return 0;
 }
@@ -2081,12 +2151,22 @@ int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
         case BOHIP_INFO_CAPACITY: *value = g->cap; return 0;
         case BOHIP_INFO_REFITS: *value = g->refits; return 0;
         case BOHIP_INFO_APPENDS: *value = g->appends; return 0;
+        case BOHIP_INFO_CHOL_FORM: *value = g->chol_form_last; return 0;
+        case BOHIP_INFO_CHOL_FALLBACKS: *value = g->chol_fallbacks; return 0;
+        case BOHIP_INFO_CHOL_ABORT_TILES: *value = g->chol_abort_T; return 0;
+        case BOHIP_INFO_JITTER_STEPS: *value = g->jitter_steps_last; return 0;
         default: return fail(BOHIP_E_ARG, "unknown info id");
     }
 }
 int bohip_gp_set_batch_hint(bohip_gp* g, int64_t total_candidates) {
     if (!g || total_candidates < 0) return fail(BOHIP_E_ARG, "bad arguments");
     g->batch_hint = total_candidates;
+    return 0;
+}
+int bohip_gp_set_jitter(bohip_gp* g, double rel, int max_tries) {
+    if (!g || !(rel >= 0.0) || max_tries < 0 || max_tries > 32) return fail(BOHIP_E_ARG, "bad arguments");
+    g->jitter_rel = rel;
+    g->jitter_tries = rel > 0.0 ? max_tries : 0;
     return 0;
 }
 int bohip_gp_set_maxtime(bohip_gp* g, double seconds) {

@@ -214,9 +214,13 @@ static int mgp_exchange(bohip_mgp* m, int64_t S, Best* out) {
         HIPCHK(hipSetDevice(m->devs[i]));
         HIPCHK(hipStreamSynchronize(m->h[i]->stream));
     }
-    for (int i = 1; i < m->nd; ++i)
-        if (std::memcmp(m->hfinal, m->hfinal + (int64_t)i * S, (size_t)S * sizeof(Best)) != 0)
-            return fail(BOHIP_E_COMM, "devices disagree on the reduced arg-max records");
+    // every device reduced the same gathered records with the same kernel: its copy can only differ if the collective delivered
+    // different data to different ranks.  Checked on request (BOHIP_MGP_VERIFY=1, and in the tests), not on every step.
+    static const bool verify = getenv("BOHIP_MGP_VERIFY") != nullptr && atoi(getenv("BOHIP_MGP_VERIFY")) != 0;
+    if (verify)
+        for (int i = 1; i < m->nd; ++i)
+            if (std::memcmp(m->hfinal, m->hfinal + (int64_t)i * S, (size_t)S * sizeof(Best)) != 0)
+                return fail(BOHIP_E_COMM, "devices disagree on the reduced arg-max records");
     std::memcpy(out, m->hfinal, (size_t)S * sizeof(Best));
     m->exchanges++;
     return 0;
@@ -229,13 +233,20 @@ static int mgp_acq_params(int acq_id, const double* acq_params, AcqParams* ap) {
     return 0;
 }
 
+// batch_hint for the duration of a sharded call, restored on every exit path (an early error return used to leave the replica --
+// which callers can borrow through bohip_mgp_handle -- choosing its scoring path for a stale batch size)
+struct HintGuard {
+    bohip_gp* g;
+    HintGuard(bohip_gp* g_, int64_t R) : g(g_) { g->batch_hint = R; }
+    ~HintGuard() { g->batch_hint = 0; }
+};
 // score the shards of device i: candidates [lo_dev, hi_dev) are at dXs_dev (device pointer, d contiguous doubles each)
 static int mgp_score_device(bohip_mgp* m, int i, int acq_id, const double* acq_params, const double* dXs_dev, int64_t R,
                             bool want_scores) {
     bohip_gp* g = m->h[i];
     const int64_t G = (int64_t)m->nd * m->spd;
     const int64_t lo_dev = shard_lo(R, G, (int64_t)i * m->spd);
-    g->batch_hint = R;   // every shard takes the summation schedule of the whole set: G-device scores == 1-device scores bit for bit
+    HintGuard hint(g, R);   // every shard takes the summation schedule of the whole set: G-device scores == 1-device scores bit for bit
     for (int ls = 0; ls < m->spd; ++ls) {
         const int64_t s = (int64_t)i * m->spd + ls, lo = shard_lo(R, G, s), hi = shard_lo(R, G, s + 1);
         Best* rec = m->dsend[i] + ls;
@@ -247,7 +258,6 @@ static int mgp_score_device(bohip_mgp* m, int i, int acq_id, const double* acq_p
             HIPCHK(hipMemcpyAsync(rec, &none, sizeof(Best), hipMemcpyHostToDevice, g->stream));
         }
     }
-    g->batch_hint = 0;
     return 0;
 }
 
@@ -341,7 +351,28 @@ int bohip_mgp_set_hyper(bohip_mgp* m, const double* loglen, double logsig, doubl
 
 int bohip_mgp_append(bohip_mgp* m, const double* X, const double* y, int64_t p) {
     if (!m) return fail(BOHIP_E_ARG, "null handle");
-    return mgp_for_each(m, [&](int i) { return bohip_gp_append(m->h[i], X, y, p); });
+    std::vector<int64_t> n_old((size_t)m->nd);
+    for (int i = 0; i < m->nd; ++i) n_old[i] = m->h[i]->n;
+    const int rc = mgp_for_each(m, [&](int i) { return bohip_gp_append(m->h[i], X, y, p); });
+    if (rc != 0 && rc != BOHIP_E_NOTPD) {
+        // a replica failed (allocation, HIP error): the others may have taken the observations.  Roll every replica back to the
+        // common state before the call -- observations dropped, factor marked stale (rebuilt at the next use) -- so that the
+        // handle stays consistent; BOHIP_E_NOTPD is the same on every replica (same data, same arithmetic) and keeps the
+        // single-handle semantics: the observations stay, the factor is stale.
+        const std::string keep = g_err;
+        for (int i = 0; i < m->nd; ++i) {
+            bohip_gp* g = m->h[i];
+            if (g->n != n_old[i]) {
+                g->n = n_old[i];
+                g->hX.resize((size_t)g->n * g->d);
+                g->hy.resize((size_t)g->n);
+            }
+            g->stale = true;
+            g->n_factored = 0;
+        }
+        g_err = keep;
+    }
+    return rc;
 }
 
 int bohip_mgp_refit(bohip_mgp* m) {
@@ -426,7 +457,7 @@ int bohip_mgp_thompson(bohip_mgp* m, const double* Xs, int64_t R, int64_t S, uin
         CHK(ensure_xs(g, std::max<int64_t>(Rd, 1)));
         CHK(ensure_score_scratch(g, std::max<int64_t>(Rd, 1)));
         if (Rd > 0) HIPCHK(hipMemcpyAsync(g->dXs, Xs + lo_dev * g->d, (size_t)Rd * g->d * 8, hipMemcpyHostToDevice, g->stream));
-        g->batch_hint = R;
+        HintGuard hint(g, R);
         for (int ls = 0; ls < m->spd; ++ls) {
             const int64_t s = (int64_t)i * m->spd + ls, lo = shard_lo(R, G, s), hi = shard_lo(R, G, s + 1);
             Best* rec = m->dsend[i] + (int64_t)ls * S;
@@ -437,7 +468,6 @@ int bohip_mgp_thompson(bohip_mgp* m, const double* Xs, int64_t R, int64_t S, uin
                                (long long)lo);
             HIPCHK(hipGetLastError());
         }
-        g->batch_hint = 0;
         return 0;
     }));
     return mgp_exchange(m, S, reinterpret_cast<Best*>(best));
@@ -462,12 +492,11 @@ int bohip_mgp_acquire_max(bohip_mgp* m, int acq_id, const double* acq_params, co
         bohip_gp* g = m->h[i];
         const int64_t lo = shard_lo(R, G, (int64_t)i * m->spd), hi = shard_lo(R, G, (int64_t)(i + 1) * m->spd), Rd = hi - lo;
         bohip_best b{-INFINITY, -1};
-        g->batch_hint = R;
+        HintGuard hint(g, R);
         const int rc = Rd > 0 ? bohip_gp_acquire_max(g, acq_id, acq_params, lowerbounds, upperbounds, starts + lo * d, Rd, maxeval,
                                                      ftol_rel, xtol_abs, x_out ? x_out + lo * d : nullptr,
                                                      f_out ? f_out + lo : nullptr, &b, bx.data() + (size_t)i * d, &ev[i])
                               : 0;
-        g->batch_hint = 0;
         if (rc != 0) return rc;
         rec[i].val = b.val;
         rec[i].idx = b.idx >= 0 ? b.idx + lo : -1;
@@ -491,6 +520,16 @@ int bohip_mgp_acquire_max(bohip_mgp* m, int acq_id, const double* acq_params, co
     return 0;
 }
 
+int bohip_mgp_set_maxtime(bohip_mgp* m, double seconds) {
+    if (!m) return fail(BOHIP_E_ARG, "null handle");
+    for (int i = 0; i < m->nd; ++i) CHK(bohip_gp_set_maxtime(m->h[i], seconds));
+    return 0;
+}
+int bohip_mgp_set_jitter(bohip_mgp* m, double rel, int max_tries) {
+    if (!m) return fail(BOHIP_E_ARG, "null handle");
+    for (int i = 0; i < m->nd; ++i) CHK(bohip_gp_set_jitter(m->h[i], rel, max_tries));
+    return 0;
+}
 bohip_gp* bohip_mgp_handle(bohip_mgp* m, int i) { return (m && i >= 0 && i < m->nd) ? m->h[i] : nullptr; }
 
 int bohip_mgp_info(const bohip_mgp* m, int what, int64_t* value) {

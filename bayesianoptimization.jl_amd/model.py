@@ -219,6 +219,12 @@ class ElasticGPE:
         """NLopt's maxtime for the device ascent (0 = unlimited)."""
         check(self._lib.bohip_gp_set_maxtime(self._h, float(seconds)))
 
+    def set_jitter(self, rel, max_tries=10):
+        """Jitter escalation on a failed factorisation (the role of GaussianProcesses.jl's make_posdef! behind update!,
+        src/models/gp.jl:11,16 -- UPSTREAM-UNVERIFIED, off by default): a refit that fails is repeated with
+        rel x mean(diag cK) more on the diagonal, x10 per further try; info(INFO_JITTER_STEPS) tells how many it took."""
+        check(self._lib.bohip_gp_set_jitter(self._h, float(rel), int(max_tries)))
+
     def ascend(self, acq, params, lowerbounds, upperbounds, starts, maxeval=2000, ftol_rel=1e-10, xtol_abs=1e-10):
         """Local search of acquire_max on the device (src/acquisition.jl:48-68 with :LD_LBFGS and bounds): every start
         column is refined by a projected L-BFGS ascent, all columns in lock step.  Returns

@@ -118,6 +118,14 @@ class MultiGPE:
         check(self._lib.bohip_mgp_thompson(self._h, _ptr(xs), xs.shape[1], S, seed, out))
         return np.array([b.val for b in out]), np.array([b.idx for b in out], dtype=np.int64)
 
+    def set_maxtime(self, seconds):
+        """NLopt's maxtime for the device ascent, on every replica (0 = unlimited)."""
+        check(self._lib.bohip_mgp_set_maxtime(self._h, float(seconds)))
+
+    def set_jitter(self, rel, max_tries=10):
+        """see ElasticGPE.set_jitter; applied to every replica"""
+        check(self._lib.bohip_mgp_set_jitter(self._h, float(rel), int(max_tries)))
+
     def ascend(self, acq, params, lowerbounds, upperbounds, starts, maxeval=2000, ftol_rel=1e-10, xtol_abs=1e-10):
         starts = _cols(starts, self.dim)
         R = starts.shape[1]

@@ -129,6 +129,12 @@ int bohip_gp_acquire_max(bohip_gp *gp, int acq_id, const double *acq_params, con
 /* NLopt's maxtime option (forwarded by the reference at src/acquisition.jl:24-27): wall-clock budget in seconds of ONE
  * bohip_gp_acquire_max call, checked once per ascent iteration; 0 (default) = unlimited.                          */
 int bohip_gp_set_maxtime(bohip_gp *gp, double seconds);
+/* Jitter escalation when the factorisation fails (the role of GaussianProcesses.jl's make_posdef! behind update!/fit!,
+ * src/models/gp.jl:11,16 -- UPSTREAM-UNVERIFIED, so OFF by default and BOHIP_E_NOTPD reports the failing pivot): with
+ * max_tries > 0 a failed refit is repeated with rel x mean(diag cK) added to the diagonal, x10 per further try.
+ * BOHIP_INFO_JITTER_STEPS tells how many tries the last refit needed.  Env BOHIP_JITTER="rel[,tries]" sets it for every
+ * handle of the process.                                                                                          */
+int bohip_gp_set_jitter(bohip_gp *gp, double rel, int max_tries);
 
 /* ---- ThompsonSamplingSimple (reference src/acquisitionfunctions.jl:107-108, myrand
  * src/models/gp.jl:6-7) in its batched form: S independent draws mu_j + sigma_j z_sj over the R
@@ -158,6 +164,10 @@ int bohip_gp_get_alpha(bohip_gp *gp, double *alpha);
 #define BOHIP_INFO_CAPACITY 1     /* current observation capacity                                */
 #define BOHIP_INFO_REFITS 2       /* number of full refits so far                                */
 #define BOHIP_INFO_APPENDS 3      /* number of incremental factor extensions so far              */
+#define BOHIP_INFO_CHOL_FORM 4    /* factorisation form of the last refit: 0 launch chain, 1-3 dataflow forms, 4 executor */
+#define BOHIP_INFO_CHOL_FALLBACKS 5   /* refits of this handle that timed out on a dependency and were redone launch-chained */
+#define BOHIP_INFO_CHOL_ABORT_TILES 6 /* row tiles of the last factorisation that timed out (0: never)  */
+#define BOHIP_INFO_JITTER_STEPS 7 /* jitter tries the last refit needed (0: none; see bohip_gp_set_jitter) */
 int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
 /* Sharded scoring: candidates are scored by one of three summation schedules chosen by batch size
  * (row-wise, split-K, whole-K MFMA jobs); they agree to ~1e-11 relative but not bit for bit.  A rank that scores a
@@ -208,6 +218,9 @@ int bohip_mgp_acquire_max(bohip_mgp *mgp, int acq_id, const double *acq_params, 
                           const double *upperbounds, const double *starts, int64_t R, int64_t maxeval, double ftol_rel,
                           double xtol_abs, double *x_out, double *f_out, bohip_best *best, double *best_x,
                           int64_t *evals_out);
+/* the per-handle options of bohip_gp_set_maxtime / bohip_gp_set_jitter, applied to every replica */
+int bohip_mgp_set_maxtime(bohip_mgp *mgp, double seconds);
+int bohip_mgp_set_jitter(bohip_mgp *mgp, double rel, int max_tries);
 bohip_gp *bohip_mgp_handle(bohip_mgp *mgp, int i); /* replica on the i-th listed device (borrowed, for dims/maxy/get_xy/mll...) */
 #define BOHIP_MGP_INFO_DEVICES 0
 #define BOHIP_MGP_INFO_SHARDS 1

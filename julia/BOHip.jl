@@ -70,6 +70,7 @@ c_gp_score(h, acq, p, Xs, R, sc, best) = ccall((:bohip_gp_score, libbohip), Cint
 c_gp_score_grad(h, acq, p, Xs, R, sc, g) = ccall((:bohip_gp_score_grad, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}), h, acq, p, Xs, R, sc, g)
 c_gp_acquire_max(h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev) = ccall((:bohip_gp_acquire_max, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Best}, Ptr{Float64}, Ptr{Int64}), h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev)
 c_gp_set_maxtime(h, s) = ccall((:bohip_gp_set_maxtime, libbohip), Cint, (Ptr{Cvoid}, Float64), h, s)
+c_gp_set_jitter(h, rel, tries) = ccall((:bohip_gp_set_jitter, libbohip), Cint, (Ptr{Cvoid}, Float64, Cint), h, rel, tries)
 c_gp_thompson(h, Xs, R, S, seed, j0, best) = ccall((:bohip_gp_thompson, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, UInt64, Int64, Ptr{Best}), h, Xs, R, S, seed, j0, best)
 c_thompson_normal(seed, s, j) = ccall((:bohip_thompson_normal, libbohip), Float64, (UInt64, Int64, Int64), seed, s, j)
 c_gp_score_dev(h, acq, p, dXs, R, dsc, dbest) = ccall((:bohip_gp_score_dev, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}), h, acq, p, dXs, R, dsc, dbest)
@@ -93,6 +94,8 @@ c_mgp_set_candidates(h, Xs, R) = ccall((:bohip_mgp_set_candidates, libbohip), Ci
 c_mgp_score_resident(h, acq, p, best) = ccall((:bohip_mgp_score_resident, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Best}), h, acq, p, best)
 c_mgp_thompson(h, Xs, R, S, seed, best) = ccall((:bohip_mgp_thompson, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, UInt64, Ptr{Best}), h, Xs, R, S, seed, best)
 c_mgp_acquire_max(h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev) = ccall((:bohip_mgp_acquire_max, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Best}, Ptr{Float64}, Ptr{Int64}), h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev)
+c_mgp_set_maxtime(h, s) = ccall((:bohip_mgp_set_maxtime, libbohip), Cint, (Ptr{Cvoid}, Float64), h, s)
+c_mgp_set_jitter(h, rel, tries) = ccall((:bohip_mgp_set_jitter, libbohip), Cint, (Ptr{Cvoid}, Float64, Cint), h, rel, tries)
 c_mgp_handle(h, i) = ccall((:bohip_mgp_handle, libbohip), Ptr{Cvoid}, (Ptr{Cvoid}, Cint), h, i)
 c_mgp_info(h, what, out) = ccall((:bohip_mgp_info, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), h, what, out)
 # multi-GPU, one process per device (Distributed.jl / MPI.jl carry the 128-byte id)
@@ -312,6 +315,7 @@ function acquire_max_device(a::AbstractAcquisition, m::AbstractBOHipModel, lower
         best = Ref(Best(-Inf, -1)); bx = Vector{Float64}(undef, m.dim); ev = Ref{Int64}(0)
         ftol = Float64(get(options, :ftol_rel, 1e-10)); xtol = Float64(get(options, :xtol_abs, 1e-10))
         m isa BOHipGPE && check(c_gp_set_maxtime(m.handle, Float64(get(options, :maxtime, 0.0))))
+        m isa BOHipMultiGPE && check(c_mgp_set_maxtime(m.handle, Float64(get(options, :maxtime, 0.0))))
         rc = m isa BOHipMultiGPE ?
              c_mgp_acquire_max(m.handle, acqid(a), acqparams(a), lb, ub, starts, size(starts, 2), options.maxeval, ftol, xtol,
                                C_NULL, C_NULL, best, bx, ev) :

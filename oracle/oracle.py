@@ -289,6 +289,27 @@ class NumpyGP:
         return mu, var
 
 
+def fit_with_jitter(orc, X, y, loglen, logsig, lognoise, beta, rel, max_tries=10, kern="SEArd"):
+    """Oracle twin of bohip_gp_set_jitter (the role of GaussianProcesses.jl's make_posdef! behind update!,
+    src/models/gp.jl:11,16 -- UPSTREAM-UNVERIFIED, which is why the device keeps it behind a switch that is off by default):
+    factorise; if a pivot fails, add rel x mean(diag cK) to the diagonal and try again, x10 per further try.
+    Returns (L, alpha, tries_used, jitter_added)."""
+    cK = orc.build_cK(X, loglen, logsig, lognoise, kern)
+    mean_diag = math.exp(2.0 * logsig) + math.exp(2.0 * lognoise)
+    jit, added = rel * mean_diag, 0.0
+    for t in range(max_tries + 1):
+        try:
+            A = cK if t == 0 else cK + added * np.eye(len(cK))
+            L = orc.cholesky(A)
+            return L, orc.alpha(L, y, beta), t, added
+        except np.linalg.LinAlgError:
+            if t == max_tries:
+                raise
+            added = jit
+            jit *= 10.0
+    raise AssertionError("unreachable")
+
+
 # ------------------------------------------------------------------------------------------
 # Candidate generator: latin_hypercube_sampling, src/utils.jl:101-120 (NumPy RNG instead of
 # Julia's global RNG -- the draws are not reproducible across languages, so candidates are an

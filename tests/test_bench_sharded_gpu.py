@@ -36,4 +36,11 @@ def test_two_ranks_sharing_one_gpu_match_single_rank():
     m = bohip.ElasticGPE(bench.DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0, capacity=bench.N_OBS)
     m.append_(X.T, y)
     _, bv, bi = m.score("EI", [float(y.max())], bench.lhs(8192, seed=1).T)
-    assert line["best"] == {"value": bv, "index": bi}
+    # two processes refit on ONE GPU at the same moment here: if one of them timed out on the dataflow factorisation (bounded
+    # waits, tests/test_hardening_gpu.py) it fell back to the launch-chained form, whose factor differs in the last bits
+    fell_back = "timed out on a dependency" in out.stderr
+    assert line["best"]["index"] == bi
+    if fell_back:
+        assert line["best"]["value"] == pytest.approx(bv, rel=1e-9)
+    else:
+        assert line["best"] == {"value": bv, "index": bi}

@@ -152,12 +152,19 @@ def test_bench_launches_the_way_the_driver_does(bohip):
     assert one["n_gpus"] == 1 and one["value_host_buffers"] > 0 and one["host_buffers_same_winner"] is True
     two = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                       "--no-cpu-baseline"], env={"BOHIP_LOGICAL_SHARDS": "1"})
-    assert two["n_gpus"] == 2 and two["config"]["R_total"] == 8192 and "in-library RCCL" in two["config"]["parallelism"]
+    # logical shards are a TEST mode and the line says so: n_gpus counts devices, the shard count has its own field
+    assert two["n_gpus"] == 1 and two["logical_shards"] == 2 and "test_mode" in two
+    assert two["config"]["R_total"] == 8192 and "in-library RCCL" in two["config"]["parallelism"]
+    assert "no collective" in one["config"]["parallelism"] and one["roofline"]["step_over_kernel"] >= 1.0
     assert 0 < two["roofline"]["frac"] < 1
     tr = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
                      "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
                      "--warmup", "1", "--no-cpu-baseline"])
     assert "bohip_gp_score_sharded_dev" in tr["config"]["parallelism"] and tr["best"] == one["best"]
+    strong = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--strong",
+                         "--no-cpu-baseline", "--no-c4"])
+    assert strong["scaling"] == "strong" and strong["config"]["R_total"] == 32768 and strong["roofline"]["launches_per_step"] == 4
+    assert "cholesky_c4" in one and one["cholesky_c4"]["N"] == 10000
     X, y = bench.synth(0)
     ll = np.full(bench.DIM, np.log(0.5))
     m = bohip.ElasticGPE(bench.DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0, capacity=bench.N_OBS)
@@ -166,3 +173,56 @@ def test_bench_launches_the_way_the_driver_does(bohip):
     assert two["best"] == {"value": bv, "index": bi}
     _, bv, bi = m.score("EI", [float(y.max())], bench.lhs(4096, seed=1).T)
     assert one["best"] == {"value": bv, "index": bi}
+
+
+def test_worker_threads_and_verified_exchange_on_one_device(bohip):
+    """The per-device worker threads are on by default only with more than one device, so the one-GPU tests above run the inline
+    branch of mgp_for_each.  BOHIP_MGP_THREADS=1 forces the threaded branch (one worker for the one device, 4 logical shards);
+    BOHIP_MGP_VERIFY=1 keeps the cross-copy check of the exchange on.  Same bits as one handle."""
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, bohip
+rng = np.random.default_rng(3)
+N, d, R = 700, 4, 3001
+X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N); Xs = rng.random((R, d))
+ll = np.full(d, -0.5)
+one = bohip.ElasticGPE(d, kernel=bohip.SEArd(ll, 0.1), logNoise=-2.0, capacity=N); one.append_(X.T, y)
+mg = bohip.MultiGPE(d, devices=(0,), shards_per_device=4, kernel=bohip.SEArd(ll, 0.1), logNoise=-2.0, capacity=N); mg.append_(X.T, y)
+tau = float(y.max())
+for acq, p in (("EI", [tau]), ("UCB", [2.0])):
+    s1, v1, i1 = one.score(acq, p, Xs.T); sg, vg, ig = mg.score(acq, p, Xs.T)
+    assert np.array_equal(s1, sg) and (v1, i1) == (vg, ig), acq
+v, i = one.thompson(Xs.T, 64, seed=9); vg, ig = mg.thompson(Xs.T, 64, seed=9)
+assert np.array_equal(v, vg) and np.array_equal(i, ig)
+mg.set_maxtime(5.0)
+f, Xa, bv, bi, bx, ev = mg.ascend("EI", [tau], np.zeros(d), np.ones(d), Xs[:24].T, maxeval=200)
+f1, X1, bv1, bi1, bx1, ev1 = one.ascend("EI", [tau], np.zeros(d), np.ones(d), Xs[:24].T, maxeval=200)
+assert bi == bi1 and abs(bv - bv1) <= 1e-9 * max(1.0, abs(bv1))
+print("THREADS-OK")
+""" % ROOT
+    o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BOHIP_MGP_THREADS="1", BOHIP_MGP_VERIFY="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert o.returncode == 0 and "THREADS-OK" in o.stdout, o.stderr[-3000:]
+
+
+def test_two_real_devices_if_present(bohip):
+    """devices = [0, 1]: worker thread per device, ncclCommInitAll over two ranks, the pinned result block both devices write.
+    SKIPPED on a one-GPU box (every gpurun box): until a node with more than one GPU has run this, the n_devices > 1 path of
+    csrc/multigpu.hip is UNVERIFIED on hardware (DESIGN.md section 9 says so)."""
+    from bohip import _lib
+
+    if _lib.load().bohip_device_count() < 2:
+        pytest.skip("one GPU visible: the n_devices > 1 path stays unverified on hardware")
+    X, y, Xs = synth(1200, 5, 4099, seed=4)
+    ll = np.linspace(-0.8, -0.3, 5)
+    one = make_model(bohip, X, y, ll, 0.1, -2.0, 0.05)
+    mg = make_multi(bohip, X, y, ll, 1, 0.1, -2.0, 0.05, devices=(0, 1))
+    tau = float(y.max())
+    for acq, p in [("EI", [tau]), ("UCB", [2.0])]:
+        sc1, bv1, bi1 = one.score(acq, p, Xs.T)
+        scg, bvg, big = mg.score(acq, p, Xs.T)
+        np.testing.assert_array_equal(scg, sc1)
+        assert (bvg, big) == (bv1, bi1)
+    mg.set_candidates(Xs.T)
+    assert mg.score_resident("EI", [tau]) == one.score("EI", [tau], Xs.T)[1:]
