@@ -277,7 +277,10 @@ static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <=
                             // vs 0.82 ms.  Far beyond that its one-tier K=128 bulk updates lose to the two-tier launch chain, below 3 there is
                             // nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every 2 <= T <= CHOL_DF_TCAP.
 static int g_chol_df_tmax = 96;   // = CHOL_DF_TCAP, N <= ~12200 (N=12000: 16.5 vs 18.5 ms for the launch chain)
-static std::atomic<int> g_chol_df_disabled{0};   // set when a dataflow factorisation timed out on a dependency: launch chain from then on (process-wide)
+// A dataflow factorisation that timed out on a dependency (another process holds the CUs, two streams share a hardware queue, ...)
+// switches the PROCESS to the launch chain -- for the next `skip` refits, not for good: the cause is usually transient, a
+// time-out costs one bounded wait (200 ms), and every further time-out doubles the pause (8, 24, 56, ... up to 1024 refits).
+static std::atomic<int> g_chol_df_skip{0}, g_chol_df_backoff{0};
 static unsigned long long g_chol_spin_ticks = CH_SPIN_TICKS_DEFAULT;   // BOHIP_CHOL_SPIN_US: bound of every in-kernel wait of the dataflow forms
 static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_exec) from g_chol_exec_min row tiles on (BOHIP_CHOL_EXEC=0: the stream-based second form)
 static int g_chol_exec_min = 32;  // BOHIP_CHOL_EXEC_MIN: N=4000 2.42 vs 2.49 ms for the first dataflow form, N=5000 3.23 vs 3.75; below (N=3000) the first form wins (1.67 vs 1.78)
@@ -934,7 +937,10 @@ static int refit_once(bohip_gp* g, double jitter) {
     // (the chain's fill the LDS): the chain's 8-9 (+ solve followers), form 1's T - 3 row followers and 2 (T - 3) column
     // updaters.  On a device (or partition: CPX mode exposes 32 CUs) that cannot hold them the launch chain is used.
     const int cus = device_cus();
-    const bool want_df = !g_chol_df_disabled.load(std::memory_order_relaxed) &&
+    bool paused = false;
+    for (int sk = g_chol_df_skip.load(std::memory_order_relaxed); sk > 0;)
+        if (g_chol_df_skip.compare_exchange_weak(sk, sk - 1, std::memory_order_relaxed)) { paused = true; break; }
+    const bool want_df = !paused &&
                          ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP));
     const bool exec_ok = g_chol_exec && T >= std::max(4, g_chol_exec_min) && cus >= 9 + g_chol_nsf + 8;
     const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
@@ -965,10 +971,14 @@ static int refit_once(bohip_gp* g, double jitter) {
             // the process (BOHIP_CHOL_DF_STRICT=1: report it instead, for tests and tools).
             g->chol_fallbacks++;
             g->chol_abort_T = T;
-            fprintf(stderr, "libbohip: dataflow factorisation (form %d, %d row tiles) timed out on a dependency; using the launch-chained form from now on\n",
+            fprintf(stderr, "libbohip: dataflow factorisation (form %d, %d row tiles) timed out on a dependency; using the launch-chained form for a while\n",
                     g->chol_form_last, T);
             if (getenv("BOHIP_CHOL_DF_STRICT")) return fail(BOHIP_E_HIP, "dataflow factorisation timed out on a dependency (BOHIP_CHOL_DF_STRICT)");
-            g_chol_df_disabled.store(1, std::memory_order_relaxed);
+            {
+                const int bo = std::min(1024, 2 * g_chol_df_backoff.load(std::memory_order_relaxed) + 8);
+                g_chol_df_backoff.store(bo, std::memory_order_relaxed);
+                g_chol_df_skip.store(bo + 1, std::memory_order_relaxed);   // (+1: the repeat of this very refit)
+            }
             g->stale = true;
             return refit_once(g, jitter);
         }
