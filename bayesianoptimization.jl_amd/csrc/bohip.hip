@@ -82,7 +82,7 @@ struct bohip_gp {
     bool w_seeded = false;                        // the diagonal blocks of W were produced during the factorisation (k_chol_inverter)
     ExTask* dex_tasks = nullptr;                  // task records of the executor form (kernels_exec.hip), built once per (buffers, T)
     size_t ex_cap = 0;
-    int ex_T = 0, ex_nsf = 0, ex_qbeg[EX_NQ + 1] = {0, 0, 0, 0};
+    int ex_T = 0, ex_nsf = 0, ex_qbeg[EX_NQ + 1] = {0, 0, 0, 0, 0};
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
@@ -285,6 +285,8 @@ static unsigned long long g_chol_spin_ticks = CH_SPIN_TICKS_DEFAULT;   // BOHIP_
 static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_exec) from g_chol_exec_min row tiles on (BOHIP_CHOL_EXEC=0: the stream-based second form)
 static int g_chol_exec_min = 32;  // BOHIP_CHOL_EXEC_MIN: N=4000 2.42 vs 2.49 ms for the first dataflow form, N=5000 3.23 vs 3.75; below (N=3000) the first form wins (1.67 vs 1.78)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
+static int g_chol_exec_urgent = 24; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
+static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
 static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
@@ -328,6 +330,8 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_EXEC")) g_chol_exec = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_MIN")) g_chol_exec_min = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_PAIRS")) g_chol_exec_pairs = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL")) g_chol_exec_fill = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_URGENT")) g_chol_exec_urgent = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(CH_NSF_MAX, std::max(1, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
@@ -418,7 +422,7 @@ static int inverse_join(bohip_gp* g, hipStream_t st, int P, int nb) {
 // ---- A2, dataflow form (kernels_chol.hip): ONE persistent chain launch on the critical stream; the panel followers and the
 // flag-gated trailing updates of every block are enqueued up front on the side stream.  No host events inside the factorisation.
 static size_t chol_abort_word(int T) { return (size_t)T * (CH_PANELS + 7) + (size_t)T * T * (CH_PANELS + 1); }   // see the layout in cholesky_dataflow
-static size_t chol_flag_words(int T) { return chol_abort_word(T) + 4; }
+static size_t chol_flag_words(int T) { return chol_abort_word(T) + 8; }   // abort word + the executor's queue cursors
 static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T);
 static CholFlags chol_flags_layout(bohip_gp* g, int T) { return chol_flags_layout_at(g->dchol_flags, g->dchol_idl, T); }
 static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T) {
@@ -721,7 +725,7 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
 // then resident.  Layout of the counters inside the flag area (all zeroed per factorisation):
 //   tile (i, c), i >= c+2:  ver = xp[((c-1) T + i) 8 + 0], pver = xp[.. + 1]   (the chain uses xp[(k T + i) 8 + p] for i = k+1, k+2 only)
 //   tile (c+1, c):          ver = farall[c], pver = fol[c];      tile (c, c):  ver = colall[c], pver = col[c]
-//   sver(i, k) = colr[k T + i];   queue cursors = the three words behind the abort word
+//   sver(i, k) = colr[k T + i];   queue cursors = the four words behind the abort word
 static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_base, int64_t ld, int T, int CH_NSF, std::vector<ExTask>& all, int* qbeg) {
     const CholFlags fl = chol_flags_layout_at(flag_base, nullptr, T);
     auto widx = [&](const unsigned* p) { return (uint32_t)(p - flag_base); };
@@ -755,7 +759,7 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
                 t.dep_idx[nd] = d.idx; t.dep_want[nd] = d.want; ++nd;
             }
             t.sig_idx[0] = s0; t.sig_idx[1] = s1;
-            t.kc = h == 0 ? kc_h0 : kc_h1; t.diag_h = diag ? h : -1; t.rmw = rmw; t.prio = qi == 0 ? 2 : (qi == 1 ? 1 : 0);
+            t.kc = h == 0 ? kc_h0 : kc_h1; t.diag_h = diag ? h : -1; t.rmw = rmw; t.prio = qi <= 1 ? 2 : (qi == 2 ? 1 : 0);
             t.kc_split = kc_split;
             t.dep2_idx[0] = d2a.idx; t.dep2_want[0] = d2a.want; t.dep2_idx[1] = d2b.idx; t.dep2_want[1] = d2b.want;
             q[qi].push_back(t);
@@ -767,7 +771,7 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
         const double* Wkk = dW + (int64_t)k * TILE * (ld + 1);
         auto solve_rows = [&]() {   // (the rows k+3 .. k+2+CH_NSF are solved panel by panel inside the chain kernel: solve_follower)
             for (int i = k + 3 + CH_NSF; i < T; ++i)
-                add(0, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
+                add(1, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
                     {{widx(fl.solved + k), 1u}, {k >= 1 ? ver(i, k) : EX_NONE, 16u * (unsigned)(nb(k) + 1)}}, sver(i, k), EX_NONE);
         };
         // Late(k): blocks max(k-1, 0) .. k into the tiles read next; the three tiles of row k+3 (what the chain waits for) first
@@ -794,7 +798,7 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
             } else {
                 b0 = {sver(c, k), 16u};
             }
-            add(0, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
+            add(i < k + 3 + CH_NSF ? 0 : 1, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
                 {{sver(i, k), 16u}, b0, b1, p_dep, v_dep}, ver(i, c), i == k + 3 ? widx(fl.rest + k) : EX_NONE);
         };
         // the three tiles the chain waits for come FIRST: they are claimed while block k is still being factored (their first
@@ -810,8 +814,8 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
         // Early(kp): P(i, c) = sum_{b = ks(c)}^{kp} S(i, b) S(c, b)'  for the tiles Late(kp + 2) finishes
         auto early = [&](int i, int c) {
             if (i >= T || c >= T || ks(c) > kp) return;
-            add(1, Sp(i, ks(c)), Sp(c, ks(c)), const_cast<double*>(Pp(i, c)), nullptr, (kp - ks(c) + 1) * CPB, (kp - ks(c) + 1) * CPB, i == c, 0,
-                {{sver(i, kp), 16u}, {sver(c, kp), 16u}}, pver(i, c), EX_NONE);
+            add(2, Sp(i, ks(c)), Sp(c, ks(c)), const_cast<double*>(Pp(i, c)), nullptr, (kp - ks(c) + 1) * CPB,
+                (kp - ks(c) + 1) * CPB, i == c, 0, {{sver(i, kp), 16u}, {sver(c, kp), 16u}}, pver(i, c), EX_NONE);
         };
         early(kp + 5, kp + 3);
         early(kp + 5, kp + 4);
@@ -821,7 +825,7 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
     for (int m = 0; 4 * m + 8 <= T - 1; ++m)
         for (int c = 4 * m + 8; c < T; ++c)
             for (int i = c; i < T; ++i)
-                add(2, Sp(i, 4 * m), Sp(c, 4 * m), Ap(i, c), nullptr, 4 * CPB, 4 * CPB, i == c, 1,
+                add(3, Sp(i, 4 * m), Sp(c, 4 * m), Ap(i, c), nullptr, 4 * CPB, 4 * CPB, i == c, 1,
                     {{sver(i, 4 * m + 3), 16u}, {sver(c, 4 * m + 3), 16u}, {ver(i, c), 16u * (unsigned)m}}, ver(i, c), EX_NONE);
     all.clear();
     qbeg[0] = 0;
@@ -866,7 +870,9 @@ static int cholesky_exec(bohip_gp* g, int T) {
         q.heads = q.abort + 1;
         q.ld = ld;
         q.spin_ticks = g_chol_spin_ticks;
-        q.stride[0] = 1; q.stride[1] = g_chol_exec_pairs ? 2 : 1; q.stride[2] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
+        q.fill = g_chol_exec_fill;
+        q.nurgent = std::min(g_chol_exec_wgs / 2, g_chol_exec_urgent);
+        q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[3] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
         HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
         hipLaunchKernelGGL(k_chol_exec, dim3(g_chol_exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
         HIPCHK(hipGetLastError());
@@ -2212,7 +2218,7 @@ int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {
 extern "C" {
 // test hook (tests/test_exec_tasks.py): the executor's task records for T row tiles with the three matrices at the fake
 // addresses base_L/S/W (bytes) and flag word 0 at index 0 -- the CPU test replays them against a model of the chain.
-// out: n x 16 uint64 words (the 128-byte records); returns the number of records, qbeg[0..3] the queue boundaries,
+// out: n x 16 uint64 words (the 128-byte records); returns the number of records, qbeg[0..4] the queue boundaries,
 // layout[0..9] the word offsets of panel, solved, crit, rest, col, farall, fol, colall, colr, xp inside the flag area;
 // layout[10] the number of solve-follower workgroups of the chain kernel (CH_NSF).
 int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base_S, uint64_t base_W, uint64_t* out, int64_t cap,

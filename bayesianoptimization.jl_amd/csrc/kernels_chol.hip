@@ -751,11 +751,12 @@ __device__ __forceinline__ void solve_follower(const double* __restrict__ Lmat, 
             if (tid == 0) flag_wait_ge(fl.xp + ((size_t)(k - 1) * T + r) * CH_PANELS, 16u * (unsigned)(nb + 1), fl.abort, fl.spin_ticks);
             __syncthreads();
         }
+        if (tid == 0 && f < 4) CH_MARK(7168 + 256 * f + k);
         load_row_piece(Lmat, ld, r, k, ar);
         follow_block<false, 0>(Lmat, ld, S, r, k, fl, sm, ar, dd, nullptr);
         release_wg();
         __syncthreads();
-        if (tid == 0) { flag_set(fl.colr + (size_t)k * T + r, 16u); if (f == 0) CH_MARK(4608 + k); }   // sver(r, k)
+        if (tid == 0) { flag_set(fl.colr + (size_t)k * T + r, 16u); if (f == 0) CH_MARK(4608 + k); if (f < 4) CH_MARK(6144 + 256 * f + k); }   // sver(r, k)
     }
 }
 

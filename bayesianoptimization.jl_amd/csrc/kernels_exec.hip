@@ -9,17 +9,20 @@
 //
 // Here everything outside the chain is a TASK = one 128 x 64 half tile  C = beta C + alpha A B' (- P)  on the contraction engine
 // of gemm_core.h, described by an immutable 128-byte record the host writes once per (handle, T).  ONE persistent kernel
-// (k_chol_exec, 512 workgroups = two per CU) executes them: a workgroup that is free looks at the heads of three in-order
+// (k_chol_exec, 512 workgroups = two per CU) executes them: a workgroup that is free looks at the heads of four in-order
 // queues, highest priority first, CLAIMS the first head whose dependencies are met (compare-and-swap on the queue cursor)
 // and runs it.  Nobody ever holds a task it cannot run, so no workgroup slot is spent spinning, no launch boundary and no host
 // event sits between dependent tasks, and progress does not depend on how many executor workgroups are resident.
 //
-//   queue 0  per block k:  Solve(i, k) = A(i, k) W_kk'  for the rows i >= k+3 (W_kk: the chain's inverter workgroup), then
-//            Late(k): the tiles the chain and Solve(k+1) read next -- (k+3, k+2), (k+3, k+3) and column k+1 (rows >= k+3) --
-//            receive the blocks k-1 and k (K = 256) and the pre-summed older blocks P of the current window
-//   queue 1  Early(k): P(i, c) = sum over the window's blocks up to k of S(i, b) S(c, b)' for the tiles Late(k+2) will finish
+//   queue 0  URGENT, per block k: Late(k) of the tiles the chain kernel itself reads next -- (k+3, k+1), (k+3, k+2), (k+3, k+3), which
+//            its followers and gated updates wait for, and (k+4 .. k+2+nsf, k+1), which its solve followers read.  Their own
+//            queue: queued behind the far rows of the block before (which wait for that block's inverse and row solves) they
+//            were claimed 40-80 us late, and a follower that starts late never catches up
+//   queue 1  per block k:  Solve(i, k) = A(i, k) W_kk'  for the rows the chain does not solve itself (W_kk: the chain's inverter
+//            workgroup), then Late(k) of column k+1 for those rows: blocks k-1 and k (K = 256) and the pre-summed older blocks P
+//   queue 2  Early(k): P(i, c) = sum over the window's blocks up to k of S(i, b) S(c, b)' for the tiles Late(k+2) will finish
 //            (K = 128 .. 640; depends on S only, two blocks of slack) -- takes the long contraction off the critical path
-//   queue 2  bulk: group m (blocks 4m .. 4m+3, K = 512) applied to every tile of the columns >= 4m+8, column-major, so that
+//   queue 3  bulk: group m (blocks 4m .. 4m+3, K = 512) applied to every tile of the columns >= 4m+8, column-major, so that
 //            the four columns the chain reaches next are done first
 //
 // Dependencies are counters in the flag area (one word per producer granule, each finished task adds 8 = its waves):
@@ -38,7 +41,7 @@ namespace bohip {
 
 constexpr unsigned EX_NONE = 0xffffffffu;
 constexpr int EX_NDEP = 6;
-constexpr int EX_NQ = 3;
+constexpr int EX_NQ = 4;
 
 struct ExTask {                 // 128 bytes, written by the host once per (handle, T), never modified on the device
     const double* A;            // [128][16 kc]  K-major, row stride ld
@@ -67,6 +70,9 @@ struct ExQueues {
     unsigned* abort;
     int64_t ld;
     unsigned long long spin_ticks;   // a workgroup that finds no runnable task for this long gives up (see flag_wait_ge)
+    int nurgent;                // workgroups 0 .. nurgent-1 serve the urgent queue (and nothing else until it is exhausted)
+    int fill;                   // a workgroup that holds a claimed task whose counters are not in yet takes bulk work meanwhile:
+                                // 1 = if the held task is an Early sum (queue 2: two blocks of slack), 2 = also for queue 1, 0 = never
     int stride[EX_NQ];          // records per claim: 1, or 2 = both halves of a tile run back to back by one workgroup (the look and
                                 // claim between two tasks cost ~12 us against ~70 us of work: queues 1 and 2 are claimed in pairs)
 };
@@ -83,13 +89,21 @@ __device__ __forceinline__ bool ex_dep_pending(const ExTask* t, int d, const uns
     const uint32_t idx = t->dep_idx[d];
     return idx != EX_NONE && __hip_atomic_load(flags + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t->dep_want[d];
 }
-// wait until every counter of a claimed task has arrived (wave 0).  false: abort / time-out.
-// `ntile` tiles = 2 ntile consecutive records (the two halves of a tile share their counters): lane 8 j + d looks at tile j
+// are the counters of a claim (`ntile` tiles = 2 ntile consecutive records; the two halves of a tile share their counters) all in?
+// wave 0: lane 8 j + d looks at counter d of tile j
+__device__ __forceinline__ bool ex_ready_once(const ExQueues& q, const ExTask* t, int ntile, int lane) {
+    const bool p2 = (lane >> 3) < ntile && (lane & 7) < EX_NDEP && ex_dep_pending(t + 2 * (lane >> 3), lane & 7, q.flags);
+    return __ballot(p2) == 0ull;
+}
+__device__ __forceinline__ int ex_ntile(const ExQueues& q, int qi, unsigned c) {
+    const unsigned nq = (unsigned)(q.qbeg[qi + 1] - q.qbeg[qi]), st = (unsigned)q.stride[qi];
+    return st <= 2u ? 1 : (int)(((nq - c < st ? nq - c : st) + 1u) / 2u);
+}
+// wait until every counter of a claim has arrived (wave 0).  false: abort / time-out.
 __device__ __forceinline__ bool ex_wait_task(const ExQueues& q, const ExTask* t, int ntile, int lane) {
     const unsigned long long t0 = wall_clock64();
     for (;;) {
-        const bool p2 = (lane >> 3) < ntile && (lane & 7) < EX_NDEP && ex_dep_pending(t + 2 * (lane >> 3), lane & 7, q.flags);
-        if (__ballot(p2) == 0ull) return true;
+        if (ex_ready_once(q, t, ntile, lane)) return true;
         if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
         if (wall_clock64() - t0 > q.spin_ticks) {
             if (lane == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -98,20 +112,22 @@ __device__ __forceinline__ bool ex_wait_task(const ExQueues& q, const ExTask* t,
         __builtin_amdgcn_s_sleep(8);
     }
 }
-// claim from queue qi (its head was seen runnable): the task index, -1 on abort, -2 if the queue ran dry meanwhile
-__device__ __forceinline__ int ex_claim(const ExQueues& q, int qi, unsigned h_seen, int lane) {
+// Claim from queue qi (its head was seen runnable) with ONE fetch-and-add: the first record of the claim, or -2 if the queue ran dry
+// meanwhile.  Under contention the claimer gets a task a little behind the head it looked at; `ready` tells whether THAT task's
+// counters are in (looked at once, not waited for: see the caller).
+__device__ __forceinline__ int ex_claim(const ExQueues& q, int qi, unsigned h_seen, int lane, bool& ready) {
     unsigned c = 0;
     if (lane == 0) c = atomicAdd(q.heads + qi, (unsigned)q.stride[qi]);
     c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
-    const unsigned nq = (unsigned)(q.qbeg[qi + 1] - q.qbeg[qi]);
-    if (c >= nq) return -2;
-    // usually c is a task a little behind the head that was seen runnable: wait for ITS counters (and, when a claim covers
-    // several tiles, for those of every tile of the claim: the look only saw the first)
-    const int ntile = q.stride[qi] <= 2 ? 1 : (int)((nq - c < (unsigned)q.stride[qi] ? nq - c : (unsigned)q.stride[qi]) + 1u) / 2;
-    if ((c != h_seen || ntile > 1) && !ex_wait_task(q, q.tasks + q.qbeg[qi] + c, ntile, lane)) return -1;
+    if (c >= (unsigned)(q.qbeg[qi + 1] - q.qbeg[qi])) return -2;
+    const int ntile = ex_ntile(q, qi, c);
+    ready = (c == h_seen && ntile == 1) || ex_ready_once(q, q.tasks + q.qbeg[qi] + c, ntile, lane);
     return q.qbeg[qi] + (int)c;
 }
-__device__ __forceinline__ int ex_pick(const ExQueues& q, int lane) {
+// Look at the heads of the queues `qlo` .. `qhi` (lane 8 q + d: counter d of queue q's head record) and claim from the first one
+// whose head is runnable.  wait = true: stay until something could be claimed; -1 = every queue exhausted (or abort).
+// wait = false: one look; -3 = nothing runnable right now.
+__device__ __forceinline__ int ex_pick(const ExQueues& q, int lane, bool& ready, int qlo, int qhi, bool wait) {
     const int qi = lane >> 3, d = lane & 7;
     const unsigned long long t_idle = wall_clock64();
     int backoff = 1;
@@ -121,20 +137,21 @@ __device__ __forceinline__ int ex_pick(const ExQueues& q, int lane) {
             n = (unsigned)(q.qbeg[qi + 1] - q.qbeg[qi]);
             h = __hip_atomic_load(q.heads + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const bool live = qi < EX_NQ && h < n;
+        const bool live = qi >= qlo && qi <= qhi && qi < EX_NQ && h < n;
         const bool pending = live && d < EX_NDEP && ex_dep_pending(q.tasks + q.qbeg[qi] + h, d, q.flags);
         const unsigned long long lv = __ballot(live), pd = __ballot(pending);
-        if (lv == 0ull) return -1;
+        if (lv == 0ull) return wait ? -1 : -3;
         int pickq = -1;
 #pragma unroll
         for (int c = EX_NQ - 1; c >= 0; --c)
             if (((lv >> (8 * c)) & 1ull) && ((pd >> (8 * c)) & 0xffull) == 0ull) pickq = c;
         if (pickq >= 0) {
             const unsigned hs = (unsigned)__builtin_amdgcn_readlane((int)h, 8 * pickq);
-            const int r = ex_claim(q, pickq, hs, lane);
+            const int r = ex_claim(q, pickq, hs, lane, ready);
             if (r != -2) return r;
             continue;   // the queue ran dry between the look and the claim
         }
+        if (!wait) return -3;
         if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
         if (wall_clock64() - t_idle > q.spin_ticks) {   // no runnable task for this long: something upstream never arrived
             if (lane == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -278,17 +295,45 @@ __device__ __forceinline__ int ex_run(const ExTask& t, const ExQueues& q, double
         const unsigned long long lv = __ballot(lk_live), pd = __ballot(pending);
         int pickq = -1;
 #pragma unroll
-        for (int c = EX_NQ - 1; c >= 0; --c)
+        for (int c = EX_NQ - 1; c >= 1; --c)   // (queue 0 has its own workgroups: see k_chol_exec)
             if (((lv >> (8 * c)) & 1ull) && ((pd >> (8 * c)) & 0xffull) == 0ull) pickq = c;
         if (pickq >= 0) res = (pickq << 24) | (int)((unsigned)__builtin_amdgcn_readlane((int)lk_h, 8 * pickq) & 0xffffffu);
     }
     return res;
 }
 
+// What a free workgroup does (wave 0 decides, the others wait at the barrier):
+//   nothing in hand   claim -- from the queue the look during the last epilogue found runnable, else after a fresh look.  The
+//                     claim is a fetch-and-add, so under contention it lands a little behind the head that was seen runnable,
+//                     on a task whose counters may not be in yet.
+//   counters in       run it.
+//   counters not in   HOLD it (slot `pend`).  An urgent task (queue 0) is simply waited for.  Anything else is patient: while it
+//                     waits the workgroup looks at the bulk queue and, if its head is runnable, claims there too -- runs that
+//                     claim if its counters are in, else holds it in the second slot (`pend2`) -- and comes back to the held
+//                     tasks after everything it ran.  (Waiting idle cost ~90 of the ~490 resident workgroups during the
+//                     bulk-bound phase of N = 10^4: rows whose solve was claimed microseconds earlier, Early sums of rows not
+//                     solved yet.)  A workgroup NEVER blocks on one claim while it holds another: the first version of this
+//                     waited for the bulk claim and dead-locked -- a bulk task of the next group waits for blocks the chain can
+//                     only reach once the Early sum held in the other slot has run.  Held tasks are never given back; what a
+//                     held task waits for is running, held by a workgroup that keeps polling it, or the chain's.
 __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int s_task;
-    int look = -1;   // wave 0: what the look during the previous task's epilogue found ((queue << 24) | head), -1 nothing
+    __shared__ int s_task, s_cnt, s_cut;
+    // the workgroup's scheduling state lives in LDS (wave 0 reads and writes it between tasks): in registers it would be alive
+    // across the contraction loop, which has none to spare
+    __shared__ int s_look;     // what the look during the previous task's epilogue found ((queue << 24) | head), -1 nothing
+    __shared__ int s_pend;     // a claimed task of the queues 1 .. EX_NQ-2 whose counters were not in when last looked at
+    __shared__ int s_pend2;    // the same for a bulk claim (queue EX_NQ-1)
+    __shared__ int s_pend2n;   //   records of that bulk claim still to run (0: the whole claim)
+    __shared__ int s_urgent;
+    if (threadIdx.x == 0) { s_look = -1; s_pend = -1; s_pend2 = -1; s_pend2n = 0; s_urgent = (int)blockIdx.x < q.nurgent; }
+    __syncthreads();
+    // The urgent queue (~10 tasks per block: what the chain kernel reads next) has its own workgroups: each takes the next urgent
+    // task with a fetch-and-add AHEAD of time and waits for its counters, so the task starts the moment they arrive -- no look, no
+    // claim on the critical path -- and nobody else touches that queue.  (Claimed by everybody it was either raced -- when its
+    // head turned runnable every free workgroup saw it at once and walked away with an urgent task of a block further down, which
+    // nobody may work beside: ~250 of 490 workgroups parked -- or, claimed exactly by compare-and-swap, serialised at one claim
+    // per look, ~5 us each.)
     for (;;) {
 #if BOHIP_CHOL_TRACE
         const unsigned long long tr0 = wall_clock64();
@@ -296,25 +341,93 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
         if (threadIdx.x < 64) {
             int pl = threadIdx.x;
             asm volatile("" : "+v"(pl));   // opaque: the look's lane arithmetic must not be kept alive across the task
-            int tk = -2;
-            if (look >= 0) tk = ex_claim(q, look >> 24, (unsigned)(look & 0xffffff), pl);
-            if (tk == -2) tk = ex_pick(q, pl);
-            if (pl == 0) s_task = tk;
+            int run = -1, run_n = 0;   // run_n > 0: only that many records (the rest of a bulk claim that was interrupted)
+            int look = s_look, pend = s_pend, pend2 = s_pend2, pend2_n = s_pend2n;
+            bool urgent_wg = s_urgent != 0;
+            const unsigned long long t_wait = wall_clock64();
+            auto queue_of = [&](int t) { return t >= q.qbeg[2] ? (t >= q.qbeg[3] ? 3 : 2) : (t >= q.qbeg[1] ? 1 : 0); };
+            auto in_hand_ready = [&](int t) { const int qt = queue_of(t); return ex_ready_once(q, q.tasks + t, ex_ntile(q, qt, (unsigned)(t - q.qbeg[qt])), pl); };
+            if (urgent_wg) {
+                unsigned c = 0;
+                if (pl == 0) c = atomicAdd(q.heads, 1u);
+                c = (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+                if (c < (unsigned)(q.qbeg[1] - q.qbeg[0])) {
+                    run = ex_wait_task(q, q.tasks + q.qbeg[0] + c, 1, pl) ? q.qbeg[0] + (int)c : -1;
+                } else {
+                    urgent_wg = false;   // the urgent queue is exhausted: an ordinary workgroup from here on
+                }
+            }
+            if (!urgent_wg && run < 0)
+            for (;;) {
+                if (pend >= 0 && in_hand_ready(pend)) { run = pend; pend = -1; break; }
+                if (pend2 >= 0 && (pend2_n > 0 ? ex_ready_once(q, q.tasks + pend2, 1, pl) : in_hand_ready(pend2))) {
+                    run = pend2; run_n = pend2_n; pend2 = -1; pend2_n = 0; break;
+                }
+                bool rdy = true;
+                int tk = -3;
+                if (pend < 0) {
+                    // the first slot is free: claim as usual (a bulk claim only if the second slot is free too)
+                    const int qhi = pend2 < 0 ? EX_NQ - 1 : EX_NQ - 2;
+                    if (look >= 0 && (look >> 24) <= qhi) { tk = ex_claim(q, look >> 24, (unsigned)(look & 0xffffff), pl, rdy); if (tk == -2) tk = -3; }
+                    look = -1;
+                    if (tk == -3) tk = ex_pick(q, pl, rdy, 1, qhi, pend2 < 0);
+                    if (tk == -1) { run = -1; break; }     // every queue exhausted (nothing held either), or abort
+                } else if (pend2 < 0 && (q.fill >= 2 || (q.fill == 1 && queue_of(pend) == 2))) {
+                    // a patient task is held: bulk work meanwhile, if there is some right now
+                    tk = ex_pick(q, pl, rdy, EX_NQ - 1, EX_NQ - 1, false);
+                }
+                if (tk >= 0) {
+                    if (rdy) { run = tk; break; }
+                    if (queue_of(tk) == EX_NQ - 1) pend2 = tk; else pend = tk;
+                    continue;
+                }
+                if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { run = -1; break; }
+                if (wall_clock64() - t_wait > q.spin_ticks) {
+                    if (pl == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    run = -1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (pl == 0) { s_task = run; s_cnt = run_n; s_look = -1; s_pend = pend; s_pend2 = pend2; s_pend2n = pend2_n; s_urgent = urgent_wg ? 1 : 0; }
         }
         __syncthreads();
         const int ti = __builtin_amdgcn_readfirstlane(s_task);
+        const int tn = __builtin_amdgcn_readfirstlane(s_cnt);
         __syncthreads();
         if (ti < 0) break;
-        const int qi_ = ti >= q.qbeg[1] ? (ti >= q.qbeg[2] ? 2 : 1) : 0;
-        const int pair = min(q.stride[qi_], q.qbeg[qi_ + 1] - ti);
+        const int qi_ = ti >= q.qbeg[2] ? (ti >= q.qbeg[3] ? 3 : 2) : (ti >= q.qbeg[1] ? 1 : 0);
+        const int pair = tn > 0 ? tn : min(q.stride[qi_], q.qbeg[qi_ + 1] - ti);
         for (int u = 0; u < pair; ++u) {
             int tid = threadIdx.x;
             asm volatile("" : "+v"(tid));   // opaque per task: nothing lane-dependent is hoisted out of this loop
 #if BOHIP_CHOL_TRACE
             const unsigned long long tr1 = wall_clock64();
 #endif
-            look = ex_run(q.tasks[ti + u], q, smem, tid, u == pair - 1, ti + u);
+            const int look = ex_run(q.tasks[ti + u], q, smem, tid, u == pair - 1, ti + u);
+            if (threadIdx.x == 0) s_look = look;
+            // between the records of a bulk claim: has the task held in the first slot become runnable?  then it goes first and
+            // the rest of the claim waits in the second slot (a held task is never delayed by more than one record, ~65 us)
+            int cut = 0;
+            if (u + 1 < pair && qi_ == EX_NQ - 1 && threadIdx.x < 64) {
+                int pl = threadIdx.x;
+                asm volatile("" : "+v"(pl));
+                const int pend = s_pend;
+                if (pend >= 0 && s_pend2 < 0) {
+                    const int qp = pend >= q.qbeg[2] ? 2 : 1;
+                    if (ex_ready_once(q, q.tasks + pend, ex_ntile(q, qp, (unsigned)(pend - q.qbeg[qp])), pl)) cut = 1;
+                }
+                if (pl == 0) {
+                    s_cut = cut;
+                    if (cut) { s_pend2 = ti + u + 1; s_pend2n = pair - (u + 1); s_look = -1; }
+                }
+            }
             __syncthreads();   // the LDS tile is rewritten by the next task's DMA
+            if (u + 1 < pair && qi_ == EX_NQ - 1) {
+                const int c_ = __builtin_amdgcn_readfirstlane(s_cut);
+                __syncthreads();
+                if (c_) break;
+            }
 #if BOHIP_CHOL_TRACE
             if (threadIdx.x == 0 && ti + u < 65536) {
                 g_ex_trace[8 * (ti + u)] = u == 0 ? tr0 : tr1; g_ex_trace[8 * (ti + u) + 1] = tr1; g_ex_trace[8 * (ti + u) + 2] = wall_clock64();

@@ -18,6 +18,7 @@ import numpy as np
 import pytest
 
 TILE, CT, KC, NONE = 128, 64, 16, 0xFFFFFFFF
+NQ = 4   # queues: urgent | solve + late | early | bulk
 BASE_L, BASE_S, BASE_W = 1 << 44, 2 << 44, 3 << 44
 
 
@@ -28,7 +29,7 @@ def get_tasks(T, ld):
     f = lib.bohip_debug_exec_tasks
     f.restype = C.c_int64
     f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
-    qbeg = (C.c_int * 4)()
+    qbeg = (C.c_int * 5)()
     layout = (C.c_int64 * 11)()
     n = f(T, ld, BASE_L, BASE_S, BASE_W, None, 0, qbeg, layout)
     buf = np.zeros((n, 16), dtype=np.uint64)
@@ -111,7 +112,7 @@ def replay(T, order, seed=0):
         return all(flags[i] >= w for i, w in t["dep"] + t["dep2"])
 
     snap = {}
-    heads = [qbeg[q] for q in range(3)]
+    heads = [qbeg[q] for q in range(NQ)]
     chain_k = 0   # next block of the chain
 
     def chain_can_run():
@@ -164,7 +165,7 @@ def replay(T, order, seed=0):
 
     steps = 0
     while True:
-        for q in range(3):   # a two-piece task at a queue head whose first-stage counters are in: the device would start its first piece now
+        for q in range(NQ):   # a two-piece task at a queue head whose first-stage counters are in: the device would start its first piece now
             if heads[q] < qbeg[q + 1]:
                 t = tasks[heads[q]]
                 if t["kc_split"] and id(t) not in snap and all(flags[i] >= w for i, w in t["dep"]):
@@ -173,7 +174,7 @@ def replay(T, order, seed=0):
                     a1, b1 = view(t["A"], TILE, K1).copy(), view(t["B"], CT, K1).copy()
                     assert not np.isnan(a1).any() and not np.isnan(b1).any(), "first piece would read an operand before it was written"
                     snap[id(t)] = (a1, b1)
-        runnable = [q for q in range(3) if heads[q] < qbeg[q + 1] and ready(tasks[heads[q]])]
+        runnable = [q for q in range(NQ) if heads[q] < qbeg[q + 1] and ready(tasks[heads[q]])]
         can_chain = chain_can_run()
         tfs = [("tf", f) for f in range(NSF) if tf_can_run(f)]
         if not runnable and not can_chain and not tfs:
@@ -228,7 +229,7 @@ def test_every_tile_gets_every_block_once():
     ld = TILE * T + 16
     recs, qbeg, lay = get_tasks(T, ld)
     cover = {}
-    for q in range(3):
+    for q in range(NQ):
         for r in recs[qbeg[q]:qbeg[q + 1]]:
             t = decode(r)
             if t["C"] >> 44 == BASE_L >> 44 and t["rmw"]:        # a trailing-matrix tile: which blocks does this record subtract?

@@ -15,5 +15,7 @@ echo "# executor forced from 4 row tiles" >> $out/sizes.txt
 BOHIP_CHOL_DATAFLOW=2 BOHIP_CHOL_EXEC_MIN=4 timeout 600 python tools/chol_sizes.py 1000 2000 3000 4000 5000 >> $out/sizes.txt 2>&1
 echo "# BOHIP_CHOL_EXEC=0 (stream-based second form)" >> $out/sizes.txt
 BOHIP_CHOL_EXEC=0 timeout 600 python tools/chol_sizes.py 8000 10000 >> $out/sizes.txt 2>&1
+echo "# executor, BOHIP_CHOL_EXEC_FILL=0" >> $out/sizes.txt
+BOHIP_CHOL_EXEC_FILL=0 timeout 600 python tools/chol_sizes.py 6000 10000 >> $out/sizes.txt 2>&1
 echo "# executor, BOHIP_CHOL_EXEC_PAIRS=0" >> $out/sizes.txt
 BOHIP_CHOL_EXEC_PAIRS=0 timeout 600 python tools/chol_sizes.py 6000 10000 >> $out/sizes.txt 2>&1

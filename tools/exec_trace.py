@@ -22,7 +22,7 @@ ld = ((N + 1 + 127) // 128) * 128 + 16
 f = lib.bohip_debug_exec_tasks
 f.restype = C.c_int64
 f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
-qbeg = (C.c_int * 4)(); lay = (C.c_int64 * 11)()
+qbeg = (C.c_int * 5)(); lay = (C.c_int64 * 11)()
 n = f(T, ld, 1 << 44, 2 << 44, 3 << 44, None, 0, qbeg, lay)
 recs = np.zeros((n, 16), dtype=np.uint64)
 f(T, ld, 1 << 44, 2 << 44, 3 << 44, recs.ctypes.data_as(C.c_void_p), n, qbeg, lay)
@@ -42,51 +42,75 @@ print(f"N={N} T={T}: {n} tasks, queues {qb}; chain total {us(ct[3072 + 2 * (T - 
 # utilisation: busy worker-time per window, by queue
 end = us(et[:, 2].max())
 W = 500.0
-names = ["solve/late", "early", "bulk"]
+names = ["urgent", "solve/late", "early", "bulk"]
 print(f"window(us)   busy workers (of 512) by queue [{', '.join(names)}]  | idle-looking share | chain blocks finished")
 blk_end = us(ct[3072 + 1:3072 + 2 * T:2])
 for w0 in np.arange(0, end, W):
     row = []
-    for q in range(3):
+    for q in range(4):
         s, e = us(et[qb[q]:qb[q + 1], 1]), us(et[qb[q]:qb[q + 1], 2])
         row.append(np.clip(np.minimum(e, w0 + W) - np.maximum(s, w0), 0, None).sum() / W)
-    print(f"{w0:8.0f}   {row[0]:6.1f} {row[1]:6.1f} {row[2]:6.1f}   total {sum(row):6.1f}   | blocks done {int((blk_end < w0 + W).sum())}")
+    print(f"{w0:8.0f}   {row[0]:6.1f} {row[1]:6.1f} {row[2]:6.1f} {row[3]:6.1f}   total {sum(row):6.1f}   | blocks done {int((blk_end < w0 + W).sum())}")
+print("window(us)   workers LOOKING or WAITING for a claimed task's counters, by queue of the task they then ran")
+for w0 in np.arange(0, end, W):
+    row = []
+    for q in range(4):
+        s_, e_ = us(et[qb[q]:qb[q + 1], 0]), us(et[qb[q]:qb[q + 1], 1])
+        row.append(np.clip(np.minimum(e_, w0 + W) - np.maximum(s_, w0), 0, None).sum() / W)
+    print(f"{w0:8.0f}   {row[0]:6.1f} {row[1]:6.1f} {row[2]:6.1f} {row[3]:6.1f}   total {sum(row):6.1f}")
 dur = us(et[:, 2]) - us(et[:, 1])
 look = us(et[:, 1]) - us(et[:, 0])
-for q in range(3):
+for q in range(4):
     sl = slice(qb[q], qb[q + 1])
     k_ = kc[sl]
     print(f"queue {q} ({names[q]}): {qb[q+1]-qb[q]} tasks, run time mean {dur[sl].mean():.1f} us (per 128 of K: {(dur[sl] / (k_ / 8)).mean():.2f} us), look+wait before start mean {look[sl].mean():.1f} us")
 # critical latency per block: pivot end -> inverse published -> first Solve row -> first-row Late tiles -> the chain sees rest[k]
 print("block:  pivot end | inverse +us | S(k+3,k) by the chain's solve_follower | first-row Late start,end | Solve far rows start,end | follower saw rest[k] (relative to pivot end)")
-pos = qb[0]
+NSF = int(lay[10])
+pos0, pos1 = qb[0], qb[1]
+rows = {}
 for k in range(T - 3):
-    NSF = int(lay[10])
     nurg = 2 * (3 + max(0, min(T, k + 3 + NSF) - (k + 4)))
     nsolve = 2 * max(0, T - k - 3 - NSF)
-    late = et[pos:pos + 6]; solve = et[pos + nurg:pos + nurg + nsolve]
-    pos += nurg + 2 * nsolve
+    late = et[pos0:pos0 + 6]; solve = et[pos1:pos1 + nsolve]
+    rows[k] = late
+    pos0 += nurg
+    pos1 += 2 * nsolve
     pe = us(ct[3072 + 2 * k + 1])
     if k < 6 or k % 8 == 0:
         sv = f"{us(solve[:, 1]).min() - pe:6.1f} {us(solve[:, 2]).max() - pe:6.1f}" if nsolve else "   -      -  "
         print(f"{k:4d}: {pe:9.1f} | {us(ct[4096 + k]) - pe:6.1f} | {us(ct[4608 + k]) - pe:6.1f} | "
               f"{us(late[:, 1]).min() - pe:6.1f} {us(late[:, 2]).max() - pe:6.1f} | {sv} | {us(ct[4352 + k + 1]) - pe:6.1f} | next pivot start {us(ct[3072 + 2 * (k + 1)]) - pe:6.1f}")
-
 # the chain's own waits, per block k (us relative to the pivot end of block k-1): what held pivot k back?
 pdur = [(us(ct[3072 + 2 * k + 1]) - us(ct[3072 + 2 * k])) for k in range(T)]
 gaps = [(us(ct[3072 + 2 * (k + 1)]) - us(ct[3072 + 2 * k + 1])) for k in range(T - 1)]
 print(f"pivot duration mean {np.mean(pdur):.1f} us (min {np.min(pdur):.1f} max {np.max(pdur):.1f}); gap to the next pivot mean {np.mean(gaps):.1f} us (median {np.median(gaps):.1f}, max {np.max(gaps):.1f})")
 print("block k: [rel. to pivot k-1 end] owner waits for crit[k-2] from .. to | follower of row k saw crit[k-2] | owner saw last panel of L(k,k-1) | pivot k start || first-row Late(k-1) tasks: start / stage-2 in / loop done / end")
-pos = qb[0]
-rows = {}
-for k in range(T - 3):
-    NSF = int(lay[10])
-    nurg = 2 * (3 + max(0, min(T, k + 3 + NSF) - (k + 4)))
-    nsolve = 2 * max(0, T - k - 3 - NSF)
-    rows[k] = et[pos:pos + 6]
-    pos += nurg + 2 * nsolve
 for k in list(range(2, 8)) + list(range(8, T - 3, 6)):
     pe = us(ct[3072 + 2 * (k - 1) + 1])
     lt = rows.get(k - 1)
     ls = " ".join(f"[{us(r[1]) - pe:.0f}/{us(r[4]) - pe:.0f}/{us(r[5]) - pe:.0f}/{us(r[2]) - pe:.0f}]" for r in lt) if lt is not None else ""
     print(f"{k:4d}: {us(ct[4864 + k]) - pe:6.1f} .. {us(ct[5120 + k]) - pe:6.1f} | {us(ct[5632 + k - 1]) - pe:6.1f} | {us(ct[5376 + k]) - pe:6.1f} | {us(ct[3072 + 2 * k]) - pe:6.1f} || {ls}")
+
+# the solve followers' chain: follower f of block k (row k+3+f) -- input tile final / S complete -- and the urgent Late task that
+# produced its input (Late(k-1) of tile (k+3+f, k): record pair 3 + f of block k-1's urgent group), all relative to pivot k-1's end
+print("solve followers, block k: per follower f [input seen / S done] and the Late(k-1) task of its input tile [start/stage-2 in/end] (us rel. to pivot k-1 end; pivot k start in the last column)")
+posu = {}
+p_ = qb[0]
+for k in range(T - 3):
+    posu[k] = p_
+    p_ += 2 * (3 + max(0, min(T, k + 3 + NSF) - (k + 4)))
+for k in list(range(2, 6)) + list(range(6, T - 4, 5)):
+    pe = us(ct[3072 + 2 * (k - 1) + 1])
+    parts = []
+    for f in range(min(NSF, 4)):
+        if k + 3 + f >= T:
+            continue
+        txt = f"f{f} [{us(ct[7168 + 256 * f + k]) - pe:.0f}/{us(ct[6144 + 256 * f + k]) - pe:.0f}]"
+        # input tile (k+3+f, k) = column c = k of Late(k-1): row i = (k-1) + 4 + f -> urgent iff f + 1 < NSF: pair index 3 + f
+        if f + 1 < NSF and k - 1 in posu:
+            r0 = et[posu[k - 1] + 2 * (3 + f)]
+            r1 = et[posu[k - 1] + 2 * (3 + f) + 1]
+            txt += f" <- Late [{min(us(r0[1]), us(r1[1])) - pe:.0f}/{max(us(r0[4]), us(r1[4])) - pe:.0f}/{max(us(r0[2]), us(r1[2])) - pe:.0f}]"
+        parts.append(txt)
+    print(f"{k:4d}: " + "  ".join(parts) + f"   | pivot k start {us(ct[3072 + 2 * k]) - pe:.0f}, end {us(ct[3072 + 2 * k + 1]) - pe:.0f}")
