@@ -45,7 +45,7 @@ constexpr int CH_PANELS = TILE / 16;          // 8 panels of 16 columns per 128-
 constexpr int WK_LPS = 16;                    // worker LDS: published panel LP[128][16]
 constexpr int WK_XS = 17;                     //             solved rows   XB[128][17]
 constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + 2 * TILE * WK_XS + 256 + 2;   // LPt[16][130] | XB[128][17] | XS[128][17] | W16[16][16] | next-panel-ready word
-constexpr int INV_LDS_DOUBLES = TILE * TILE + 16 * (TILE - 16) + 8 * TILE + 256;   // the inverter workgroup's image (inverter_role)
+constexpr int INV_LDS_DOUBLES = (TILE - 16) * TILE + 16 * (TILE - 16) + 16 * TILE + 256;   // the inverter workgroup's image (inverter_role)
 constexpr int CH_LDS_BYTES = (INV_LDS_DOUBLES > TILE * PF_LD + 2 * TILE + 256 ? INV_LDS_DOUBLES : TILE * PF_LD + 2 * TILE + 256) * 8;   // the potf2 image + dl + idl + W16 scratch (the worker arrays alias its start), or the inverter's
 static_assert(WK_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "worker arrays must fit inside the diagonal-block image");
 
@@ -627,101 +627,119 @@ __device__ __forceinline__ void gated_worker(double* __restrict__ Lmat, int64_t 
 // solved[k] rises ~3 us after the pivot block ends.  Image: Wimg[m][c] = W[m][c] for the rows m < 112 (zero above the diagonal).
 constexpr int INV_WROWS = TILE - 16;
 static_assert(INV_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "inverter image must fit the chain's LDS");
+// Round p, all 512 threads, thread (c = tid & 127, rq = tid >> 7) owns column c of the rows 4 rq .. 4 rq + 3 of a row panel:
+//   [event p: panel p of L_kk and W16_p published]
+//   ONE memory round trip: W16_p and the rows of L behind the NEXT pivot block, L[16(p+1) .., 0 .. 16p+15] (complete with event p)
+//   W[p, 0:p] = -W16_p T(p)          (T(p) was computed in round p-1; 16 x 16 product per column, exchanged through LDS)
+//   T(p+1)    =  L[p+1, 0:p+1] W[0:p+1, 0:p+1]   -- the long product, now BEHIND the publication of row panel p's inputs and
+//                                                    before event p+1 arrives (the pivot needs 5-7 us per panel)
+//   stores of row panel p (16-byte agent-scope pieces; the last panel straight from registers)
+// so what is left behind the block's LAST event is one round trip, a 16 x 16 product and the stores.  (First incremental
+// version: T(p) was computed after its own loads, 256 threads, one LDS read per FMA: it fell ~2 us behind per panel over the
+// last panels and published the inverse 18-25 us after the pivot block -- no better than the recursive-doubling inverse.)
 __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ W,
                                               double* __restrict__ WT, int64_t ldw, int T, const CholFlags& fl, double* sm) {
-    if (threadIdx.x >= PF_THREADS) return;
-    double* Wimg = sm;                         // [128][128]  W_kk (zero above the diagonal)
-    double* Lrow = sm + TILE * TILE;           // [16][112]   rows 16p .. 16p+15 of L_kk, columns < 16p
-    double* Tl = Lrow + 16 * INV_WROWS;        // [8][128]    rows 0..7 of T for the threads that build the rows 8..15
-    double* W16s = Tl + 8 * TILE;              // [16][16]
-    const int tid = threadIdx.x, c = tid & 127, rh = tid >> 7;
-    for (int e = tid; e < TILE * TILE; e += PF_THREADS) Wimg[e] = 0.0;   // the strict upper triangle is never written again
+    double* Wimg = sm;                         // [112][128]  W_kk rows 0..111 (zero above the diagonal)
+    double* Lrow = sm + INV_WROWS * TILE;      // [16][112]   rows of L_kk behind the next pivot block
+    double* Tl = Lrow + 16 * INV_WROWS;        // [16][128]   T(p), exchanged between the four row groups
+    double* W16s = Tl + 16 * TILE;             // [16][16]
+    const int tid = threadIdx.x, c = tid & 127, rq = tid >> 7;
+    for (int e = tid; e < INV_WROWS * TILE; e += CH_THREADS) Wimg[e] = 0.0;   // the strict upper triangle is never written again
     __syncthreads();
     for (int k = 0; k < T; ++k) {
         const int64_t off = (int64_t)k * TILE;
         const double* Lblk = Lmat + off * (ld + 1);
         double* Wb = W + off * (ldw + 1);
         double* WTb = WT + off * (ldw + 1);
+        double t[4] = {0.0, 0.0, 0.0, 0.0};   // T(p): rows 4 rq .. 4 rq + 3, column c (c < 16 p)
         for (int p = 0; p < CH_PANELS; ++p) {
-            const int R0 = 16 * p;
-            double t[8];
+            const int R0 = 16 * p, R1 = R0 + 16;
+            if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
+            __syncthreads();
+            if (tid < 256) W16s[tid] = ld_agent(fl.w16_g + ((size_t)k * CH_PANELS + p) * 256 + tid);
+            if (p + 1 < CH_PANELS) {   // rows 16(p+1) .. of L_kk, columns < 16(p+1): thread (r = tid >> 5, mm = tid & 31)
+                const int r = tid >> 5, mm = tid & 31;
+                const double* src = Lblk + (int64_t)(R1 + r) * ld;
+                for (int col = mm; col < R1; col += 32) Lrow[r * INV_WROWS + col] = ld_agent(src + col);
+            }
+            if (p > 0 && c < R0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = 0.0;
-            if (p > 0) {   // (panel p-1's flag was seen in the previous round: the rows behind the pivot are published)
-                {
-                    const int r = tid >> 4, mm = tid & 15;
-                    const double* src = Lblk + (int64_t)(R0 + r) * ld + mm;
-                    for (int u = 0; u < p; ++u) Lrow[r * INV_WROWS + 16 * u + mm] = ld_agent(src + 16 * u);
+                for (int j = 0; j < 4; ++j) Tl[(4 * rq + j) * TILE + c] = t[j];
+            }
+            __syncthreads();
+            double wn[4] = {0.0, 0.0, 0.0, 0.0};
+            if (p > 0 && c < R0) {   // the new rows 16p + 4 rq .. + 3 of W, column c: -W16 T
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * rq + j;
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int m = 0; m < 16; ++m)
+                        if (m <= r) sacc += W16s[r * 16 + m] * Tl[m * TILE + c];
+                    wn[j] = -sacc;
+                    if (p + 1 < CH_PANELS) Wimg[(R0 + r) * TILE + c] = wn[j];
                 }
-                __syncthreads();
-                if (c < R0) {   // thread (c, rh): rows 8 rh .. 8 rh + 7 of T = L[p, 0:p] W[0:p, 0:p], column c
-                    // 8 contraction indices per round: 8 + 32 LDS reads (the L rows as 16-byte pieces) for 64 FMAs, all issued
-                    // before the first use (one read per FMA in a dependent loop took ~10 us per panel: behind the 7 us pivot cadence)
-                    const double* lr = Lrow + 8 * rh * INV_WROWS;
-                    for (int m0 = 0; m0 < R0; m0 += 8) {
+            }
+            if (p + 1 < CH_PANELS && tid < 256) Wimg[(R0 + (tid >> 4)) * TILE + R0 + (tid & 15)] = W16s[tid];   // the diagonal block is W16 itself
+            __syncthreads();
+            if (p + 1 < CH_PANELS) {
+                // T(p+1), column c < 16(p+1): 8 contraction indices per round -- 8 + 16 LDS reads (the L rows as 16-byte pieces) for 32 FMAs
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = 0.0;
+                if (c < R1) {
+                    const double* lr = Lrow + 4 * rq * INV_WROWS;
+                    for (int m0 = 0; m0 < R1; m0 += 8) {
                         double w[8];
 #pragma unroll
                         for (int q = 0; q < 8; ++q) w[q] = Wimg[(m0 + q) * TILE + c];
+                        d2 l[4][4];
 #pragma unroll
-                        for (int jh = 0; jh < 2; ++jh) {
-                            d2 l[4][4];
+                        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int q = 0; q < 4; ++q) l[j][q] = *reinterpret_cast<const d2*>(lr + j * INV_WROWS + m0 + 2 * q);
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) l[j][q] = *reinterpret_cast<const d2*>(lr + (4 * jh + j) * INV_WROWS + m0 + 2 * q);
+                        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
+                            for (int q = 0; q < 4; ++q) {
+                                t[j] += l[j][q].x * w[2 * q];
+                                t[j] += l[j][q].y * w[2 * q + 1];
+                            }
+                    }
+                }
+                // row panel p out, from the image: W rows (16-byte pieces along the row) and the same entries as columns of W'
+                {
+                    const int r = (tid & 255) >> 4, q = tid & 15, hh = tid >> 8;
+                    for (int u = (q >> 3) + 2 * hh; u <= p; u += 4) {
+                        const int col = 16 * u + 2 * (q & 7);
+                        const d2 v = *reinterpret_cast<const d2*>(Wimg + (R0 + r) * TILE + col);
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(Wb + (int64_t)(R0 + r) * ldw + col), "v"(v) : "memory");
+                    }
+                    if (c < R1) {
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    t[4 * jh + j] += l[j][q].x * w[2 * q];
-                                    t[4 * jh + j] += l[j][q].y * w[2 * q + 1];
-                                }
+                        for (int e = 0; e < 2; ++e) {
+                            const int rr = 2 * (2 * rq + e);
+                            d2 v;
+                            v.x = Wimg[(R0 + rr) * TILE + c];
+                            v.y = Wimg[(R0 + rr + 1) * TILE + c];
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTb + (int64_t)c * ldw + R0 + rr), "v"(v) : "memory");
                         }
                     }
-                    if (rh == 0) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) Tl[j * TILE + c] = t[j];
-                    }
                 }
-            }
-            if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
-            __syncthreads();
-            W16s[tid] = ld_agent(fl.w16_g + ((size_t)k * CH_PANELS + p) * 256 + tid);
-            __syncthreads();
-            if (p > 0 && c < R0) {   // rows 8 rh .. 8 rh + 7 of the new row panel: -W16 T
+            } else {
+                // the last row panel goes out straight from the registers (rows 112 + 4 rq .. + 3, column c) and from W16
+                if (c < R0) {
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    const int r = 8 * rh + rr;
-                    double sacc = 0.0;
-                    if (rh == 0) {
-#pragma unroll
-                        for (int j = 0; j <= rr; ++j) sacc += W16s[r * 16 + j] * t[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) sacc += W16s[r * 16 + j] * Tl[j * TILE + c];
-#pragma unroll
-                        for (int j = 0; j <= rr; ++j) sacc += W16s[r * 16 + 8 + j] * t[j];
-                    }
-                    Wimg[(R0 + r) * TILE + c] = -sacc;
+                    for (int j = 0; j < 4; ++j) st_agent(Wb + (int64_t)(R0 + 4 * rq + j) * ldw + c, wn[j]);
+                    d2 v0, v1;
+                    v0.x = wn[0]; v0.y = wn[1]; v1.x = wn[2]; v1.y = wn[3];
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq), "v"(v0) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq + 2), "v"(v1) : "memory");
                 }
-            }
-            Wimg[(R0 + (tid >> 4)) * TILE + R0 + (tid & 15)] = W16s[tid];   // the diagonal block is W16 itself (zeros above its diagonal)
-            __syncthreads();
-            {   // row panel p out: W rows (16-byte pieces along the row) and the same entries as columns of W'
-                const int r = tid >> 4, q = tid & 15;
-                for (int u = q >> 3; u <= p; u += 2) {
-                    const int col = 16 * u + 2 * (q & 7);
-                    const d2 v = *reinterpret_cast<const d2*>(Wimg + (R0 + r) * TILE + col);
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(Wb + (int64_t)(R0 + r) * ldw + col), "v"(v) : "memory");
-                }
-                if (c < R0 + 16) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int rr = 2 * (4 * rh + e);
-                        d2 v;
-                        v.x = Wimg[(R0 + rr) * TILE + c];
-                        v.y = Wimg[(R0 + rr + 1) * TILE + c];
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTb + (int64_t)c * ldw + R0 + rr), "v"(v) : "memory");
+                if (tid < 256) {
+                    const int r = tid >> 4, j = tid & 15;
+                    if (j <= r) {
+                        st_agent(Wb + (int64_t)(R0 + r) * ldw + R0 + j, W16s[tid]);
+                        st_agent(WTb + (int64_t)(R0 + j) * ldw + R0 + r, W16s[tid]);
                     }
                 }
             }
