@@ -2216,6 +2216,14 @@ int bohip_gp_get_timing(bohip_gp* g, const char** names, double* ms, int cap) {
 }  // extern "C"
 #include "multigpu.hip"
 extern "C" {
+// tools only: the resident W = L^-1 (which = 0) or W' (which = 1), n x n row-major
+int bohip_debug_read_w(bohip_gp* g, int which, double* out) {
+    if (!g || !out) return BOHIP_E_ARG;
+    hipSetDevice(g->device);
+    hipStreamSynchronize(g->stream);
+    const double* src = which ? g->dWT : g->dW;
+    return hipMemcpy2D(out, (size_t)g->n * 8, src, (size_t)g->ld * 8, (size_t)g->n * 8, (size_t)g->n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : BOHIP_E_HIP;
+}
 // test hook (tests/test_exec_tasks.py): the executor's task records for T row tiles with the three matrices at the fake
 // addresses base_L/S/W (bytes) and flag word 0 at index 0 -- the CPU test replays them against a model of the chain.
 // out: n x 16 uint64 words (the 128-byte records); returns the number of records, qbeg[0..4] the queue boundaries,

@@ -33,6 +33,12 @@ struct KernelHyper {
 // bound of every in-kernel wait of the dataflow factorisation, in ticks of wall_clock64() (100 MHz): 200 ms (kernels_chol.hip)
 constexpr unsigned long long CH_SPIN_TICKS_DEFAULT = 20000000ull;
 
+// INLINE-ASM 16-BYTE STORES carry "s_nop 1" behind them.  gfx9 has a hazard: a VMEM store of more than 64 bits of data followed by
+// a VALU instruction that writes one of the store's data VGPRs needs a wait state.  hipcc inserts it for stores it emitted
+// itself, but its hazard recogniser does not look inside an inline-asm string, so `global_store_dwordx4 ... sc1` written as asm
+// (the atomic builtins stop at 8 bytes) followed by ordinary code that reuses the data registers stored a corrupted low dword:
+// measured in the inverter (kernels_chol.hip) as the first double of every other 16-byte piece off by ~1e-7 relative.
+
 struct Best {
     double val;
     long long idx;

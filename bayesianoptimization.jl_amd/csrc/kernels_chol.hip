@@ -712,7 +712,7 @@ __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, i
                     for (int u = (q >> 3) + 2 * hh; u <= p; u += 4) {
                         const int col = 16 * u + 2 * (q & 7);
                         const d2 v = *reinterpret_cast<const d2*>(Wimg + (R0 + r) * TILE + col);
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(Wb + (int64_t)(R0 + r) * ldw + col), "v"(v) : "memory");
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(Wb + (int64_t)(R0 + r) * ldw + col), "v"(v) : "memory");
                     }
                     if (c < R1) {
 #pragma unroll
@@ -721,7 +721,7 @@ __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, i
                             d2 v;
                             v.x = Wimg[(R0 + rr) * TILE + c];
                             v.y = Wimg[(R0 + rr + 1) * TILE + c];
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTb + (int64_t)c * ldw + R0 + rr), "v"(v) : "memory");
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTb + (int64_t)c * ldw + R0 + rr), "v"(v) : "memory");
                         }
                     }
                 }
@@ -732,8 +732,8 @@ __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, i
                     for (int j = 0; j < 4; ++j) st_agent(Wb + (int64_t)(R0 + 4 * rq + j) * ldw + c, wn[j]);
                     d2 v0, v1;
                     v0.x = wn[0]; v0.y = wn[1]; v1.x = wn[2]; v1.y = wn[3];
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq), "v"(v0) : "memory");
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq + 2), "v"(v1) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq), "v"(v0) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq + 2), "v"(v1) : "memory");
                 }
                 if (tid < 256) {
                     const int r = tid >> 4, j = tid & 15;

@@ -281,7 +281,7 @@ __device__ __forceinline__ int ex_run(const ExTask& t, const ExQueues& q, double
                 v.y -= pv[u].y;
             }
         }
-        if (k1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+        if (k1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
         else __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed (a workgroup-scope fence emits no such wait)

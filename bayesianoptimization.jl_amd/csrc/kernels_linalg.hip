@@ -338,7 +338,7 @@ __device__ __forceinline__ void inverse_phase(double* a, const double* idl, int 
             d2 v;
             v.x = a[i * PF_LD + c];
             v.y = (c + 1 <= i) ? a[i * PF_LD + c + 1] : 0.0;
-            if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(Wblk + (int64_t)i * ldw + c), "v"(v) : "memory");
+            if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(Wblk + (int64_t)i * ldw + c), "v"(v) : "memory");
             else *reinterpret_cast<d2*>(Wblk + (int64_t)i * ldw + c) = v;
         }
         // W'[r][q] = W[q][r] for q >= r: row r = i, columns q = c, c + 1
@@ -346,7 +346,7 @@ __device__ __forceinline__ void inverse_phase(double* a, const double* idl, int 
             d2 v;
             v.x = (c >= i) ? a[c * PF_LD + i] : 0.0;
             v.y = a[(c + 1) * PF_LD + i];
-            if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(WTblk + (int64_t)i * ldw + c), "v"(v) : "memory");
+            if constexpr (SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTblk + (int64_t)i * ldw + c), "v"(v) : "memory");
             else *reinterpret_cast<d2*>(WTblk + (int64_t)i * ldw + c) = v;
         }
     }
@@ -602,7 +602,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
                 if (k1) *reinterpret_cast<d2*>(dst) = v;
                 else *dst = v.x;
             } else if (k1) {
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(v) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
             } else {
                 __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
