@@ -285,7 +285,7 @@ static unsigned long long g_chol_spin_ticks = CH_SPIN_TICKS_DEFAULT;   // BOHIP_
 static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_exec) from g_chol_exec_min row tiles on (BOHIP_CHOL_EXEC=0: the stream-based second form)
 static int g_chol_exec_min = 32;  // BOHIP_CHOL_EXEC_MIN: N=4000 2.42 vs 2.49 ms for the first dataflow form, N=5000 3.23 vs 3.75; below (N=3000) the first form wins (1.67 vs 1.78)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
-static int g_chol_exec_urgent = 24; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
+static int g_chol_exec_urgent = 40; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
 static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
@@ -769,46 +769,47 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
     for (int k = 0; k + 3 < T; ++k) {
         // Solve(i, k) = A(i, k) W_kk'  (W_kk lower-triangular: the left half of the columns needs the first 64 contraction indices only)
         const double* Wkk = dW + (int64_t)k * TILE * (ld + 1);
-        auto solve_rows = [&]() {   // (the rows k+3 .. k+2+CH_NSF are solved panel by panel inside the chain kernel: solve_follower)
-            for (int i = k + 3 + CH_NSF; i < T; ++i)
-                add(1, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
-                    {{widx(fl.solved + k), 1u}, {k >= 1 ? ver(i, k) : EX_NONE, 16u * (unsigned)(nb(k) + 1)}}, sver(i, k), EX_NONE);
+        // The rows k+3 .. k+2+CH_NSF are solved panel by panel inside the chain kernel (solve_follower).  The next NBU rows -- the
+        // ones that become follower rows within NBU blocks -- have their row step (Solve, then Late of column k+1) in the URGENT
+        // queue: what paces the whole factorisation is the latency pivot k -> inverse -> Solve -> Late of the row that enters the
+        // follower window next (chain period ~ 69 us + that latency - ~29 us), and in the ordinary queue that row's two steps wait
+        // for a free workgroup twice and run beside bulk work.  Everything further out is queue 1.
+        const int NBU = 2, rb = k + 3 + CH_NSF;   // first row solved by the executor
+        auto solve_row = [&](int qi, int i) {
+            add(qi, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
+                {{widx(fl.solved + k), 1u}, {k >= 1 ? ver(i, k) : EX_NONE, 16u * (unsigned)(nb(k) + 1)}}, sver(i, k), EX_NONE);
         };
         // Late(k): blocks max(k-1, 0) .. k into the tiles read next; the three tiles of row k+3 (what the chain waits for) first
         const int kb0 = std::max(k - 1, 0), kcl = (k - kb0 + 1) * CPB;
-        auto late = [&](int i, int c) {
+        auto late = [&](int qi, int i, int c) {
             const bool has_p = e_of(i, c) >= ks(c);
             auto chain_row = [&](int kk, int r) { return Dep{widx(fl.xp + ((size_t)kk * T + r) * CH_PANELS + (CH_PANELS - 1)), 1u}; };
             const Dep p_dep{has_p ? pver(i, c) : EX_NONE, 16u}, v_dep{ver(i, c), 16u * (unsigned)nb(c)};
-            if (i < k + 3 + CH_NSF && k >= 1) {
-                // a tile whose row of S(:, k) comes from the chain kernel's solve followers -- the three tiles the chain waits for, and
-                // the tiles the later followers read next: the block k-1 half of the contraction needs nothing of block k, so the task
-                // is claimed and starts while block k is still being factored, and waits for S(i, k) (and the chain's row c) inside
+            if (k >= 1) {
+                // TWO PIECES: the block k-1 half of the contraction needs nothing of block k, so the task is claimed and starts before
+                // S(i, k) exists -- for the follower rows while block k is still being factored, for the others while their row
+                // solve is running -- and waits for S(i, k) (and the chain's row c) inside, half a contraction from its end
                 const Dep b_prev = c == k + 1 ? chain_row(k - 1, c) : Dep{sver(c, k - 1), 16u};
-                add(0, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
+                add(qi, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
                     {{sver(i, k - 1), 16u}, b_prev, p_dep, v_dep}, ver(i, c), i == k + 3 ? widx(fl.rest + k) : EX_NONE, CPB,
                     Dep{sver(i, k), 16u}, c <= k + 2 ? chain_row(k, c) : Dep{EX_NONE, 0});
                 return;
             }
-            // rows of S on the B side: row c of the blocks kb0 .. k
-            Dep b0{EX_NONE, 0}, b1{EX_NONE, 0};
-            if (c <= k + 2) {   // row c of block k is one of the chain's two: its last-panel flag
-                b0 = chain_row(k, c);
-                if (c == k + 2 && k >= 1) b1 = {sver(c, k - 1), 16u};
-            } else {
-                b0 = {sver(c, k), 16u};
-            }
-            add(i < k + 3 + CH_NSF ? 0 : 1, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
-                {{sver(i, k), 16u}, b0, b1, p_dep, v_dep}, ver(i, c), i == k + 3 ? widx(fl.rest + k) : EX_NONE);
+            // block 0: one piece.  rows of S on the B side: row c of block 0
+            const Dep b0 = c <= k + 2 ? chain_row(k, c) : Dep{sver(c, k), 16u};
+            add(qi, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
+                {{sver(i, k), 16u}, b0, p_dep, v_dep}, ver(i, c), i == k + 3 ? widx(fl.rest + k) : EX_NONE);
         };
-        // the three tiles the chain waits for come FIRST: they are claimed while block k is still being factored (their first
-        // piece needs block k-1 only) and finish a few microseconds after the chain's solve_follower has delivered S(k+3, k)
-        late(k + 3, k + 1);
-        late(k + 3, k + 2);
-        late(k + 3, k + 3);
-        for (int i = k + 4; i < std::min(T, k + 3 + CH_NSF); ++i) late(i, k + 1);
-        solve_rows();
-        for (int i = k + 3 + CH_NSF; i < T; ++i) late(i, k + 1);
+        // urgent, in the order they are needed: the three tiles the chain waits for, the tiles its solve followers read next, then
+        // the row steps of the rows about to enter the follower window
+        late(0, k + 3, k + 1);
+        late(0, k + 3, k + 2);
+        late(0, k + 3, k + 3);
+        for (int i = k + 4; i < std::min(T, rb); ++i) late(0, i, k + 1);
+        for (int i = rb; i < std::min(T, rb + NBU); ++i) solve_row(0, i);
+        for (int i = rb; i < std::min(T, rb + NBU); ++i) late(0, i, k + 1);
+        for (int i = rb + NBU; i < T; ++i) solve_row(1, i);
+        for (int i = rb + NBU; i < T; ++i) late(1, i, k + 1);
     }
     for (int kp = 0; kp + 5 < T; ++kp) {
         // Early(kp): P(i, c) = sum_{b = ks(c)}^{kp} S(i, b) S(c, b)'  for the tiles Late(kp + 2) finishes

@@ -70,8 +70,9 @@ NSF = int(lay[10])
 pos0, pos1 = qb[0], qb[1]
 rows = {}
 for k in range(T - 3):
-    nurg = 2 * (3 + max(0, min(T, k + 3 + NSF) - (k + 4)))
-    nsolve = 2 * max(0, T - k - 3 - NSF)
+    rb = k + 3 + NSF; nbu = min(2, max(0, T - rb))
+    nurg = 2 * (3 + max(0, min(T, rb) - (k + 4))) + 4 * nbu
+    nsolve = 2 * max(0, T - rb - 2)
     late = et[pos0:pos0 + 6]; solve = et[pos1:pos1 + nsolve]
     rows[k] = late
     pos0 += nurg
@@ -99,7 +100,7 @@ posu = {}
 p_ = qb[0]
 for k in range(T - 3):
     posu[k] = p_
-    p_ += 2 * (3 + max(0, min(T, k + 3 + NSF) - (k + 4)))
+    p_ += 2 * (3 + max(0, min(T, k + 3 + NSF) - (k + 4))) + 4 * min(2, max(0, T - (k + 3 + NSF)))
 for k in list(range(2, 6)) + list(range(6, T - 4, 5)):
     pe = us(ct[3072 + 2 * (k - 1) + 1])
     parts = []
