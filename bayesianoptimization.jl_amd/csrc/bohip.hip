@@ -285,7 +285,7 @@ static unsigned long long g_chol_spin_ticks = CH_SPIN_TICKS_DEFAULT;   // BOHIP_
 static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_exec) from g_chol_exec_min row tiles on (BOHIP_CHOL_EXEC=0: the stream-based second form)
 static int g_chol_exec_min = 32;  // BOHIP_CHOL_EXEC_MIN: N=4000 2.42 vs 2.49 ms for the first dataflow form, N=5000 3.23 vs 3.75; below (N=3000) the first form wins (1.67 vs 1.78)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
-static int g_chol_exec_urgent = 40; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
+static int g_chol_exec_urgent = 32; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
 static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
