@@ -82,7 +82,8 @@ struct bohip_gp {
     bool w_seeded = false;                        // the diagonal blocks of W were produced during the factorisation (k_chol_inverter)
     ExTask* dex_tasks = nullptr;                  // task records of the executor form (kernels_exec.hip), built once per (buffers, T)
     size_t ex_cap = 0;
-    int ex_T = 0, ex_nsf = 0, ex_qbeg[EX_NQ + 1] = {0, 0, 0, 0, 0};
+    int ex_T = 0, ex_nsf = 0, ex_inv_g = -1, ex_qbeg[EX_NQ + 1] = {0};
+    bool w_done = false;       // the last factorisation also produced W = L^-1 (executor form with its inverse queue)
     // scoring scratch
     double* dKsT = nullptr;
     int64_t kst_rows = 0;
@@ -283,7 +284,13 @@ static int g_chol_df_tmax = 96;   // = CHOL_DF_TCAP, N <= ~12200 (N=12000: 16.5 
 static std::atomic<int> g_chol_df_skip{0}, g_chol_df_backoff{0};
 static unsigned long long g_chol_spin_ticks = CH_SPIN_TICKS_DEFAULT;   // BOHIP_CHOL_SPIN_US: bound of every in-kernel wait of the dataflow forms
 static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_exec) from g_chol_exec_min row tiles on (BOHIP_CHOL_EXEC=0: the stream-based second form)
-static int g_chol_exec_min = 32;  // BOHIP_CHOL_EXEC_MIN: N=4000 2.42 vs 2.49 ms for the first dataflow form, N=5000 3.23 vs 3.75; below (N=3000) the first form wins (1.67 vs 1.78)
+static int g_chol_exec_min = -1;  // BOHIP_CHOL_EXEC_MIN, row tiles.  Default: 4 with the executor's inverse queues (factorisation + inverse: N=500 0.41 ms against
+                                  // 0.51 for the first dataflow form + the inverse behind it, N=1000 0.70 / 0.87, N=3000 2.02 / 2.49, N=4000 2.96 / 3.50), 32 without
+                                  // them (the factorisation alone: N=3000 1.75 against 1.67 for the first form, N=4000 2.42 / 2.49, N=5000 3.23 / 3.75)
+static int g_chol_exec_fill_inv = 1;    // a workgroup waiting for the counters of a claimed task runs inverse-wave tasks meanwhile (BOHIP_CHOL_EXEC_FILL_INV)
+static int g_chol_exec_inv_pairs = 0;   // inverse queue claimed one record (0) or one tile = two records (1) at a time (BOHIP_CHOL_EXEC_INV_PAIRS)
+static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
+                                   // of contraction (BOHIP_CHOL_INV_G; 0 = off: the level-by-level inverse runs after the factorisation)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
 static int g_chol_exec_urgent = 32; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
@@ -333,6 +340,9 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL")) g_chol_exec_fill = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_URGENT")) g_chol_exec_urgent = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(CH_NSF_MAX, std::max(1, atoi(e)));
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL_INV")) g_chol_exec_fill_inv = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_INV_PAIRS")) g_chol_exec_inv_pairs = atoi(e) != 0;
+    if (const char* e = getenv("BOHIP_CHOL_INV_G")) g_chol_inv_g = std::min(64, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_PULL")) g_trigemm_pull = atoi(e);
@@ -422,7 +432,8 @@ static int inverse_join(bohip_gp* g, hipStream_t st, int P, int nb) {
 // ---- A2, dataflow form (kernels_chol.hip): ONE persistent chain launch on the critical stream; the panel followers and the
 // flag-gated trailing updates of every block are enqueued up front on the side stream.  No host events inside the factorisation.
 static size_t chol_abort_word(int T) { return (size_t)T * (CH_PANELS + 7) + (size_t)T * T * (CH_PANELS + 1); }   // see the layout in cholesky_dataflow
-static size_t chol_flag_words(int T) { return chol_abort_word(T) + 8; }   // abort word + the executor's queue cursors
+static size_t chol_inv_word(int T) { return chol_abort_word(T) + 8; }      // the inverse queue's counters: 4 words per tile (i, j)
+static size_t chol_flag_words(int T) { return chol_inv_word(T) + (size_t)4 * T * T; }   // abort word + the executor's queue cursors + those
 static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T);
 static CholFlags chol_flags_layout(bohip_gp* g, int T) { return chol_flags_layout_at(g->dchol_flags, g->dchol_idl, T); }
 static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T) {
@@ -726,7 +737,8 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
 //   tile (i, c), i >= c+2:  ver = xp[((c-1) T + i) 8 + 0], pver = xp[.. + 1]   (the chain uses xp[(k T + i) 8 + p] for i = k+1, k+2 only)
 //   tile (c+1, c):          ver = farall[c], pver = fol[c];      tile (c, c):  ver = colall[c], pver = col[c]
 //   sver(i, k) = colr[k T + i];   queue cursors = the four words behind the abort word
-static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_base, int64_t ld, int T, int CH_NSF, std::vector<ExTask>& all, int* qbeg) {
+static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsigned* flag_base, int64_t ld, int T, int CH_NSF, int inv_g,
+                           std::vector<ExTask>& all, int* qbeg) {
     const CholFlags fl = chol_flags_layout_at(flag_base, nullptr, T);
     auto widx = [&](const unsigned* p) { return (uint32_t)(p - flag_base); };
     auto nb = [](int c) { return std::max(c / 4 - 1, 0); };         // bulk groups that touch column c
@@ -826,8 +838,88 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
     for (int m = 0; 4 * m + 8 <= T - 1; ++m)
         for (int c = 4 * m + 8; c < T; ++c)
             for (int i = c; i < T; ++i)
-                add(3, Sp(i, 4 * m), Sp(c, 4 * m), Ap(i, c), nullptr, 4 * CPB, 4 * CPB, i == c, 1,
+                add(EX_QBULK, Sp(i, 4 * m), Sp(c, 4 * m), Ap(i, c), nullptr, 4 * CPB, 4 * CPB, i == c, 1,
                     {{sver(i, 4 * m + 3), 16u}, {sver(c, 4 * m + 3), 16u}, {ver(i, c), 16u * (unsigned)m}}, ver(i, c), EX_NONE);
+    // Queues 3 (EX_QROWS) and 5 (EX_QWAVE): W = L^-1 behind the chain (inv_g > 0: blocks per piece of the long contraction = chunk size G).
+    //   Z(i, j) = -sum_{k=j}^{i-1} L(i, k) W(k, j)   accumulated in place at W(i, j), in k order, from three kinds of pieces:
+    //       wave m     chunk m = blocks [G m, G (m+1)), pushed to EVERY row i >= G (m+1) + 1 as soon as the chunk's rows of W are
+    //                  final (right-looking: queue 5, lowest priority -- thousands of independent K = 128 G tasks per wave)
+    //       partial    what is left of row i's own chunk, [G m_i, i-1), m_i = (i-1) / G
+    //       last       {i-1}: the only piece that needs row i-1 of W; it also stores Z' to the mirror tile (j, i) of W
+    //   W(i, j) = W_ii Z(i, j)                        A = W_ii, B = Z' (K-major), result to W(i, j) and transposed to W'(j, i)
+    // partial, last and the product form the row-to-row chain (queue 3, ABOVE the bulk updates: per row one K = 128 task + the product,
+    // little work but serial -- starved behind the bulk it started when the bulk ended and the waves with it;
+    // in ONE queue with the waves every row waited behind a whole wave).  Counters, 4 words per tile behind the queue cursors:
+    // [0] zver = rounds on Z (16 each), [1] zt = Z' complete, [2] wfin.  Everything a record waits for is earlier in its queue, in
+    // another queue or the chain's; nothing outside these two queues ever waits for them.
+    if (inv_g > 0) {
+        const int G = inv_g;
+        const uint32_t ivb = (uint32_t)chol_inv_word(T);
+        auto iw = [&](int i, int j, int w) { return ivb + (uint32_t)(((size_t)i * T + j) * 4 + w); };
+        auto chain_row = [&](int kk, int r) { return Dep{widx(fl.xp + ((size_t)kk * T + r) * CH_PANELS + (CH_PANELS - 1)), 1u}; };
+        auto l_final = [&](int i, int k) {   // row i of L complete up to block k (rows are solved in block order)
+            return i <= k + 2 ? chain_row(k, i) : Dep{sver(i, k), 16u};
+        };
+        auto w_final = [&](int k, int j) { return k > j ? Dep{iw(k, j, 2), 16u} : Dep{widx(fl.solved + j), 1u}; };   // W(k, j); the diagonal tile is the inverter's
+        auto add_inv = [&](int qi, const double* A, const double* B, double* C, double* CTb, int kc, int mode, std::initializer_list<Dep> deps,
+                           uint32_t s0, uint32_t s1) {
+            for (int h = 0; h < 2; ++h) {
+                ExTask t{};
+                t.A = A; t.B = B + (int64_t)h * CTILE * ld; t.C = C + h * CTILE; t.P = CTb ? CTb + (int64_t)h * CTILE * ld : nullptr;
+                int nd = 0;
+                for (int d = 0; d < EX_NDEP; ++d) { t.dep_idx[d] = EX_NONE; t.dep_want[d] = 0; }
+                for (const Dep& d : deps) {
+                    if (d.idx == EX_NONE || d.want == 0) continue;
+                    t.dep_idx[nd] = d.idx; t.dep_want[nd] = d.want; ++nd;
+                }
+                t.sig_idx[0] = s0; t.sig_idx[1] = s1;
+                t.kc = kc; t.diag_h = -1; t.rmw = mode | (CTb ? 4 : 0); t.prio = 0; t.kc_split = 0;
+                t.dep2_idx[0] = t.dep2_idx[1] = EX_NONE;
+                q[qi].push_back(t);
+            }
+        };
+        auto Wp = [&](int i, int j) { return dW + (int64_t)i * TILE * ld + (int64_t)j * TILE; };
+        auto WTp = [&](int j, int i) { return dWT + (int64_t)j * TILE * ld + (int64_t)i * TILE; };
+        auto m_of = [&](int i) { return (i - 1) / G; };                                       // row i's own (incomplete) chunk
+        auto n_waves = [&](int i, int j) { return std::max(0, m_of(i) - j / G); };           // wave pieces tile (i, j) receives
+        auto has_partial = [&](int i, int j) { return G * m_of(i) < i - 1 && j < i - 1; };
+        auto zdep = [&](int i, int j, int n) { return Dep{n ? iw(i, j, 0) : EX_NONE, 16u * (unsigned)n}; };
+        auto wave = [&](int m) {   // after the product of row G (m+1) - 1
+            const int k1 = G * (m + 1);
+            for (int i = k1 + 1; i < T; ++i)
+                for (int j = 0; j < k1; ++j) {
+                    const int a = std::max(j, G * m), nbf = j >= G * m ? 0 : m - j / G;
+                    add_inv(EX_QWAVE, Sp(i, a), WTp(j, a), Wp(i, j), nullptr, (k1 - a) * CPB, nbf == 0 ? 2 : 1,
+                            {l_final(i, k1 - 1), w_final(k1 - 1, j), zdep(i, j, nbf)}, iw(i, j, 0), EX_NONE);
+                }
+        };
+        auto partial = [&](int i) {
+            const int k0 = G * m_of(i);
+            for (int j = 0; j < i - 1; ++j) {
+                if (!has_partial(i, j)) continue;
+                const int a = std::max(j, k0), nbf = n_waves(i, j);
+                add_inv(EX_QROWS, Sp(i, a), WTp(j, a), Wp(i, j), nullptr, (i - 1 - a) * CPB, nbf == 0 ? 2 : 1,
+                        {l_final(i, i - 2), w_final(i - 2, j), zdep(i, j, nbf)}, iw(i, j, 0), EX_NONE);
+            }
+        };
+        auto last = [&](int i) {
+            for (int j = 0; j < i; ++j) {
+                const int nbf = n_waves(i, j) + (has_partial(i, j) ? 1 : 0);
+                add_inv(EX_QROWS, Sp(i, i - 1), WTp(j, i - 1), Wp(i, j), Wp(j, i), CPB, nbf == 0 ? 2 : 1,
+                        {l_final(i, i - 1), w_final(i - 1, j), zdep(i, j, nbf)}, iw(i, j, 0), iw(i, j, 1));
+            }
+        };
+        auto product = [&](int i) {
+            for (int j = 0; j < i; ++j)
+                add_inv(EX_QROWS, Wp(i, i), Wp(j, i), Wp(i, j), WTp(j, i), CPB, 0, {Dep{iw(i, j, 1), 16u}, Dep{widx(fl.solved + i), 1u}}, iw(i, j, 2), EX_NONE);
+        };
+        for (int i = 1; i < T; ++i) {
+            if (i + 1 < T) partial(i + 1);
+            last(i);
+            product(i);
+            if ((i + 1) % G == 0) wave((i + 1) / G - 1);
+        }
+    }
     all.clear();
     qbeg[0] = 0;
     for (int qi = 0; qi < EX_NQ; ++qi) {
@@ -836,9 +928,9 @@ static void exec_task_list(double* dL, double* dS, double* dW, unsigned* flag_ba
     }
 }
 static int build_exec_tasks(bohip_gp* g, int T) {
-    if (g->ex_T == T && g->dex_tasks && g->ex_nsf == g_chol_nsf) return 0;
+    if (g->ex_T == T && g->dex_tasks && g->ex_nsf == g_chol_nsf && g->ex_inv_g == g_chol_inv_g) return 0;
     std::vector<ExTask> all;
-    exec_task_list(g->dL, g->dS, g->dW, g->dchol_flags, g->ld, T, g_chol_nsf, all, g->ex_qbeg);
+    exec_task_list(g->dL, g->dS, g->dW, g->dWT, g->dchol_flags, g->ld, T, g_chol_nsf, g_chol_inv_g, all, g->ex_qbeg);
     if (all.size() > g->ex_cap) {
         if (g->dex_tasks) hipFree(g->dex_tasks);
         g->dex_tasks = nullptr; g->ex_cap = 0;
@@ -849,6 +941,7 @@ static int build_exec_tasks(bohip_gp* g, int T) {
     HIPCHK(hipStreamSynchronize(g->stream));   // `all` is pageable host memory that dies with this frame
     g->ex_T = T;
     g->ex_nsf = g_chol_nsf;
+    g->ex_inv_g = g_chol_inv_g;
     return 0;
 }
 
@@ -873,7 +966,9 @@ static int cholesky_exec(bohip_gp* g, int T) {
         q.spin_ticks = g_chol_spin_ticks;
         q.fill = g_chol_exec_fill;
         q.nurgent = std::min(g_chol_exec_wgs / 2, g_chol_exec_urgent);
-        q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[3] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
+        q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
+        q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
+        q.fill_inv = g_chol_exec_fill_inv;
         HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
         hipLaunchKernelGGL(k_chol_exec, dim3(g_chol_exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
         HIPCHK(hipGetLastError());
@@ -883,6 +978,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
     hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
     HIPCHK(hipGetLastError());
     g->w_seeded = true;
+    g->w_done = T > 3 && g->ex_qbeg[EX_QROWS + 1] > g->ex_qbeg[EX_QROWS];
     return 0;
 }
 
@@ -949,10 +1045,12 @@ static int refit_once(bohip_gp* g, double jitter) {
         if (g_chol_df_skip.compare_exchange_weak(sk, sk - 1, std::memory_order_relaxed)) { paused = true; break; }
     const bool want_df = !paused &&
                          ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP));
-    const bool exec_ok = g_chol_exec && T >= std::max(4, g_chol_exec_min) && cus >= 9 + g_chol_nsf + 8;
+    const int exec_min = g_chol_exec_min >= 0 ? g_chol_exec_min : (g_chol_inv_g > 0 ? 4 : 32);
+    const bool exec_ok = g_chol_exec && T >= std::max(4, exec_min) && cus >= 9 + g_chol_nsf + 8;
     const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
     const bool form1_ok = cus >= 8 + 3 * std::max(0, T - 3) + 8;
     if (want_df && (exec_ok || form2_ok || form1_ok)) {
+        g->w_done = false;
         if (exec_ok) { g->chol_form_last = 4; CHK(cholesky_exec(g, T)); }
         else if (form2_ok && g_chol_df2_ll) { g->chol_form_last = 3; CHK(cholesky_dataflow3(g, T)); }
         else if (form2_ok) { g->chol_form_last = 2; CHK(cholesky_dataflow2(g, T)); }
@@ -963,7 +1061,8 @@ static int refit_once(bohip_gp* g, double jitter) {
             hipLaunchKernelGGL(k_inv128, dim3(T), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, g->dL, ld, g->dW, g->dWT, ld);
             HIPCHK(hipGetLastError());
         }
-        for (int h = 1; h < T; h *= 2) CHK(inverse_level(g, g->stream, 0, T, h));
+        if (!g->w_done)
+            for (int h = 1; h < T; h *= 2) CHK(inverse_level(g, g->stream, 0, T, h));
         t_end(g);
         t_begin(g, "alpha");
         CHK(compute_alpha(g));
@@ -2230,18 +2329,20 @@ int bohip_debug_read_w(bohip_gp* g, int which, double* out) {
 // out: n x 16 uint64 words (the 128-byte records); returns the number of records, qbeg[0..4] the queue boundaries,
 // layout[0..9] the word offsets of panel, solved, crit, rest, col, farall, fol, colall, colr, xp inside the flag area;
 // layout[10] the number of solve-follower workgroups of the chain kernel (CH_NSF).
-int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base_S, uint64_t base_W, uint64_t* out, int64_t cap,
-                               int* qbeg, int64_t* layout) {
+int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base_S, uint64_t base_W, uint64_t base_WT, int inv_g, uint64_t* out,
+                               int64_t cap, int* qbeg, int64_t* layout) {
     std::vector<bohip::ExTask> all;
     int qb[bohip::EX_NQ + 1];
     unsigned* fb = reinterpret_cast<unsigned*>(uintptr_t(1) << 40);
-    exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W), fb, ld, T, g_chol_nsf, all, qb);
+    exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W),
+                   reinterpret_cast<double*>(base_WT), fb, ld, T, g_chol_nsf, inv_g, all, qb);
     for (int i = 0; i <= bohip::EX_NQ; ++i) qbeg[i] = qb[i];
     const bohip::CholFlags fl = chol_flags_layout_at(fb, nullptr, T);
     const unsigned* ptrs[10] = {fl.panel, fl.solved, fl.crit, fl.rest, fl.col, fl.farall, fl.fol, fl.colall, fl.colr, fl.xp};
     for (int i = 0; i < 10; ++i) layout[i] = ptrs[i] - fb;
     if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(bohip::CH_NSF_MAX, std::max(1, atoi(e)));
     layout[10] = g_chol_nsf;
+    layout[11] = (int64_t)chol_inv_word(T);
     if ((int64_t)all.size() <= cap && out) std::memcpy(out, all.data(), all.size() * sizeof(bohip::ExTask));
     return (int64_t)all.size();
 }

@@ -24,6 +24,13 @@
 //            (K = 128 .. 640; depends on S only, two blocks of slack) -- takes the long contraction off the critical path
 //   queue 3  bulk: group m (blocks 4m .. 4m+3, K = 512) applied to every tile of the columns >= 4m+8, column-major, so that
 //            the four columns the chain reaches next are done first
+//   queue 4  the triangular inverse W = L^-1 (what the scoring path contracts with), grown row by row BEHIND the chain instead
+//            of after the factorisation: W(i, j) = W_ii Z(i, j), Z(i, j) = -sum_{k=j}^{i-1} L(i, k) W(k, j).  Row i needs row i of L
+//            (final one block before pivot i) and the rows < i of W, so its work (~ i^2) becomes available as the factorisation's
+//            own work (~ (T-k)^2 per block) dries up: the two fill each other's idle time.  Nothing outside this queue ever
+//            waits for it.  Z is accumulated in place (pieces of <= G blocks, in order), its last piece also stores Z' to the
+//            mirror tile of W (strictly upper: never read by anybody else), from where the product with W_ii reads it as the
+//            K-major operand; that product stores W(i, j) and the same entries as W'(j, i).
 //
 // Dependencies are counters in the flag area (one word per producer granule, each finished task adds 8 = its waves):
 //   ver(i, c)   read-modify-write rounds completed on tile (i, c): bulk group m needs 16 m, Late needs 16 (number of groups)
@@ -41,19 +48,23 @@ namespace bohip {
 
 constexpr unsigned EX_NONE = 0xffffffffu;
 constexpr int EX_NDEP = 6;
-constexpr int EX_NQ = 4;
+constexpr int EX_TRACE_CAP = 1 << 18;   // (trace build only)
+constexpr int EX_NQ = 6;
+constexpr int EX_QROWS = 3;     // the triangular inverse W = L^-1 grown behind the chain: its row-to-row chain (little work, but serial: ABOVE the bulk)
+constexpr int EX_QBULK = 4;     // bulk updates
+constexpr int EX_QWAVE = 5;     // the inverse's waves (most of its work, independent tasks: lowest priority, and what a waiting workgroup fills in)
 
 struct ExTask {                 // 128 bytes, written by the host once per (handle, T), never modified on the device
     const double* A;            // [128][16 kc]  K-major, row stride ld
     const double* B;            // [64][16 kc]
     double* C;                  // [128][64]
-    const double* P;            // optional: C -= P as well
+    const double* P;            // optional: C -= P as well; with rmw bit 2: NOT an operand but the [64][128] block that receives the transposed result
     uint32_t dep_idx[EX_NDEP];  // word index into the flag area, EX_NONE = unused
     uint32_t dep_want[EX_NDEP];
     uint32_t sig_idx[2];        // counters every wave adds 1 to once its stores have landed
     int32_t kc;                 // 16-deep contraction chunks
     int32_t diag_h;             // -1, or this task is half `diag_h` of a DIAGONAL tile: entries with 64 h + c > r stay untouched
-    int32_t rmw;                // 1: C = C - A B' - P;  0: C = A B'
+    int32_t rmw;                // bits 0-1: 1: C = C - A B' - P;  0: C = A B';  2: C = -A B'.   bit 2: the result also goes out transposed, to P
     int32_t prio;               // s_setprio of the task's waves: the chain waits for queue 0, so its tasks win the matrix pipe of a shared CU
     int32_t kc_split;           // > 0: the contraction runs in two pieces, chunks [0, kc_split) at once and [kc_split, kc) once the
     uint32_t dep2_idx[2];       //      counters dep2 have arrived (waited for INSIDE the task: the three tiles the chain waits for start on
@@ -71,6 +82,7 @@ struct ExQueues {
     int64_t ld;
     unsigned long long spin_ticks;   // a workgroup that finds no runnable task for this long gives up (see flag_wait_ge)
     int nurgent;                // workgroups 0 .. nurgent-1 serve the urgent queue (and nothing else until it is exhausted)
+    int fill_inv;               // ... and inverse-wave work (1), see k_chol_exec
     int fill;                   // a workgroup that holds a claimed task whose counters are not in yet takes bulk work meanwhile:
                                 // 1 = if the held task is an Early sum (queue 2: two blocks of slack), 2 = also for queue 1, 0 = never
     int stride[EX_NQ];          // records per claim: 1, or 2 = both halves of a tile run back to back by one workgroup (the look and
@@ -124,10 +136,10 @@ __device__ __forceinline__ int ex_claim(const ExQueues& q, int qi, unsigned h_se
     ready = (c == h_seen && ntile == 1) || ex_ready_once(q, q.tasks + q.qbeg[qi] + c, ntile, lane);
     return q.qbeg[qi] + (int)c;
 }
-// Look at the heads of the queues `qlo` .. `qhi` (lane 8 q + d: counter d of queue q's head record) and claim from the first one
+// Look at the heads of the queues in `qmask` (lane 8 q + d: counter d of queue q's head record) and claim from the first one
 // whose head is runnable.  wait = true: stay until something could be claimed; -1 = every queue exhausted (or abort).
 // wait = false: one look; -3 = nothing runnable right now.
-__device__ __forceinline__ int ex_pick(const ExQueues& q, int lane, bool& ready, int qlo, int qhi, bool wait) {
+__device__ __forceinline__ int ex_pick(const ExQueues& q, int lane, bool& ready, unsigned qmask, bool wait) {
     const int qi = lane >> 3, d = lane & 7;
     const unsigned long long t_idle = wall_clock64();
     int backoff = 1;
@@ -137,7 +149,7 @@ __device__ __forceinline__ int ex_pick(const ExQueues& q, int lane, bool& ready,
             n = (unsigned)(q.qbeg[qi + 1] - q.qbeg[qi]);
             h = __hip_atomic_load(q.heads + qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        const bool live = qi >= qlo && qi <= qhi && qi < EX_NQ && h < n;
+        const bool live = qi < EX_NQ && ((qmask >> qi) & 1u) != 0u && h < n;
         const bool pending = live && d < EX_NDEP && ex_dep_pending(q.tasks + q.qbeg[qi] + h, d, q.flags);
         const unsigned long long lv = __ballot(live), pd = __ballot(pending);
         if (lv == 0ull) return wait ? -1 : -3;
@@ -163,7 +175,7 @@ __device__ __forceinline__ int ex_pick(const ExQueues& q, int lane, bool& ready,
 }
 
 #if BOHIP_CHOL_TRACE
-__device__ unsigned long long g_ex_trace[65536 * 8];   // per task: looking since | claimed and runnable | finished | workgroup | second-stage counters in | main loop done
+__device__ unsigned long long g_ex_trace[EX_TRACE_CAP * 8];   // per task: looking since | claimed and runnable | finished | workgroup | second-stage counters in | main loop done
 #endif
 // The look for the NEXT task rides on this task's epilogue (do_look): wave 0 reads the queue heads while the tile goes through
 // LDS, the head records' counters' names while the old tile value is fetched, the counters while the stores drain -- three
@@ -203,12 +215,12 @@ __device__ __forceinline__ int ex_run(const ExTask& t, const ExQueues& q, double
         }
         __syncthreads();
 #if BOHIP_CHOL_TRACE
-        if (tid == 0 && trace_slot >= 0 && trace_slot < 65536) g_ex_trace[8 * trace_slot + 4] = wall_clock64();
+        if (tid == 0 && trace_slot >= 0 && trace_slot < EX_TRACE_CAP) g_ex_trace[8 * trace_slot + 4] = wall_clock64();
 #endif
     }
     gemm_tile_loop_glds3_ks<4, 0, true>(t.A, ld, t.B, ld, ksp, t.kc, smem, acc, TILE, 1 << 30, tid);
 #if BOHIP_CHOL_TRACE
-    if (tid == 0 && trace_slot >= 0 && trace_slot < 65536) g_ex_trace[8 * trace_slot + 5] = wall_clock64();
+    if (tid == 0 && trace_slot >= 0 && trace_slot < EX_TRACE_CAP) g_ex_trace[8 * trace_slot + 5] = wall_clock64();
 #endif
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wr = (wave & 3) >> 1, wc = wave & 1;
     const bool looker = do_look && tid < 64;
@@ -239,11 +251,12 @@ __device__ __forceinline__ int ex_run(const ExTask& t, const ExQueues& q, double
         }
     }
     constexpr int NP = (TILE * CTILE / 2) / GEMM_THREADS_8;   // 8 pieces per thread
-    const int rmw = t.rmw, dh = t.diag_h;
-    const double* P = t.P;
+    const int rmw = t.rmw & 3, dh = t.diag_h;
+    const bool has_ct = (t.rmw & 4) != 0;
+    const double* P = has_ct ? nullptr : t.P;
     double* C = t.C;
     d2 oldv[NP], pv[NP];
-    if (rmw) {
+    if (rmw == 1) {
 #pragma unroll
         for (int u = 0; u < NP; ++u) {
             const int piece = tid + GEMM_THREADS_8 * u, r = piece >> 5, c = (piece & 31) * 2;
@@ -273,16 +286,40 @@ __device__ __forceinline__ int ex_run(const ExTask& t, const ExQueues& q, double
         const bool k0 = !(dh >= 0 && CTILE * dh + c > r), k1 = !(dh >= 0 && CTILE * dh + c + 1 > r);
         if (!k0) continue;   // (k1 implies k0): the strict upper triangle of a diagonal tile stays zero
         d2 v = *reinterpret_cast<const d2*>(Tl + r * TS + c);
-        if (rmw) {
+        if (rmw == 1) {
             v.x = oldv[u].x - v.x;
             v.y = oldv[u].y - v.y;
             if (P) {
                 v.x -= pv[u].x;
                 v.y -= pv[u].y;
             }
+        } else if (rmw == 2) {
+            v.x = -v.x;
+            v.y = -v.y;
         }
+        oldv[u] = v;   // (kept for the transposed copy)
         if (k1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
         else __hip_atomic_store(dst, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (has_ct) {
+        // the same values once more as a [64][128] block (rows = the tile's columns): through LDS again, so that they leave as
+        // 16-byte pieces, 1 KB contiguous per wave instruction (never a diagonal tile)
+        constexpr int TST = TILE + 2;
+        __syncthreads();   // every thread has read its pieces of Tl
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int piece = tid + GEMM_THREADS_8 * u, r = piece >> 5, c = (piece & 31) * 2;
+            Tl[c * TST + r] = oldv[u].x;
+            Tl[(c + 1) * TST + r] = oldv[u].y;
+        }
+        __syncthreads();
+        double* CTp = const_cast<double*>(t.P);
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int piece = tid + GEMM_THREADS_8 * u, cr = piece >> 6, rr = (piece & 63) * 2;
+            const d2 v = *reinterpret_cast<const d2*>(Tl + cr * TST + rr);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(CTp + (int64_t)cr * ld + rr), "v"(v) : "memory");
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // landed (a workgroup-scope fence emits no such wait)
     if (lane == 0) {
@@ -325,8 +362,11 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
     __shared__ int s_pend;     // a claimed task of the queues 1 .. EX_NQ-2 whose counters were not in when last looked at
     __shared__ int s_pend2;    // the same for a bulk claim (queue EX_NQ-1)
     __shared__ int s_pend2n;   //   records of that bulk claim still to run (0: the whole claim)
+    __shared__ int s_pend3;    // a claimed record of the inverse queue whose counters are not in: held in a slot of its own that
+                               // restricts nothing -- no other queue and not the chain ever waits for an inverse record, so a
+                               // workgroup holding one goes on claiming everywhere else
     __shared__ int s_urgent;
-    if (threadIdx.x == 0) { s_look = -1; s_pend = -1; s_pend2 = -1; s_pend2n = 0; s_urgent = (int)blockIdx.x < q.nurgent; }
+    if (threadIdx.x == 0) { s_look = -1; s_pend = -1; s_pend2 = -1; s_pend2n = 0; s_pend3 = -1; s_urgent = (int)blockIdx.x < q.nurgent; }
     __syncthreads();
     // The urgent queue (~10 tasks per block: what the chain kernel reads next) has its own workgroups: each takes the next urgent
     // task with a fetch-and-add AHEAD of time and waits for its counters, so the task starts the moment they arrive -- no look, no
@@ -342,10 +382,15 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
             int pl = threadIdx.x;
             asm volatile("" : "+v"(pl));   // opaque: the look's lane arithmetic must not be kept alive across the task
             int run = -1, run_n = 0;   // run_n > 0: only that many records (the rest of a bulk claim that was interrupted)
-            int look = s_look, pend = s_pend, pend2 = s_pend2, pend2_n = s_pend2n;
+            int look = s_look, pend = s_pend, pend2 = s_pend2, pend2_n = s_pend2n, pend3 = s_pend3;
             bool urgent_wg = s_urgent != 0;
             const unsigned long long t_wait = wall_clock64();
-            auto queue_of = [&](int t) { return t >= q.qbeg[2] ? (t >= q.qbeg[3] ? 3 : 2) : (t >= q.qbeg[1] ? 1 : 0); };
+            auto queue_of = [&](int t) {
+                int qq = 0;
+#pragma unroll
+                for (int c = 1; c < EX_NQ; ++c) qq = t >= q.qbeg[c] ? c : qq;
+                return qq;
+            };
             auto in_hand_ready = [&](int t) { const int qt = queue_of(t); return ex_ready_once(q, q.tasks + t, ex_ntile(q, qt, (unsigned)(t - q.qbeg[qt])), pl); };
             if (urgent_wg) {
                 unsigned c = 0;
@@ -363,22 +408,33 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                 if (pend2 >= 0 && (pend2_n > 0 ? ex_ready_once(q, q.tasks + pend2, 1, pl) : in_hand_ready(pend2))) {
                     run = pend2; run_n = pend2_n; pend2 = -1; pend2_n = 0; break;
                 }
+                if (pend3 >= 0 && in_hand_ready(pend3)) { run = pend3; pend3 = -1; break; }
                 bool rdy = true;
                 int tk = -3;
+                // which queues may this workgroup claim from right now?  one held record per slot: `pend` (queues 1, 2), `pend2`
+                // (bulk), `pend3` (inverse: rows or waves).  While `pend` is occupied only fill-in work is taken: inverse waves
+                // (nothing ever waits for those), bulk if asked for (q.fill).
+                unsigned qmask = 0u;
                 if (pend < 0) {
-                    // the first slot is free: claim as usual (a bulk claim only if the second slot is free too)
-                    const int qhi = pend2 < 0 ? EX_NQ - 1 : EX_NQ - 2;
-                    if (look >= 0 && (look >> 24) <= qhi) { tk = ex_claim(q, look >> 24, (unsigned)(look & 0xffffff), pl, rdy); if (tk == -2) tk = -3; }
+                    qmask = 6u;
+                    if (pend3 < 0) qmask |= 1u << EX_QROWS;
+                    if (pend2 < 0) qmask |= 1u << EX_QBULK;
+                    if (pend3 < 0 && pend2 < 0) qmask |= 1u << EX_QWAVE;
+                } else {
+                    if (pend2 < 0 && (q.fill >= 2 || (q.fill == 1 && queue_of(pend) == 2))) qmask |= 1u << EX_QBULK;
+                    if (pend3 < 0 && q.fill_inv) qmask |= 1u << EX_QWAVE;
+                }
+                const bool nothing_held = pend < 0 && pend2 < 0 && pend3 < 0;
+                if (qmask != 0u) {
+                    if (look >= 0 && ((qmask >> (look >> 24)) & 1u)) { tk = ex_claim(q, look >> 24, (unsigned)(look & 0xffffff), pl, rdy); if (tk == -2) tk = -3; }
                     look = -1;
-                    if (tk == -3) tk = ex_pick(q, pl, rdy, 1, qhi, pend2 < 0);
+                    if (tk == -3) tk = ex_pick(q, pl, rdy, qmask, nothing_held);
                     if (tk == -1) { run = -1; break; }     // every queue exhausted (nothing held either), or abort
-                } else if (pend2 < 0 && (q.fill >= 2 || (q.fill == 1 && queue_of(pend) == 2))) {
-                    // a patient task is held: bulk work meanwhile, if there is some right now
-                    tk = ex_pick(q, pl, rdy, EX_NQ - 1, EX_NQ - 1, false);
                 }
                 if (tk >= 0) {
                     if (rdy) { run = tk; break; }
-                    if (queue_of(tk) == EX_NQ - 1) pend2 = tk; else pend = tk;
+                    const int qt = queue_of(tk);
+                    if (qt == EX_QROWS || qt == EX_QWAVE) pend3 = tk; else if (qt == EX_QBULK) pend2 = tk; else pend = tk;
                     continue;
                 }
                 if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { run = -1; break; }
@@ -389,14 +445,16 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                 }
                 __builtin_amdgcn_s_sleep(8);
             }
-            if (pl == 0) { s_task = run; s_cnt = run_n; s_look = -1; s_pend = pend; s_pend2 = pend2; s_pend2n = pend2_n; s_urgent = urgent_wg ? 1 : 0; }
+            if (pl == 0) { s_task = run; s_cnt = run_n; s_look = -1; s_pend = pend; s_pend2 = pend2; s_pend2n = pend2_n; s_pend3 = pend3; s_urgent = urgent_wg ? 1 : 0; }
         }
         __syncthreads();
         const int ti = __builtin_amdgcn_readfirstlane(s_task);
         const int tn = __builtin_amdgcn_readfirstlane(s_cnt);
         __syncthreads();
         if (ti < 0) break;
-        const int qi_ = ti >= q.qbeg[2] ? (ti >= q.qbeg[3] ? 3 : 2) : (ti >= q.qbeg[1] ? 1 : 0);
+        int qi_ = 0;
+#pragma unroll
+        for (int c = 1; c < EX_NQ; ++c) qi_ = ti >= q.qbeg[c] ? c : qi_;
         const int pair = tn > 0 ? tn : min(q.stride[qi_], q.qbeg[qi_ + 1] - ti);
         for (int u = 0; u < pair; ++u) {
             int tid = threadIdx.x;
@@ -409,7 +467,7 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
             // between the records of a bulk claim: has the task held in the first slot become runnable?  then it goes first and
             // the rest of the claim waits in the second slot (a held task is never delayed by more than one record, ~65 us)
             int cut = 0;
-            if (u + 1 < pair && qi_ == EX_NQ - 1 && threadIdx.x < 64) {
+            if (u + 1 < pair && qi_ == EX_QBULK && threadIdx.x < 64) {
                 int pl = threadIdx.x;
                 asm volatile("" : "+v"(pl));
                 const int pend = s_pend;
@@ -423,13 +481,13 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                 }
             }
             __syncthreads();   // the LDS tile is rewritten by the next task's DMA
-            if (u + 1 < pair && qi_ == EX_NQ - 1) {
+            if (u + 1 < pair && qi_ == EX_QBULK) {
                 const int c_ = __builtin_amdgcn_readfirstlane(s_cut);
                 __syncthreads();
                 if (c_) break;
             }
 #if BOHIP_CHOL_TRACE
-            if (threadIdx.x == 0 && ti + u < 65536) {
+            if (threadIdx.x == 0 && ti + u < EX_TRACE_CAP) {
                 g_ex_trace[8 * (ti + u)] = u == 0 ? tr0 : tr1; g_ex_trace[8 * (ti + u) + 1] = tr1; g_ex_trace[8 * (ti + u) + 2] = wall_clock64();
                 g_ex_trace[8 * (ti + u) + 3] = blockIdx.x;
             }

@@ -18,23 +18,25 @@ import numpy as np
 import pytest
 
 TILE, CT, KC, NONE = 128, 64, 16, 0xFFFFFFFF
-NQ = 4   # queues: urgent | solve + late | early | bulk
-BASE_L, BASE_S, BASE_W = 1 << 44, 2 << 44, 3 << 44
+NQ = 6   # queues: urgent | solve + late | early | inverse: row chain | bulk | inverse: waves
+BASE_L, BASE_S, BASE_W, BASE_WT = 1 << 44, 2 << 44, 3 << 44, 4 << 44
+INV_G = 2   # blocks per piece of the inverse queue's long contractions (small, so that multi-piece tiles occur at test sizes)
 
 
-def get_tasks(T, ld):
+def get_tasks(T, ld, inv_g=INV_G):
     from bohip import _lib
 
     lib = C.CDLL(_lib.LIB_PATH)
     f = lib.bohip_debug_exec_tasks
     f.restype = C.c_int64
-    f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
-    qbeg = (C.c_int * 5)()
-    layout = (C.c_int64 * 11)()
-    n = f(T, ld, BASE_L, BASE_S, BASE_W, None, 0, qbeg, layout)
+    f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int),
+                  C.POINTER(C.c_int64)]
+    qbeg = (C.c_int * (NQ + 1))()
+    layout = (C.c_int64 * 12)()
+    n = f(T, ld, BASE_L, BASE_S, BASE_W, BASE_WT, inv_g, None, 0, qbeg, layout)
     buf = np.zeros((n, 16), dtype=np.uint64)
-    assert f(T, ld, BASE_L, BASE_S, BASE_W, buf.ctypes.data_as(C.c_void_p), n, qbeg, layout) == n
-    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp", "nsf"]
+    assert f(T, ld, BASE_L, BASE_S, BASE_W, BASE_WT, inv_g, buf.ctypes.data_as(C.c_void_p), n, qbeg, layout) == n
+    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp", "nsf", "inv"]
     return buf, list(qbeg), dict(zip(names, layout))
 
 
@@ -44,7 +46,7 @@ def decode(rec):
     t["dep"] = [(int(w[8 + d]), int(w[14 + d])) for d in range(6) if int(w[8 + d]) != NONE]
     t["sig"] = [int(w[20 + s]) for s in range(2) if int(w[20 + s]) != NONE]
     i32 = rec.view(np.int32)
-    t["kc"], t["diag_h"], t["rmw"] = int(i32[22]), int(i32[23]), int(i32[24])
+    t["kc"], t["diag_h"], t["rmw"], t["ct"] = int(i32[22]), int(i32[23]), int(i32[24]) & 3, (int(i32[24]) & 4) != 0
     t["kc_split"] = int(i32[26])
     t["dep2"] = [(int(w[27 + s]), int(w[29 + s])) for s in range(2) if int(w[27 + s]) != NONE]
     if t["kc_split"] == 0:
@@ -52,21 +54,29 @@ def decode(rec):
     return t
 
 
-def replay(T, order, seed=0):
+def replay(T, order, seed=0, inv_g=INV_G):
     ld = TILE * T + 16
     N = TILE * T
     rng = np.random.default_rng(seed)
-    recs, qbeg, lay = get_tasks(T, ld)
+    recs, qbeg, lay = get_tasks(T, ld, inv_g)
     tasks = [decode(r) for r in recs]
     # a well-conditioned SPD matrix (kernel matrix of random points + noise), lower triangle only -- as k_build_cov leaves it
     X = rng.random((N, 3))
     d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
     K = np.exp(-0.5 * d2 / 0.09) + 0.05 * np.eye(N)
-    mats = {BASE_L: np.zeros((ld, ld)), BASE_S: np.zeros((ld, ld)), BASE_W: np.zeros((ld, ld))}
+    mats = {BASE_L: np.zeros((ld, ld)), BASE_S: np.zeros((ld, ld)), BASE_W: np.zeros((ld, ld)), BASE_WT: np.zeros((ld, ld))}
     mats[BASE_L][:N, :N] = np.tril(K)
     # poison what must be written before it is read
     mats[BASE_S][:] = np.nan
-    flags = np.zeros(lay["xp"] + 8 * T * T + 8, dtype=np.int64)
+    for i in range(T):   # W, W': everything but the diagonal tiles (their zero halves are relied on)
+        for j in range(T):
+            if i != j:
+                mats[BASE_W][i * TILE:(i + 1) * TILE, j * TILE:(j + 1) * TILE] = np.nan
+                mats[BASE_WT][i * TILE:(i + 1) * TILE, j * TILE:(j + 1) * TILE] = np.nan
+    flags = np.zeros(lay["inv"] + 4 * T * T, dtype=np.int64)
+    # operands of the contraction engine arrive through LDS-DMA, i.e. through caches nothing invalidates while the kernel runs:
+    # a location that was read that way must never be written afterwards
+    dma_read = {b: np.zeros((ld, ld), dtype=bool) for b in mats}
 
     def view(addr, rows, cols):
         base = addr & ~((1 << 44) - 1)
@@ -74,6 +84,15 @@ def replay(T, order, seed=0):
         r, c = divmod(off, ld)
         assert (addr - base) % 8 == 0 and base in mats and r + rows <= ld and c + cols <= ld, hex(addr)
         return mats[base][r:r + rows, c:c + cols]
+
+    def mark(addr, rows, cols, reading):
+        base = addr & ~((1 << 44) - 1)
+        r, c = divmod((addr - base) // 8, ld)
+        region = dma_read[base][r:r + rows, c:c + cols]
+        if reading:
+            region[:] = True
+        else:
+            assert not region.any(), f"write to a location an earlier task read through LDS-DMA: {hex(addr)}"
 
     def tile(base, i, j):
         return mats[base][i * TILE:(i + 1) * TILE, j * TILE:(j + 1) * TILE]
@@ -89,20 +108,28 @@ def replay(T, order, seed=0):
             assert id(t) in snap, "two-piece task ran without ever having been claimable on its first-stage counters alone"
             a1, b1 = snap[id(t)]
             assert np.array_equal(a1, A[:, :K1]) and np.array_equal(b1, B[:, :K1]), "first-piece operand changed after the claim"
+        mark(t["A"], TILE, K_, True)
+        mark(t["B"], CT, K_, True)
         prod = A @ B.T
         keep = np.ones((TILE, CT), dtype=bool)
         if t["diag_h"] >= 0:   # half of a diagonal tile: the strict upper triangle is never written (nor meaningful when read)
             keep = (CT * t["diag_h"] + np.arange(CT)[None, :]) <= np.arange(TILE)[:, None]
-        if t["rmw"]:
+        if t["rmw"] == 1:
+            assert not np.isnan(Cv[keep]).any(), "read-modify-write of a tile nobody has written"
             new = Cv - prod
-            if t["P"]:
+            if t["P"] and not t["ct"]:
                 Pv = view(t["P"], TILE, CT)
                 assert not np.isnan(Pv[keep]).any(), "P read before it was written"
                 new = new - Pv
         else:
-            assert t["P"] == 0
-            new = prod
+            assert t["P"] == 0 or t["ct"]
+            new = prod if t["rmw"] == 0 else -prod
+        mark(t["C"], TILE, CT, False)
         Cv[keep] = new[keep]
+        if t["ct"]:   # the same values once more, transposed, to the [64][128] block at P
+            assert t["diag_h"] < 0
+            mark(t["P"], CT, TILE, False)
+            view(t["P"], CT, TILE)[:, :] = new.T
         for s in t["sig"]:
             flags[s] += 8   # eight waves add one each
 
@@ -128,6 +155,7 @@ def replay(T, order, seed=0):
         Lkk = np.linalg.cholesky(np.tril(tile(BASE_L, k, k)) + np.tril(tile(BASE_L, k, k), -1).T)
         tile(BASE_L, k, k)[:, :] = Lkk
         tile(BASE_W, k, k)[:, :] = np.linalg.inv(Lkk)
+        tile(BASE_WT, k, k)[:, :] = np.linalg.inv(Lkk).T
         flags[lay["solved"] + k] = 1
         for r in (k + 1, k + 2):
             if r < T:
@@ -208,6 +236,15 @@ def replay(T, order, seed=0):
     got = np.tril(L[:N, :N])
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < 1e-12, err
+    if inv_g > 0:   # the inverse queue: W = L^-1 in the lower triangle of W, the same entries in the upper triangle of W'
+        assert qbeg[NQ] > qbeg[NQ - 1] and qbeg[4] > qbeg[3]
+        Wref = np.linalg.inv(ref)
+        W = np.tril(mats[BASE_W][:N, :N])
+        assert not np.isnan(W).any()
+        assert np.abs(W - Wref).max() / np.abs(Wref).max() < 1e-11
+        assert np.array_equal(np.triu(mats[BASE_WT][:N, :N]), W.T)
+    else:
+        assert qbeg[NQ] == qbeg[NQ - 1] and qbeg[4] == qbeg[3]
     return len(tasks)
 
 
@@ -219,7 +256,11 @@ def test_executor_records_replay_to_the_cholesky_factor(T, order):
 
 def test_executor_records_random_orders_mid_size():
     for seed in range(3):
-        replay(18, "random", seed=seed)
+        replay(18, "random", seed=seed, inv_g=(2, 3, 8)[seed])
+
+
+def test_executor_records_without_the_inverse_queue():
+    replay(9, "random", inv_g=0)
 
 
 def test_every_tile_gets_every_block_once():

@@ -57,7 +57,7 @@ def same_factor(a, b):
 
 def test_a_timed_out_dataflow_factorisation_falls_back_and_reports_it():
     """BOHIP_CHOL_SPIN_US=1 makes every in-kernel wait give up after a microsecond: the first refit of each size runs a dataflow
-    form (form 1 at N=1500, the executor at N=4300), times out, and is redone launch-chained in the same call."""
+    form (the executor), times out, and is redone launch-chained in the same call."""
     sizes = ((1500, 3), (4300, 4))
     ref, _ = run(sizes, 0, BOHIP_CHOL_DATAFLOW="0")
     got, err = run(sizes, 1, BOHIP_CHOL_SPIN_US="1")
@@ -72,8 +72,13 @@ def test_a_timed_out_dataflow_factorisation_falls_back_and_reports_it():
 
 def test_forms_are_reported_and_strict_mode_errors_instead_of_falling_back():
     got, _ = run(((1500, 3), (4300, 4)), 0)
-    assert got["1500"]["forms"] == [1] and got["4300"]["forms"] == [4]     # first dataflow form / executor (the defaults)
+    assert got["1500"]["forms"] == [4] and got["4300"]["forms"] == [4]     # the executor with its inverse queues (the default from 4 row tiles on)
     assert got["1500"]["fallbacks"] == 0 and got["4300"]["abort_tiles"] == 0
+    ref = got
+    got, _ = run(((1500, 3), (4300, 4)), 0, BOHIP_CHOL_INV_G="0")           # without them: the first dataflow form below 32 row tiles
+    assert got["1500"]["forms"] == [1] and got["4300"]["forms"] == [4]
+    for N in ("1500", "4300"):
+        same_factor(got[N], ref[N])
     o = subprocess.run([sys.executable, "-c", CODE % (ROOT, "((1500, 3),)", 0)], env=dict(os.environ, BOHIP_CHOL_SPIN_US="1", BOHIP_CHOL_DF_STRICT="1"),
                        capture_output=True, text=True, timeout=600)
     assert o.returncode != 0 and "timed out on a dependency" in o.stderr

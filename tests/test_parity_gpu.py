@@ -726,6 +726,9 @@ print("RESULT" + json.dumps(out))
         "form2-left-looking": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_DF2_MIN="4", BOHIP_CHOL_DF2_LL="1", BOHIP_CHOL_EXEC="0"),
         # csrc/kernels_exec.hip: the chain + one persistent task-executor kernel (the default from 47 row tiles on)
         "executor": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4"),
+        # the same without the inverse queues (W = L^-1 level by level after the factorisation), and with short pieces
+        "executor-inverse-after": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_G="0"),
+        "executor-inverse-pieces-of-2": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_G="2"),
     }
     res = {}
     for name, env in variants.items():

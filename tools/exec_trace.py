@@ -21,19 +21,21 @@ ld = ((N + 1 + 127) // 128) * 128 + 16
 # the records (same builder, fake addresses) tell which task is what
 f = lib.bohip_debug_exec_tasks
 f.restype = C.c_int64
-f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
-qbeg = (C.c_int * 5)(); lay = (C.c_int64 * 11)()
-n = f(T, ld, 1 << 44, 2 << 44, 3 << 44, None, 0, qbeg, lay)
+f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+NQ = 6
+INV_G = int(os.environ.get("BOHIP_CHOL_INV_G", "8"))
+qbeg = (C.c_int * (NQ + 1))(); lay = (C.c_int64 * 12)()
+n = f(T, ld, 1 << 44, 2 << 44, 3 << 44, 4 << 44, INV_G, None, 0, qbeg, lay)
 recs = np.zeros((n, 16), dtype=np.uint64)
-f(T, ld, 1 << 44, 2 << 44, 3 << 44, recs.ctypes.data_as(C.c_void_p), n, qbeg, lay)
+f(T, ld, 1 << 44, 2 << 44, 3 << 44, 4 << 44, INV_G, recs.ctypes.data_as(C.c_void_p), n, qbeg, lay)
 kc = recs.view(np.int32)[:, 22]
 ct = (C.c_ulonglong * 8192)()
 lib.bohip_debug_chol_trace_read.argtypes = [C.c_void_p, C.c_int64]
 assert lib.bohip_debug_chol_trace_read(ct, 8192) == 0
 ct = np.array(ct, dtype=np.int64)
-et = (C.c_ulonglong * (8 * min(n, 65536)))()
+et = (C.c_ulonglong * (8 * min(n, (1 << 18))))()
 lib.bohip_debug_exec_trace_read.argtypes = [C.c_void_p, C.c_int64]
-assert lib.bohip_debug_exec_trace_read(et, 8 * min(n, 65536)) == 0
+assert lib.bohip_debug_exec_trace_read(et, 8 * min(n, (1 << 18))) == 0
 et = np.array(et, dtype=np.int64).reshape(-1, 8)
 t0 = ct[3072]
 us = lambda v: (np.asarray(v, dtype=np.float64) - t0) / 100.0
@@ -42,25 +44,25 @@ print(f"N={N} T={T}: {n} tasks, queues {qb}; chain total {us(ct[3072 + 2 * (T - 
 # utilisation: busy worker-time per window, by queue
 end = us(et[:, 2].max())
 W = 500.0
-names = ["urgent", "solve/late", "early", "bulk"]
+names = ["urgent", "solve/late", "early", "inv-rows", "bulk", "inv-waves"]
 print(f"window(us)   busy workers (of 512) by queue [{', '.join(names)}]  | idle-looking share | chain blocks finished")
 blk_end = us(ct[3072 + 1:3072 + 2 * T:2])
 for w0 in np.arange(0, end, W):
     row = []
-    for q in range(4):
+    for q in range(NQ):
         s, e = us(et[qb[q]:qb[q + 1], 1]), us(et[qb[q]:qb[q + 1], 2])
         row.append(np.clip(np.minimum(e, w0 + W) - np.maximum(s, w0), 0, None).sum() / W)
-    print(f"{w0:8.0f}   {row[0]:6.1f} {row[1]:6.1f} {row[2]:6.1f} {row[3]:6.1f}   total {sum(row):6.1f}   | blocks done {int((blk_end < w0 + W).sum())}")
+    print(f"{w0:8.0f}   " + " ".join(f"{r:6.1f}" for r in row) + f"   total {sum(row):6.1f}   | blocks done {int((blk_end < w0 + W).sum())}")
 print("window(us)   workers LOOKING or WAITING for a claimed task's counters, by queue of the task they then ran")
 for w0 in np.arange(0, end, W):
     row = []
-    for q in range(4):
+    for q in range(NQ):
         s_, e_ = us(et[qb[q]:qb[q + 1], 0]), us(et[qb[q]:qb[q + 1], 1])
         row.append(np.clip(np.minimum(e_, w0 + W) - np.maximum(s_, w0), 0, None).sum() / W)
-    print(f"{w0:8.0f}   {row[0]:6.1f} {row[1]:6.1f} {row[2]:6.1f} {row[3]:6.1f}   total {sum(row):6.1f}")
+    print(f"{w0:8.0f}   " + " ".join(f"{r:6.1f}" for r in row) + f"   total {sum(row):6.1f}")
 dur = us(et[:, 2]) - us(et[:, 1])
 look = us(et[:, 1]) - us(et[:, 0])
-for q in range(4):
+for q in range(NQ):
     sl = slice(qb[q], qb[q + 1])
     k_ = kc[sl]
     print(f"queue {q} ({names[q]}): {qb[q+1]-qb[q]} tasks, run time mean {dur[sl].mean():.1f} us (per 128 of K: {(dur[sl] / (k_ / 8)).mean():.2f} us), look+wait before start mean {look[sl].mean():.1f} us")
@@ -115,3 +117,20 @@ for k in list(range(2, 6)) + list(range(6, T - 4, 5)):
             txt += f" <- Late [{min(us(r0[1]), us(r1[1])) - pe:.0f}/{max(us(r0[4]), us(r1[4])) - pe:.0f}/{max(us(r0[2]), us(r1[2])) - pe:.0f}]"
         parts.append(txt)
     print(f"{k:4d}: " + "  ".join(parts) + f"   | pivot k start {us(ct[3072 + 2 * k]) - pe:.0f}, end {us(ct[3072 + 2 * k + 1]) - pe:.0f}")
+
+# the inverse's row chain: per row i, when its last product (W(i, j) = W_ii Z(i, j)) ended, relative to the end of pivot i
+if qb[4] > qb[3]:
+    print("inverse row chain: row i | pivot i end (us) | last/product records of the row: first start, last end (rel. to pivot i end)")
+    A_ = recs[:, 0]; Cc = recs[:, 2]
+    rws = recs.view(np.int32)[:, 24]
+    base_W = 3 << 44
+    sl = slice(qb[3], qb[4])
+    off = (Cc[sl].astype(np.int64) - base_W) // 8
+    row_i = (off // ld) // 128
+    is_prod = ((rws[sl] & 3) == 0)
+    for i in list(range(1, 6)) + list(range(6, T, max(1, T // 12))) + [T - 1]:
+        sel = np.where((row_i == i) & is_prod)[0]
+        if len(sel) == 0: continue
+        pe = us(ct[3072 + 2 * i + 1])
+        e = et[qb[3] + sel]
+        print(f"{i:4d}: {pe:9.1f} | {us(e[:, 1]).min() - pe:7.1f} {us(e[:, 2]).max() - pe:7.1f}")
