@@ -287,6 +287,7 @@ static int g_chol_exec = 1;       // executor form (kernels_exec.hip, cholesky_e
 static int g_chol_exec_min = -1;  // BOHIP_CHOL_EXEC_MIN, row tiles.  Default: 4 with the executor's inverse queues (factorisation + inverse: N=500 0.41 ms against
                                   // 0.51 for the first dataflow form + the inverse behind it, N=1000 0.70 / 0.87, N=3000 2.02 / 2.49, N=4000 2.96 / 3.50), 32 without
                                   // them (the factorisation alone: N=3000 1.75 against 1.67 for the first form, N=4000 2.42 / 2.49, N=5000 3.23 / 3.75)
+static int g_chol_exec_patience_us = 1000;   // BOHIP_CHOL_EXEC_PATIENCE_US: how long a workgroup only polls a held record before it takes other work meanwhile
 static int g_chol_exec_fill_inv = 1;    // a workgroup waiting for the counters of a claimed task runs inverse-wave tasks meanwhile (BOHIP_CHOL_EXEC_FILL_INV)
 static int g_chol_exec_inv_pairs = 0;   // inverse queue claimed one record (0) or one tile = two records (1) at a time (BOHIP_CHOL_EXEC_INV_PAIRS)
 static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
@@ -340,6 +341,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL")) g_chol_exec_fill = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_URGENT")) g_chol_exec_urgent = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(CH_NSF_MAX, std::max(1, atoi(e)));
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_PATIENCE_US")) g_chol_exec_patience_us = std::max(0, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL_INV")) g_chol_exec_fill_inv = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_INV_PAIRS")) g_chol_exec_inv_pairs = atoi(e) != 0;
     if (const char* e = getenv("BOHIP_CHOL_INV_G")) g_chol_inv_g = std::min(64, std::max(0, atoi(e)));
@@ -433,7 +435,8 @@ static int inverse_join(bohip_gp* g, hipStream_t st, int P, int nb) {
 // flag-gated trailing updates of every block are enqueued up front on the side stream.  No host events inside the factorisation.
 static size_t chol_abort_word(int T) { return (size_t)T * (CH_PANELS + 7) + (size_t)T * T * (CH_PANELS + 1); }   // see the layout in cholesky_dataflow
 static size_t chol_inv_word(int T) { return chol_abort_word(T) + 8; }      // the inverse queue's counters: 4 words per tile (i, j)
-static size_t chol_flag_words(int T) { return chol_inv_word(T) + (size_t)4 * T * T; }   // abort word + the executor's queue cursors + those
+static size_t chol_xp3_word(int T) { return chol_inv_word(T) + (size_t)4 * T * T; }    // per-panel flags of S(k+3, k) (8 per block), then pre3 (4 per block)
+static size_t chol_flag_words(int T) { return chol_xp3_word(T) + (size_t)12 * T; }       // abort word + the executor's queue cursors + those
 static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T);
 static CholFlags chol_flags_layout(bohip_gp* g, int T) { return chol_flags_layout_at(g->dchol_flags, g->dchol_idl, T); }
 static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T) {
@@ -450,6 +453,8 @@ static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T) {
     fl.colr = fl.colall + T;
     fl.xp = fl.colr + (size_t)T * T;
     fl.abort = fl.xp + (size_t)T * T * CH_PANELS;
+    fl.xp3 = base + chol_xp3_word(T);
+    fl.pre3 = fl.xp3 + (size_t)T * CH_PANELS;
     fl.w16_g = idl;
     fl.spin_ticks = g_chol_spin_ticks;
     fl.crit_want = 16u;   // the row-(k+2) update: 4 workgroups x 4 storing waves
@@ -755,7 +760,9 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
     // P(i, c): the mirror tile of the scratch matrix (its upper triangle and diagonal tiles are free during the factorisation)
     auto Pp = [&](int i, int c) { return dS + (int64_t)c * TILE * ld + (int64_t)i * TILE; };
     // last block the Early sum of tile (i, c) contains; Late adds the two blocks behind it
-    auto e_of = [](int i, int c) { return std::min(i, c + 2) - 5; };
+    // (the three tiles of a row that the chain kernel finishes itself -- i <= c + 2 -- get their last block from its gated updates:
+    // the executor's share ends one block earlier)
+    auto e_of = [](int i, int c) { return i <= c + 2 ? i - 6 : c - 3; };
     std::vector<ExTask> q[EX_NQ];
     struct Dep { uint32_t idx, want; };
     auto add = [&](int qi, const double* A, const double* B, double* C, const double* P, int kc_h0, int kc_h1, bool diag, int rmw,
@@ -791,37 +798,39 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
             add(qi, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
                 {{widx(fl.solved + k), 1u}, {k >= 1 ? ver(i, k) : EX_NONE, 16u * (unsigned)(nb(k) + 1)}}, sver(i, k), EX_NONE);
         };
-        // Late(k): blocks max(k-1, 0) .. k into the tiles read next; the three tiles of row k+3 (what the chain waits for) first
-        const int kb0 = std::max(k - 1, 0), kcl = (k - kb0 + 1) * CPB;
-        auto late = [&](int qi, int i, int c) {
+        // Late(k): blocks max(k-1, 0) .. k into the tiles read next
+        const int kb0 = std::max(k - 1, 0);
+        auto late = [&](int qi, int i, int c, uint32_t sig2) {
             const bool has_p = e_of(i, c) >= ks(c);
             auto chain_row = [&](int kk, int r) { return Dep{widx(fl.xp + ((size_t)kk * T + r) * CH_PANELS + (CH_PANELS - 1)), 1u}; };
             const Dep p_dep{has_p ? pver(i, c) : EX_NONE, 16u}, v_dep{ver(i, c), 16u * (unsigned)nb(c)};
-            if (k >= 1) {
+            // (a diagonal tile whose bulk groups already reach block k-1 -- c = k+4 a multiple of 4 -- gets block k only)
+            const int kb = (i == c && ks(c) >= k) ? k : kb0, kcl = (k - kb + 1) * CPB;
+            if (kb < k) {
                 // TWO PIECES: the block k-1 half of the contraction needs nothing of block k, so the task is claimed and starts before
                 // S(i, k) exists -- for the follower rows while block k is still being factored, for the others while their row
                 // solve is running -- and waits for S(i, k) (and the chain's row c) inside, half a contraction from its end
                 const Dep b_prev = c == k + 1 ? chain_row(k - 1, c) : Dep{sver(c, k - 1), 16u};
-                add(qi, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
-                    {{sver(i, k - 1), 16u}, b_prev, p_dep, v_dep}, ver(i, c), i == k + 3 ? widx(fl.rest + k) : EX_NONE, CPB,
-                    Dep{sver(i, k), 16u}, c <= k + 2 ? chain_row(k, c) : Dep{EX_NONE, 0});
+                add(qi, Sp(i, kb), Sp(c, kb), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
+                    {{sver(i, k - 1), 16u}, b_prev, p_dep, v_dep}, ver(i, c), sig2, CPB,
+                    Dep{sver(i, k), 16u}, c <= k + 2 ? chain_row(k, c) : (c != i ? Dep{sver(c, k), 16u} : Dep{EX_NONE, 0}));
                 return;
             }
-            // block 0: one piece.  rows of S on the B side: row c of block 0
+            // one block, one piece.  rows of S on the B side: row c of block k
             const Dep b0 = c <= k + 2 ? chain_row(k, c) : Dep{sver(c, k), 16u};
-            add(qi, Sp(i, kb0), Sp(c, kb0), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
-                {{sver(i, k), 16u}, b0, p_dep, v_dep}, ver(i, c), i == k + 3 ? widx(fl.rest + k) : EX_NONE);
+            add(qi, Sp(i, kb), Sp(c, kb), Ap(i, c), has_p ? Pp(i, c) : nullptr, kcl, kcl, i == c, 1,
+                {{sver(i, k), 16u}, b0, p_dep, v_dep}, ver(i, c), sig2);
         };
-        // urgent, in the order they are needed: the three tiles the chain waits for, the tiles its solve followers read next, then
-        // the row steps of the rows about to enter the follower window
-        late(0, k + 3, k + 1);
-        late(0, k + 3, k + 2);
-        late(0, k + 3, k + 3);
-        for (int i = k + 4; i < std::min(T, rb); ++i) late(0, i, k + 1);
+        // urgent, in the order they are needed: the tiles the chain's solve followers read in block k+1, then the three tiles of row
+        // k+4 that its gated updates finish during block k+1 (pre3; the blocks up to k: one block of slack), then the row steps of
+        // the rows about to enter the follower window
+        for (int i = k + 4; i < std::min(T, rb); ++i) late(0, i, k + 1, EX_NONE);
+        if (k + 4 < T)
+            for (int j = 0; j < 3; ++j) late(0, k + 4, k + 2 + j, widx(fl.pre3 + 4 * (k + 1) + j));
         for (int i = rb; i < std::min(T, rb + NBU); ++i) solve_row(0, i);
-        for (int i = rb; i < std::min(T, rb + NBU); ++i) late(0, i, k + 1);
+        for (int i = rb; i < std::min(T, rb + NBU); ++i) late(0, i, k + 1, EX_NONE);
         for (int i = rb + NBU; i < T; ++i) solve_row(1, i);
-        for (int i = rb + NBU; i < T; ++i) late(1, i, k + 1);
+        for (int i = rb + NBU; i < T; ++i) late(1, i, k + 1, EX_NONE);
     }
     for (int kp = 0; kp + 5 < T; ++kp) {
         // Early(kp): P(i, c) = sum_{b = ks(c)}^{kp} S(i, b) S(c, b)'  for the tiles Late(kp + 2) finishes
@@ -830,9 +839,9 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
             add(2, Sp(i, ks(c)), Sp(c, ks(c)), const_cast<double*>(Pp(i, c)), nullptr, (kp - ks(c) + 1) * CPB,
                 (kp - ks(c) + 1) * CPB, i == c, 0, {{sver(i, kp), 16u}, {sver(c, kp), 16u}}, pver(i, c), EX_NONE);
         };
-        early(kp + 5, kp + 3);
-        early(kp + 5, kp + 4);
-        early(kp + 5, kp + 5);
+        early(kp + 6, kp + 4);   // the three tiles of row kp+6: blocks up to kp (e_of), then Late(kp+2) adds two, the chain the last
+        early(kp + 6, kp + 5);
+        early(kp + 6, kp + 6);
         for (int i = kp + 6; i < T; ++i) early(i, kp + 3);
     }
     for (int m = 0; 4 * m + 8 <= T - 1; ++m)
@@ -882,7 +891,12 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
         auto WTp = [&](int j, int i) { return dWT + (int64_t)j * TILE * ld + (int64_t)i * TILE; };
         auto m_of = [&](int i) { return (i - 1) / G; };                                       // row i's own (incomplete) chunk
         auto n_waves = [&](int i, int j) { return std::max(0, m_of(i) - j / G); };           // wave pieces tile (i, j) receives
-        auto has_partial = [&](int i, int j) { return G * m_of(i) < i - 1 && j < i - 1; };
+        // what is left of row i's own chunk before its last block goes in two pieces, so that none of them has less than two rows
+        // of slack behind the product it waits for: A = [G m_i, i-2) (needs row i-3 of W), B = {i-2} (row i-2).  (One piece
+        // [G m_i, i-1): up to G-1 blocks of contraction, ~100 us at G = 8, between the products of two consecutive rows -- the
+        // rows fell behind the pivots by that much every G rows.)
+        auto has_a = [&](int i, int j) { return std::max(j, G * m_of(i)) < i - 2; };
+        auto has_b = [&](int i, int j) { return i - 2 >= G * m_of(i) && j <= i - 2; };
         auto zdep = [&](int i, int j, int n) { return Dep{n ? iw(i, j, 0) : EX_NONE, 16u * (unsigned)n}; };
         auto wave = [&](int m) {   // after the product of row G (m+1) - 1
             const int k1 = G * (m + 1);
@@ -893,18 +907,27 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
                             {l_final(i, k1 - 1), w_final(k1 - 1, j), zdep(i, j, nbf)}, iw(i, j, 0), EX_NONE);
                 }
         };
-        auto partial = [&](int i) {
-            const int k0 = G * m_of(i);
-            for (int j = 0; j < i - 1; ++j) {
-                if (!has_partial(i, j)) continue;
-                const int a = std::max(j, k0), nbf = n_waves(i, j);
-                add_inv(EX_QROWS, Sp(i, a), WTp(j, a), Wp(i, j), nullptr, (i - 1 - a) * CPB, nbf == 0 ? 2 : 1,
+        auto partial_a = [&](int i) {
+            if (i >= T || i < 3) return;
+            for (int j = 0; j < i - 2; ++j) {
+                if (!has_a(i, j)) continue;
+                const int a = std::max(j, G * m_of(i)), nbf = n_waves(i, j);
+                add_inv(EX_QROWS, Sp(i, a), WTp(j, a), Wp(i, j), nullptr, (i - 2 - a) * CPB, nbf == 0 ? 2 : 1,
+                        {l_final(i, i - 3), w_final(i - 3, j), zdep(i, j, nbf)}, iw(i, j, 0), EX_NONE);
+            }
+        };
+        auto partial_b = [&](int i) {
+            if (i >= T || i < 2) return;
+            for (int j = 0; j <= i - 2; ++j) {
+                if (!has_b(i, j)) continue;
+                const int nbf = n_waves(i, j) + (has_a(i, j) ? 1 : 0);
+                add_inv(EX_QROWS, Sp(i, i - 2), WTp(j, i - 2), Wp(i, j), nullptr, CPB, nbf == 0 ? 2 : 1,
                         {l_final(i, i - 2), w_final(i - 2, j), zdep(i, j, nbf)}, iw(i, j, 0), EX_NONE);
             }
         };
         auto last = [&](int i) {
             for (int j = 0; j < i; ++j) {
-                const int nbf = n_waves(i, j) + (has_partial(i, j) ? 1 : 0);
+                const int nbf = n_waves(i, j) + (has_a(i, j) ? 1 : 0) + (has_b(i, j) ? 1 : 0);
                 add_inv(EX_QROWS, Sp(i, i - 1), WTp(j, i - 1), Wp(i, j), Wp(j, i), CPB, nbf == 0 ? 2 : 1,
                         {l_final(i, i - 1), w_final(i - 1, j), zdep(i, j, nbf)}, iw(i, j, 0), iw(i, j, 1));
             }
@@ -913,8 +936,9 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
             for (int j = 0; j < i; ++j)
                 add_inv(EX_QROWS, Wp(i, i), Wp(j, i), Wp(i, j), WTp(j, i), CPB, 0, {Dep{iw(i, j, 1), 16u}, Dep{widx(fl.solved + i), 1u}}, iw(i, j, 2), EX_NONE);
         };
-        for (int i = 1; i < T; ++i) {
-            if (i + 1 < T) partial(i + 1);
+        for (int i = 1; i < T; ++i) {   // what follows needs the product of row i-1 at most, except product(i): pivot i
+            partial_a(i + 2);
+            partial_b(i + 1);
             last(i);
             product(i);
             if ((i + 1) % G == 0) wave((i + 1) / G - 1);
@@ -949,11 +973,11 @@ static int cholesky_exec(bohip_gp* g, int T) {
     const int64_t ld = g->ld;
     CHK(build_exec_tasks(g, T));
     CholFlags fl = chol_flags_layout(g, T);
-    fl.mode2 = 100;   // the chain's view: rest[k] = 48 once the three tiles of row k+3 are in, inverter workgroup on
+    fl.mode2 = 200;   // the chain's view: row k+3's three tiles carry block k (its own gated updates: rest[k] = 24), inverter workgroup on
     HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
     HIPCHK(hipEventRecord(g->ev_panels, g->stream));           // K and the cleared flags are in place
     fl.nsf = g_chol_nsf;
-    hipLaunchKernelGGL(k_chol_chain, dim3(9 + g_chol_nsf), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
+    hipLaunchKernelGGL(k_chol_chain, dim3(9 + g_chol_nsf + 6), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
     HIPCHK(hipGetLastError());
     if (T > 3) {
         ExQueues q{};
@@ -969,6 +993,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
         q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
         q.fill_inv = g_chol_exec_fill_inv;
+        q.patience_ticks = (unsigned)g_chol_exec_patience_us * 100u;
         HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
         hipLaunchKernelGGL(k_chol_exec, dim3(g_chol_exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
         HIPCHK(hipGetLastError());
@@ -1046,7 +1071,7 @@ static int refit_once(bohip_gp* g, double jitter) {
     const bool want_df = !paused &&
                          ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP));
     const int exec_min = g_chol_exec_min >= 0 ? g_chol_exec_min : (g_chol_inv_g > 0 ? 4 : 32);
-    const bool exec_ok = g_chol_exec && T >= std::max(4, exec_min) && cus >= 9 + g_chol_nsf + 8;
+    const bool exec_ok = g_chol_exec && T >= std::max(4, exec_min) && cus >= 9 + g_chol_nsf + 6 + 8;
     const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
     const bool form1_ok = cus >= 8 + 3 * std::max(0, T - 3) + 8;
     if (want_df && (exec_ok || form2_ok || form1_ok)) {
@@ -2343,6 +2368,7 @@ int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base
     if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(bohip::CH_NSF_MAX, std::max(1, atoi(e)));
     layout[10] = g_chol_nsf;
     layout[11] = (int64_t)chol_inv_word(T);
+    layout[12] = (int64_t)chol_xp3_word(T);
     if ((int64_t)all.size() <= cap && out) std::memcpy(out, all.data(), all.size() * sizeof(bohip::ExTask));
     return (int64_t)all.size();
 }

@@ -70,6 +70,8 @@ struct CholFlags {
     unsigned panel_want;  // value of panel[..] when every publishing wave has seen its stores land
     unsigned long long spin_ticks;   // bound of every in-kernel wait (wall_clock64 ticks), see flag_wait_ge
     int nsf;              // executor form: solve-follower workgroups of the chain kernel (rows k+3 .. k+2+nsf of block k)
+    unsigned* xp3;        // [T * 8]   mode2 >= 200: panel p of S(k+3, k) is complete (solve follower 0): what the gated updates of row k+3 consume
+    unsigned* pre3;       // [T * 4]   mode2 >= 200: tile (k+3, k+1+j) carries every block before k (executor: 16 per tile): pre3[4 k + j]
 };
 
 // Bound of every in-kernel wait, in ticks of wall_clock64() (100 MHz constant clock): 200 ms by default.  The longest legitimate
@@ -482,6 +484,7 @@ __host__ __device__ __forceinline__ int near_last_col(int T, int k, int win) { r
 // waves of the first row tile (row k+3) of block k's flagged update: every workgroup of that row adds 8, with or without a tile
 // (host: nt64 = 2 (T - k - 2) columns k+2 ..; mode2: columns k+1 .. near_last_col)
 __device__ __forceinline__ unsigned rest_want(const CholFlags& fl, int k) {
+    if (fl.mode2 >= 200) return 24u;   // executor form: the six gated-update workgroups of row k+3 inside the chain kernel, four storing waves each
     if (fl.mode2 >= 100) return 48u;   // left-looking form: three launches of two workgroups each hold row k+3's tiles
     return fl.mode2 ? 8u * 2u * (unsigned)(near_last_col(fl.T, k, fl.mode2) - k) : 8u * 2u * (unsigned)(fl.T - k - 2);
 }
@@ -769,12 +772,35 @@ __device__ __forceinline__ void solve_follower(const double* __restrict__ Lmat, 
             if (tid == 0) flag_wait_ge(fl.xp + ((size_t)(k - 1) * T + r) * CH_PANELS, 16u * (unsigned)(nb + 1), fl.abort, fl.spin_ticks);
             __syncthreads();
         }
-        if (tid == 0 && f < 4) CH_MARK(7168 + 256 * f + k);
+        if (tid == 0 && f < 3) CH_MARK(7168 + 256 * f + k);
         load_row_piece(Lmat, ld, r, k, ar);
-        follow_block<false, 0>(Lmat, ld, S, r, k, fl, sm, ar, dd, nullptr);
+        follow_block<false, 0>(Lmat, ld, S, r, k, fl, sm, ar, dd, (f == 0 && fl.mode2 >= 200) ? fl.xp3 + (size_t)k * CH_PANELS : nullptr);
         release_wg();
         __syncthreads();
-        if (tid == 0) { flag_set(fl.colr + (size_t)k * T + r, 16u); if (f == 0) CH_MARK(4608 + k); if (f < 4) CH_MARK(6144 + 256 * f + k); }   // sver(r, k)
+        if (tid == 0) { flag_set(fl.colr + (size_t)k * T + r, 16u); if (f == 0) CH_MARK(4608 + k); if (f < 3) CH_MARK(6144 + 256 * f + k); }   // sver(r, k)
+    }
+}
+
+// ---- role 6 (workgroups 9 + nsf .. 9 + nsf + 5, executor form): the chunk-gated update of the three tiles of row k+3 --
+// (k+3, k+1), which row k+3's critical follower solves during block k+1, and (k+3, k+2), (k+3, k+3), which block k+1's gated
+// updates continue -- with block k, consumed 16 columns at a time as solve follower 0 publishes S(k+3, k): the chain's window
+// spans three rows.  As executor tasks (Late(k): blocks k-1 and k, started when S(k+3, k) was complete) these tiles reached the
+// chain 33-50 us after the pivot block on an idle chip and 80-250 us under load, and row k+3's follower, which needs ~6 us per
+// panel against the pivot's ~7, never made a late start up: chain period = 69 us + that latency - 29.  Now the executor
+// delivers the tiles with every block BEFORE k (pre3: one block of slack) and block k is added here, final ~3 us after the
+// solve follower's last panel.
+__device__ __forceinline__ void gated_worker3(double* __restrict__ Lmat, int64_t ld, const double* __restrict__ S, int T,
+                                              const CholFlags& fl, double* sm, int tj) {
+    const int j = tj >> 1, h = tj & 1;
+    for (int k = 0; k + 3 < T; ++k) {
+        const int c = k + 1 + j;
+        const double* A = S + (int64_t)(k + 3) * TILE * ld + (int64_t)k * TILE;
+        const double* B = S + ((int64_t)c * TILE + (int64_t)h * CTILE) * ld + (int64_t)k * TILE;
+        double* C = Lmat + (int64_t)(k + 3) * TILE * ld + (int64_t)c * TILE + (int64_t)h * CTILE;
+        const unsigned* fa = fl.xp3 + (size_t)k * CH_PANELS;
+        gated_tile(A, B, C, ld, (int64_t)(k + 3) * TILE, (int64_t)c * TILE + (int64_t)h * CTILE, fa, j < 2 ? xp_at(fl, k, c) : fa,
+                   k >= 1 ? fl.pre3 + 4 * k + j : nullptr, 16u, fl.rest + k, fl, sm);
+        if (threadIdx.x == 0 && tj == 0) CH_MARK(4352 + 256 * 14 + k);   // [7936, 8192): row k+3's tiles carry block k
     }
 }
 
@@ -784,7 +810,9 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_chain(double* __restrict
                                                            double* __restrict__ WT) {
     extern __shared__ double sm[];
     const int b = blockIdx.x;
-    if (b >= 9) {
+    if (b >= 9 + fl.nsf && fl.mode2 >= 200) {
+        gated_worker3(Lmat, ld, S, T, fl, sm, b - 9 - fl.nsf);
+    } else if (b >= 9) {
         solve_follower(Lmat, ld, S, T, fl, sm, b - 9);
     } else if (b == 8) {
         inverter_role(Lmat, ld, W, WT, ld, T, fl, sm);

@@ -83,6 +83,7 @@ struct ExQueues {
     unsigned long long spin_ticks;   // a workgroup that finds no runnable task for this long gives up (see flag_wait_ge)
     int nurgent;                // workgroups 0 .. nurgent-1 serve the urgent queue (and nothing else until it is exhausted)
     int fill_inv;               // ... and inverse-wave work (1), see k_chol_exec
+    unsigned patience_ticks;    // ... but only once the held record has been waited for this long (wall-clock ticks of 10 ns)
     int fill;                   // a workgroup that holds a claimed task whose counters are not in yet takes bulk work meanwhile:
                                 // 1 = if the held task is an Early sum (queue 2: two blocks of slack), 2 = also for queue 1, 0 = never
     int stride[EX_NQ];          // records per claim: 1, or 2 = both halves of a tile run back to back by one workgroup (the look and
@@ -365,8 +366,9 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
     __shared__ int s_pend3;    // a claimed record of the inverse queue whose counters are not in: held in a slot of its own that
                                // restricts nothing -- no other queue and not the chain ever waits for an inverse record, so a
                                // workgroup holding one goes on claiming everywhere else
+    __shared__ unsigned s_tp, s_tp3;   // when the records in `pend` / `pend3` were claimed (low word of the wall clock)
     __shared__ int s_urgent;
-    if (threadIdx.x == 0) { s_look = -1; s_pend = -1; s_pend2 = -1; s_pend2n = 0; s_pend3 = -1; s_urgent = (int)blockIdx.x < q.nurgent; }
+    if (threadIdx.x == 0) { s_look = -1; s_pend = -1; s_pend2 = -1; s_pend2n = 0; s_pend3 = -1; s_tp = 0u; s_tp3 = 0u; s_urgent = (int)blockIdx.x < q.nurgent; }
     __syncthreads();
     // The urgent queue (~10 tasks per block: what the chain kernel reads next) has its own workgroups: each takes the next urgent
     // task with a fetch-and-add AHEAD of time and waits for its counters, so the task starts the moment they arrive -- no look, no
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
             asm volatile("" : "+v"(pl));   // opaque: the look's lane arithmetic must not be kept alive across the task
             int run = -1, run_n = 0;   // run_n > 0: only that many records (the rest of a bulk claim that was interrupted)
             int look = s_look, pend = s_pend, pend2 = s_pend2, pend2_n = s_pend2n, pend3 = s_pend3;
+            unsigned tp = s_tp, tp3 = s_tp3;
             bool urgent_wg = s_urgent != 0;
             const unsigned long long t_wait = wall_clock64();
             auto queue_of = [&](int t) {
@@ -414,8 +417,16 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                 // which queues may this workgroup claim from right now?  one held record per slot: `pend` (queues 1, 2), `pend2`
                 // (bulk), `pend3` (inverse: rows or waves).  While `pend` is occupied only fill-in work is taken: inverse waves
                 // (nothing ever waits for those), bulk if asked for (q.fill).
+                // A record that was claimed a little ahead of its counters is usually microseconds from runnable (its producers
+                // were claimed just before it): for `patience` the workgroup only polls -- picking up a 60-100 us task meanwhile
+                // made row-chain records and row steps start that much late on a mostly idle chip (N = 3000: the inverse's rows
+                // fell 150-340 us behind the pivots) -- and takes other work only when the wait turns out to be a long one.
+                const unsigned now = (unsigned)wall_clock64();
+                const bool patient = (pend >= 0 && now - tp < q.patience_ticks) ||
+                                     (pend3 >= 0 && pend3 < q.qbeg[EX_QROWS + 1] && now - tp3 < q.patience_ticks);
                 unsigned qmask = 0u;
-                if (pend < 0) {
+                if (patient) {
+                } else if (pend < 0) {
                     qmask = 6u;
                     if (pend3 < 0) qmask |= 1u << EX_QROWS;
                     if (pend2 < 0) qmask |= 1u << EX_QBULK;
@@ -434,7 +445,9 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                 if (tk >= 0) {
                     if (rdy) { run = tk; break; }
                     const int qt = queue_of(tk);
-                    if (qt == EX_QROWS || qt == EX_QWAVE) pend3 = tk; else if (qt == EX_QBULK) pend2 = tk; else pend = tk;
+                    if (qt == EX_QROWS || qt == EX_QWAVE) { pend3 = tk; tp3 = (unsigned)wall_clock64(); }
+                    else if (qt == EX_QBULK) pend2 = tk;
+                    else { pend = tk; tp = (unsigned)wall_clock64(); }
                     continue;
                 }
                 if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { run = -1; break; }
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                 }
                 __builtin_amdgcn_s_sleep(8);
             }
-            if (pl == 0) { s_task = run; s_cnt = run_n; s_look = -1; s_pend = pend; s_pend2 = pend2; s_pend2n = pend2_n; s_pend3 = pend3; s_urgent = urgent_wg ? 1 : 0; }
+            if (pl == 0) { s_task = run; s_cnt = run_n; s_look = -1; s_pend = pend; s_pend2 = pend2; s_pend2n = pend2_n; s_pend3 = pend3; s_tp = tp; s_tp3 = tp3; s_urgent = urgent_wg ? 1 : 0; }
         }
         __syncthreads();
         const int ti = __builtin_amdgcn_readfirstlane(s_task);

@@ -32,11 +32,11 @@ def get_tasks(T, ld, inv_g=INV_G):
     f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int),
                   C.POINTER(C.c_int64)]
     qbeg = (C.c_int * (NQ + 1))()
-    layout = (C.c_int64 * 12)()
+    layout = (C.c_int64 * 16)()
     n = f(T, ld, BASE_L, BASE_S, BASE_W, BASE_WT, inv_g, None, 0, qbeg, layout)
     buf = np.zeros((n, 16), dtype=np.uint64)
     assert f(T, ld, BASE_L, BASE_S, BASE_W, BASE_WT, inv_g, buf.ctypes.data_as(C.c_void_p), n, qbeg, layout) == n
-    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp", "nsf", "inv"]
+    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp", "nsf", "inv", "xp3"]
     return buf, list(qbeg), dict(zip(names, layout))
 
 
@@ -73,7 +73,8 @@ def replay(T, order, seed=0, inv_g=INV_G):
             if i != j:
                 mats[BASE_W][i * TILE:(i + 1) * TILE, j * TILE:(j + 1) * TILE] = np.nan
                 mats[BASE_WT][i * TILE:(i + 1) * TILE, j * TILE:(j + 1) * TILE] = np.nan
-    flags = np.zeros(lay["inv"] + 4 * T * T, dtype=np.int64)
+    flags = np.zeros(lay["xp3"] + 12 * T, dtype=np.int64)
+    pre3 = lay["xp3"] + 8 * T   # pre3[4 k + j]: tile (k+3, k+1+j) carries every block before k (the executor's share)
     # operands of the contraction engine arrive through LDS-DMA, i.e. through caches nothing invalidates while the kernel runs:
     # a location that was read that way must never be written afterwards
     dma_read = {b: np.zeros((ld, ld), dtype=bool) for b in mats}
@@ -143,7 +144,7 @@ def replay(T, order, seed=0, inv_g=INV_G):
     chain_k = 0   # next block of the chain
 
     def chain_can_run():
-        return chain_k < T and (chain_k == 0 or flags[lay["rest"] + chain_k - 1] >= 48 or chain_k + 2 >= T)
+        return chain_k < T and (chain_k == 0 or flags[lay["rest"] + chain_k - 1] >= 24 or chain_k + 2 >= T)
 
     def chain_step():
         nonlocal chain_k
@@ -151,7 +152,7 @@ def replay(T, order, seed=0, inv_g=INV_G):
         L = mats[BASE_L]
         S = mats[BASE_S]
         if k >= 1 and k + 2 < T:
-            assert flags[lay["rest"] + k - 1] >= 48
+            assert flags[lay["rest"] + k - 1] >= 24
         Lkk = np.linalg.cholesky(np.tril(tile(BASE_L, k, k)) + np.tril(tile(BASE_L, k, k), -1).T)
         tile(BASE_L, k, k)[:, :] = Lkk
         tile(BASE_W, k, k)[:, :] = np.linalg.inv(Lkk)
@@ -191,6 +192,24 @@ def replay(T, order, seed=0, inv_g=INV_G):
         flags[lay["colr"] + k * T + r] = 16
         tf_k[f] += 1
 
+    g3_k = 0   # next block of the chain kernel's gated updates of row k+3 (gated_worker3): tiles (k+3, k+1 .. k+3) get block k
+
+    def g3_can_run():
+        k = g3_k
+        if k + 3 >= T or chain_k <= k or tf_k[0] <= k:
+            return False
+        return k == 0 or all(flags[pre3 + 4 * k + j] >= 16 for j in range(3))
+
+    def g3_step():
+        nonlocal g3_k
+        k = g3_k
+        s3 = tile(BASE_S, k + 3, k)
+        for c in (k + 1, k + 2, k + 3):
+            upd = s3 @ tile(BASE_S, c, k).T
+            tile(BASE_L, k + 3, c)[:, :] -= np.tril(upd) if c == k + 3 else upd
+        flags[lay["rest"] + k] = 24
+        g3_k += 1
+
     steps = 0
     while True:
         for q in range(NQ):   # a two-piece task at a queue head whose first-stage counters are in: the device would start its first piece now
@@ -204,7 +223,7 @@ def replay(T, order, seed=0, inv_g=INV_G):
                     snap[id(t)] = (a1, b1)
         runnable = [q for q in range(NQ) if heads[q] < qbeg[q + 1] and ready(tasks[heads[q]])]
         can_chain = chain_can_run()
-        tfs = [("tf", f) for f in range(NSF) if tf_can_run(f)]
+        tfs = [("tf", f) for f in range(NSF) if tf_can_run(f)] + ([("g3", 0)] if g3_can_run() else [])
         if not runnable and not can_chain and not tfs:
             break
         if order == "tasks_first":
@@ -219,13 +238,16 @@ def replay(T, order, seed=0, inv_g=INV_G):
         if pick == "chain":
             chain_step()
         elif isinstance(pick, tuple):
-            tf_step(pick[1])
+            if pick[0] == "g3":
+                g3_step()
+            else:
+                tf_step(pick[1])
         else:
             run_task(tasks[heads[pick]])
             heads[pick] += 1
         steps += 1
     assert chain_k == T, f"dead-lock: chain stopped at block {chain_k} of {T}, queue heads {heads} of {qbeg}"
-    assert tf_k == [max(T - 3 - f, 0) for f in range(NSF)]
+    assert tf_k == [max(T - 3 - f, 0) for f in range(NSF)] and g3_k == max(T - 3, 0)
     assert heads == qbeg[1:], f"records left over: heads {heads}, queues {qbeg}"
     # k_copy_offdiag_tiles: the solved panels go home
     L = mats[BASE_L]
@@ -289,5 +311,5 @@ def test_every_tile_gets_every_block_once():
                 cover.setdefault((i, c, half), []).extend(range(kb, kb + t["kc"] * KC // TILE))
     assert cover
     for (i, c, half), blocks in cover.items():
-        want_last = c - 1 if i >= c + 2 else (c - 2 if i == c + 1 else c - 3)   # the chain applies the remaining blocks itself
+        want_last = c - 1 if i >= c + 3 else i - 4   # the chain applies the remaining blocks itself (its window spans three rows)
         assert sorted(blocks) == list(range(0, want_last + 1)), ((i, c, half), sorted(blocks), want_last)

@@ -24,7 +24,7 @@ f.restype = C.c_int64
 f.argtypes = [C.c_int, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
 NQ = 6
 INV_G = int(os.environ.get("BOHIP_CHOL_INV_G", "8"))
-qbeg = (C.c_int * (NQ + 1))(); lay = (C.c_int64 * 12)()
+qbeg = (C.c_int * (NQ + 1))(); lay = (C.c_int64 * 16)()
 n = f(T, ld, 1 << 44, 2 << 44, 3 << 44, 4 << 44, INV_G, None, 0, qbeg, lay)
 recs = np.zeros((n, 16), dtype=np.uint64)
 f(T, ld, 1 << 44, 2 << 44, 3 << 44, 4 << 44, INV_G, recs.ctypes.data_as(C.c_void_p), n, qbeg, lay)
@@ -118,19 +118,34 @@ for k in list(range(2, 6)) + list(range(6, T - 4, 5)):
         parts.append(txt)
     print(f"{k:4d}: " + "  ".join(parts) + f"   | pivot k start {us(ct[3072 + 2 * k]) - pe:.0f}, end {us(ct[3072 + 2 * k + 1]) - pe:.0f}")
 
-# the inverse's row chain: per row i, when its last product (W(i, j) = W_ii Z(i, j)) ended, relative to the end of pivot i
+# the inverse's row chain: per row i, its partial / last / product records (first start .. last end), relative to the end of pivot i
 if qb[4] > qb[3]:
-    print("inverse row chain: row i | pivot i end (us) | last/product records of the row: first start, last end (rel. to pivot i end)")
-    A_ = recs[:, 0]; Cc = recs[:, 2]
+    print("inverse row chain: row i | pivot i end (us) | partial: first start, last end | last piece: first start, last end | product: first start, last end   (rel. to pivot i end)")
+    Cc = recs[:, 2]
     rws = recs.view(np.int32)[:, 24]
     base_W = 3 << 44
     sl = slice(qb[3], qb[4])
     off = (Cc[sl].astype(np.int64) - base_W) // 8
     row_i = (off // ld) // 128
-    is_prod = ((rws[sl] & 3) == 0)
-    for i in list(range(1, 6)) + list(range(6, T, max(1, T // 12))) + [T - 1]:
-        sel = np.where((row_i == i) & is_prod)[0]
-        if len(sel) == 0: continue
+    kind = np.where((rws[sl] & 3) == 0, 2, np.where((rws[sl] & 4) != 0, 1, 0))   # 0 partial (both pieces), 1 last (stores Z'), 2 product
+    for i in list(range(1, 8)) + list(range(8, T, max(1, T // 12))) + [T - 1]:
         pe = us(ct[3072 + 2 * i + 1])
-        e = et[qb[3] + sel]
-        print(f"{i:4d}: {pe:9.1f} | {us(e[:, 1]).min() - pe:7.1f} {us(e[:, 2]).max() - pe:7.1f}")
+        txt = []
+        for kd in range(3):
+            sel = np.where((row_i == i) & (kind == kd))[0]
+            if len(sel) == 0:
+                txt.append("      -       -")
+                continue
+            e = et[qb[3] + sel]
+            txt.append(f"{us(e[:, 1]).min() - pe:7.1f} {us(e[:, 2]).max() - pe:7.1f}")
+        print(f"{i:4d}: {pe:9.1f} | " + " | ".join(txt))
+
+    if os.environ.get("ROWDUMP"):
+        for i in [int(v) for v in os.environ["ROWDUMP"].split(",")]:
+            pe = us(ct[3072 + 2 * i + 1])
+            print(f"row {i} (pivot end {pe:.1f}; inverse published {us(ct[4096 + i]) - pe:+.1f}): kind j half | looking since / start / end (rel. to pivot end) | workgroup | queue position")
+            for kd, nm in ((0, "partial"), (1, "last"), (2, "product")):
+                for ix in np.where((row_i == i) & (kind == kd))[0]:
+                    e = et[qb[3] + ix]
+                    jj = ((off[ix] % ld) // 128, ((off[ix] % ld) % 128) // 64)
+                    print(f"   {nm:8s} j={jj[0]:2d} h={jj[1]} | {us(e[0]) - pe:8.1f} {us(e[1]) - pe:8.1f} {us(e[2]) - pe:8.1f} | wg {int(e[3]):3d} | {ix}")
