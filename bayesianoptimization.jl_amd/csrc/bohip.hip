@@ -1060,7 +1060,6 @@ static int refit_once(bohip_gp* g, double jitter) {
     }
     HIPCHK(hipGetLastError());
     t_end(g);
-    t_begin(g, "cholesky");
     // Which form.  The dataflow forms make progress only while their persistent workgroups are resident TOGETHER, one per CU
     // (the chain's fill the LDS): the chain's 8-9 (+ solve followers), form 1's T - 3 row followers and 2 (T - 3) column
     // updaters.  On a device (or partition: CPX mode exposes 32 CUs) that cannot hold them the launch chain is used.
@@ -1074,6 +1073,8 @@ static int refit_once(bohip_gp* g, double jitter) {
     const bool exec_ok = g_chol_exec && T >= std::max(4, exec_min) && cus >= 9 + g_chol_nsf + 6 + 8;
     const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
     const bool form1_ok = cus >= 8 + 3 * std::max(0, T - 3) + 8;
+    // (stage name: with the executor's inverse queues the factorisation and W = L^-1 are ONE stage)
+    t_begin(g, want_df && exec_ok && g_chol_inv_g > 0 ? "cholesky+inverse" : "cholesky");
     if (want_df && (exec_ok || form2_ok || form1_ok)) {
         g->w_done = false;
         if (exec_ok) { g->chol_form_last = 4; CHK(cholesky_exec(g, T)); }
@@ -1081,14 +1082,15 @@ static int refit_once(bohip_gp* g, double jitter) {
         else if (form2_ok) { g->chol_form_last = 2; CHK(cholesky_dataflow2(g, T)); }
         else { g->chol_form_last = 1; CHK(cholesky_dataflow(g, T)); }
         t_end(g);
-        t_begin(g, "tri_inverse");
-        if (!g->w_seeded) {
-            hipLaunchKernelGGL(k_inv128, dim3(T), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, g->dL, ld, g->dW, g->dWT, ld);
-            HIPCHK(hipGetLastError());
-        }
-        if (!g->w_done)
+        if (!g->w_done) {
+            t_begin(g, "tri_inverse");
+            if (!g->w_seeded) {
+                hipLaunchKernelGGL(k_inv128, dim3(T), dim3(PF_THREADS), POTF2_LDS_BYTES, g->stream, g->dL, ld, g->dW, g->dWT, ld);
+                HIPCHK(hipGetLastError());
+            }
             for (int h = 1; h < T; h *= 2) CHK(inverse_level(g, g->stream, 0, T, h));
-        t_end(g);
+            t_end(g);
+        }
         t_begin(g, "alpha");
         CHK(compute_alpha(g));
         t_end(g);
@@ -2371,6 +2373,13 @@ int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base
     layout[12] = (int64_t)chol_xp3_word(T);
     if ((int64_t)all.size() <= cap && out) std::memcpy(out, all.data(), all.size() * sizeof(bohip::ExTask));
     return (int64_t)all.size();
+}
+// tools and bench.py: switch the executor's inverse queues at run time (returns the previous chunk size; 0 = off: the factorisation
+// alone can then be timed against its own flop count)
+int bohip_debug_set_chol_inv_g(int g_new) {
+    const int old = g_chol_inv_g;
+    g_chol_inv_g = std::min(64, std::max(0, g_new));
+    return old;
 }
 #if BOHIP_CHOL_TRACE
 int bohip_debug_chol_trace_read(unsigned long long* out, int64_t n_words) {   // tools only

@@ -32,7 +32,8 @@ def score_cfg(name, N, d, R, reps=10):
     tg = sum(v for k, v in m.timing() if k == "trigemm_sq")
     out = dict(config=name, N=N, d=d, R=R, host_call_ms=t * 1e3, candidates_per_s_host_buffers=R / t, stage_ms_last_call=st,
                trigemm_ms=tg, trigemm_tflops=flops / (tg * 1e-3) / 1e12, model_update_ms=fit,
-               cholesky_gflops=(N ** 3 / 3) / (fit["cholesky"] * 1e-3) / 1e9,
+               **({"cholesky_gflops": (N ** 3 / 3) / (fit["cholesky"] * 1e-3) / 1e9} if "cholesky" in fit else
+                  {"factor_and_inverse_gflops": (2 * N ** 3 / 3) / (fit["cholesky+inverse"] * 1e-3) / 1e9}),
                build_cov_GBps=(8.0 * N * (N + 1) / 2) / (fit["build_cov"] * 1e-3) / 1e9)
     print(json.dumps(out)); sys.stdout.flush()
 
