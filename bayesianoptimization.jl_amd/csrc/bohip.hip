@@ -263,6 +263,8 @@ static int g_inv_overlap = 0;  // BOHIP_INV_OVERLAP=1: grow W = L^-1 block by bl
                                // down under the competition (2.90 -> 3.08 ms, 13.9 -> 17.7 ms), so it stays opt-in.
 static int g_bulk_pieces = 4;   // gated pieces of the side-stream bulk update per outer block (BOHIP_BULK_PIECES; 0/1: one launch)
 static int g_split = 1;   // split-K path for batches of a few hundred candidates (BOHIP_SPLIT=0 disables)
+static int g_asc_lockstep = 0;   // BOHIP_ASC_LOCKSTEP=1: the lock-step driver of the device ascent (five launches + a stream synchronisation per
+                                 // evaluation pass) instead of the free-running one (k_asc_step)
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
@@ -352,6 +354,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
     if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
+    if (const char* e = getenv("BOHIP_ASC_LOCKSTEP")) g_asc_lockstep = atoi(e) != 0;
     if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_MAX, std::max(0, atoi(e)));
     done = true;
     return 0;
@@ -2132,8 +2135,10 @@ static int ensure_ascent(bohip_gp* g, int64_t R) {
     g->asc_block = nullptr; g->asc_ints = nullptr; g->asc_hints = nullptr; g->asc_cap = 0;
     const int64_t cap = std::max<int64_t>(R, 32), d = g->d, rd = cap * d;
     HIPCHK(hipMalloc(&g->asc_block, (size_t)((9 + 2 * ASC_M) * rd + 5 * cap) * 8));
-    HIPCHK(hipMalloc(&g->asc_ints, (size_t)2 * cap * sizeof(int)));
-    HIPCHK(hipHostMalloc((void**)&g->asc_hints, (size_t)2 * cap * sizeof(int), hipHostMallocDefault));
+    HIPCHK(hipMalloc(&g->asc_ints, (size_t)(4 * cap + 2 * ASC_RING) * sizeof(int)));
+    HIPCHK(hipMemset(g->asc_ints, 0, (size_t)(4 * cap + 2 * ASC_RING) * sizeof(int)));
+    HIPCHK(hipHostMalloc((void**)&g->asc_hints, (size_t)(2 * cap + ASC_RING) * sizeof(int), hipHostMallocDefault));
+    std::memset(g->asc_hints, 0, (size_t)(2 * cap + ASC_RING) * sizeof(int));
     if (!g->asc_bounds) HIPCHK(hipMalloc(&g->asc_bounds, (size_t)3 * DMAX * 8));
     if (!g->asc_best) HIPCHK(hipMalloc(&g->asc_best, sizeof(Best)));
     double* p = g->asc_block;
@@ -2144,6 +2149,9 @@ static int ensure_ascent(bohip_gp* g, int64_t R) {
     a.f = p; p += cap; a.ft = p; p += cap; a.fn = p; p += cap; a.step = p; p += cap; a.best_f = p; p += cap;
     a.active = g->asc_ints; a.accepted = g->asc_ints + cap;
     a.h_accepted = g->asc_hints; a.h_active = g->asc_hints + cap;
+    a.it = g->asc_ints + 2 * cap; a.bt = g->asc_ints + 3 * cap;
+    a.nact = reinterpret_cast<unsigned*>(g->asc_ints + 4 * cap); a.ticket = a.nact + ASC_RING;
+    a.h_cnt = g->asc_hints + 2 * cap;
     g->asc_cap = cap;
     return 0;
 }
@@ -2198,6 +2206,46 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     auto out_of_time = [&]() {   // NLopt's maxtime (reference src/acquisition.jl:24-27 forwards it): checked once per iteration
         return g->asc_maxtime > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= g->asc_maxtime;
     };
+    if (!g_asc_lockstep) {
+        // FREE-RUNNING form (k_asc_step): pass after pass is enqueued without waiting; the number of start points still active
+        // after pass e is read LAG passes later from pinned memory (by then it has long been written: no stall), so at most
+        // LAG passes run beyond convergence.  Same per-start-point trajectories as the lock-step form below.
+        const int LAG = 2;
+        if (any_active) {
+            HIPCHK(hipMemsetAsync(st.it, 0, (size_t)2 * g->asc_cap * sizeof(int), g->stream));   // it, bt
+            HIPCHK(hipMemsetAsync(st.nact, 0, (size_t)2 * ASC_RING * sizeof(unsigned), g->stream));
+            for (int i = 0; i < ASC_RING; ++i) st.h_cnt[i] = 0;
+            hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, 0, 0, dlb, dub, 0.1 * span);
+            int64_t e = 0, converged_at = -1;
+            auto read_count = [&](int64_t pass) -> int {   // active start points after `pass` (waits for it if need be)
+                volatile int* w = st.h_cnt + (pass % ASC_RING);
+                const auto t0 = std::chrono::steady_clock::now();
+                int v;
+                while ((v = *w) == 0) {
+                    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) return -1;
+                }
+                *w = 0;
+                return v - 1;
+            };
+            for (; evals < maxeval && !out_of_time(); ++e) {
+                CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
+                ++evals;
+                hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, 0.1 * span, ftol_rel, xtol_abs,
+                                   (int)(e % ASC_RING));
+                HIPCHK(hipGetLastError());
+                if (e >= LAG) {
+                    const int n = read_count(e - LAG);
+                    if (n < 0) return fail(BOHIP_E_HIP, "device ascent: an evaluation pass did not report back within 30 s");
+                    if (n == 0) { converged_at = e - LAG; ++e; break; }
+                }
+            }
+            HIPCHK(hipStreamSynchronize(g->stream));
+            if (converged_at < 0)   // stopped by maxeval / maxtime, or converged within the last LAG passes
+                for (int64_t p2 = std::max<int64_t>(0, e - LAG); p2 < e && converged_at < 0; ++p2)
+                    if (st.h_cnt[p2 % ASC_RING] == 1) converged_at = p2;
+            if (converged_at >= 0) evals = 2 + converged_at;   // passes that were needed: the first one + passes 0 .. converged_at
+        }
+    } else {
     while (evals < maxeval && any_active && !out_of_time()) {
         hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, nh, (it + ASC_M - 1) % ASC_M, dlb, dub,
                            0.1 * span);
@@ -2214,6 +2262,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         hipLaunchKernelGGL(k_asc_update, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, it % ASC_M, ftol_rel, xtol_abs);
         nh = std::min(nh + 1, ASC_M);
         ++it;
+    }
     }
     hipLaunchKernelGGL(k_asc_final, dim3(1), dim3(256), 0, g->stream, st, d, (int)R, g->asc_best, dbx);
     HIPCHK(hipGetLastError());

@@ -25,7 +25,13 @@ struct AscentState {
     double *best_f, *best_X;
     int *active, *accepted;
     int *h_accepted, *h_active; // pinned host mirrors read by the driver loop
+    // free-running form (k_asc_step): per start point its own iteration count and backtracking count, and per evaluation pass a
+    // ring slot: how many start points are still active after it (device counters + the word the host polls, value + 1)
+    int *it, *bt;
+    unsigned *nact, *ticket;    // [ASC_RING]
+    int *h_cnt;                 // [ASC_RING] pinned
 };
+constexpr int ASC_RING = 8;
 
 __device__ __forceinline__ double asc_wsum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -175,6 +181,123 @@ __global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R,
         if (fn > best_before) st.best_f[r] = fn;
         st.active[r] = active;
         st.h_active[r] = active;
+    }
+}
+
+// FREE-RUNNING form: one launch per evaluation pass does, for every start point on its own, whatever comes next in ITS iteration --
+// the Armijo test of its trial; on failure the halved step (up to 12 trials, as in the lock-step driver); on success (or after
+// the 12th failure) the update of k_asc_update and at once the next direction of k_asc_direction with its first trial point.
+// A start point's sequence of trial points, values and curvature pairs is exactly that of the lock-step form (its arithmetic
+// never looks at another start point, and a score_grad result does not depend on what else is in the batch), but no start
+// point waits for the slowest line search of the batch, and the HOST takes no decision between two passes: it enqueues pass
+// after pass and reads, two passes behind, how many start points were still active (a pinned word written by the last
+// workgroup of a pass).  Lock-step: five launches + a stream synchronisation per pass, 94-117 us at N = 3000 with 10 starts.
+__global__ __launch_bounds__(64) void k_asc_step(AscentState st, int d, int R, const double* __restrict__ lb,
+                                                 const double* __restrict__ ub, double first_step_scale, double ftol_rel,
+                                                 double xtol_abs, int ring_slot) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    const bool on = k < d;
+    const int64_t o = (int64_t)r * d + k;
+    int active = st.active[r];
+    if (active) {
+        const double lo = on ? lb[k] : 0.0, hi = on ? ub[k] : 0.0;
+        const double x = on ? st.X[o] : 0.0, xt = on ? st.Xt[o] : 0.0, gpo = on ? st.Gp[o] : 0.0;
+        const double dot = asc_wsum(on ? gpo * (xt - x) : 0.0);
+        const double ft = st.ft[r], f = st.f[r];
+        const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
+        const int bt = st.bt[r];
+        if (!ok && bt < 11) {
+            const double step = st.step[r] * 0.5;
+            if (on) st.Xt[o] = asc_clip(x + step * st.D[o], lo, hi);
+            if (k == 0) { st.step[r] = step; st.bt[r] = bt + 1; }
+        } else {
+            // ---- the iteration ends (k_asc_update with Xn = the accepted trial, or X itself after 12 failures)
+            const double g = on ? st.G[o] : 0.0;
+            const double xn = ok ? xt : x, gn = ok ? (on ? st.Gt[o] : 0.0) : g, fn = ok ? ft : f;
+            const double s = xn - x, y = -(gn - g), df = fn - f, best_before = st.best_f[r];
+            const double moved = sqrt(asc_wsum(s * s));
+            const bool good = asc_wsum(s * y) > 1e-14;
+            active = (df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs) ? 1 : 0;
+            const int it = st.it[r], slot = it % ASC_M;
+            const double s_new = good ? s : 0.0, y_new = good ? y : 0.0;
+            if (on) {
+                const int64_t ho = ((int64_t)slot * R + r) * d + k;
+                st.S[ho] = s_new;
+                st.Y[ho] = y_new;
+                st.X[o] = xn;
+                st.G[o] = gn;
+                if (fn > best_before) st.best_X[o] = xn;
+            }
+            if (k == 0) {
+                st.f[r] = fn;
+                if (fn > best_before) st.best_f[r] = fn;
+                st.it[r] = it + 1;
+                st.bt[r] = 0;
+            }
+            double xt_new = xn;
+            if (active) {
+                // ---- the next direction (k_asc_direction at x = xn, g = gn; the newest pair is the one just written: taken
+                // from registers, the older ones from memory -- every lane reads only elements it wrote itself)
+                const int nh = it + 1 < ASC_M ? it + 1 : ASC_M, newest = slot;
+                double q = gn;
+                double al[ASC_M], rho[ASC_M];
+#pragma unroll
+                for (int i = 0; i < ASC_M; ++i) {   // newest -> oldest
+                    if (i >= nh) break;
+                    const int sl = (newest - i + ASC_M) % ASC_M;
+                    const int64_t ho = ((int64_t)sl * R + r) * d + k;
+                    const double sv = i == 0 ? s_new : (on ? st.S[ho] : 0.0), yv = i == 0 ? y_new : (on ? st.Y[ho] : 0.0);
+                    rho[i] = 1.0 / fmax(asc_wsum(yv * sv), 1e-300);
+                    al[i] = rho[i] * asc_wsum(sv * q);
+                    q -= al[i] * yv;
+                }
+                {
+                    const double sy = asc_wsum(s_new * y_new), yy = fmax(asc_wsum(y_new * y_new), 1e-300);
+                    q *= sy > 0.0 ? sy / yy : 1.0;
+                }
+#pragma unroll
+                for (int i = ASC_M - 1; i >= 0; --i) {   // oldest -> newest
+                    if (i >= nh) continue;
+                    const int sl = (newest - i + ASC_M) % ASC_M;
+                    const int64_t ho = ((int64_t)sl * R + r) * d + k;
+                    const double sv = i == 0 ? s_new : (on ? st.S[ho] : 0.0), yv = i == 0 ? y_new : (on ? st.Y[ho] : 0.0);
+                    const double b = rho[i] * asc_wsum(yv * q);
+                    q += (al[i] - b) * sv;
+                }
+                double D = q;
+                if ((xn <= lo && D < 0.0) || (xn >= hi && D > 0.0)) D = 0.0;
+                const double gp = ((xn <= lo && gn < 0.0) || (xn >= hi && gn > 0.0)) ? 0.0 : gn;
+                double slope = asc_wsum(on ? gp * D : 0.0);
+                if (!(slope > 0.0)) {
+                    D = gp;
+                    slope = asc_wsum(on ? gp * gp : 0.0);
+                }
+                if (slope > 0.0) {
+                    if (on) {
+                        st.D[o] = D;
+                        st.Gp[o] = gp;
+                    }
+                    if (k == 0) st.step[r] = 1.0;
+                    xt_new = asc_clip(xn + D, lo, hi);
+                } else {
+                    active = 0;   // no ascent direction left: the lock-step form spends one more pass to find s = 0
+                }
+            }
+            if (on) st.Xt[o] = xt_new;
+            if (k == 0) st.active[r] = active;
+        }
+    }
+    if (k == 0) {
+        if (active) atomicAdd(st.nact + ring_slot, 1u);
+        __threadfence();
+        const unsigned t = atomicAdd(st.ticket + ring_slot, 1u);
+        if (t == (unsigned)R - 1u) {   // the last workgroup of this pass publishes the count and clears the slot for its next use
+            __threadfence();
+            const unsigned n = atomicAdd(st.nact + ring_slot, 0u);
+            st.nact[ring_slot] = 0u;
+            st.ticket[ring_slot] = 0u;
+            __hip_atomic_store(st.h_cnt + ring_slot, (int)n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

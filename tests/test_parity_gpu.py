@@ -606,6 +606,45 @@ def test_device_ascent_matches_host_restatement(bohip, orc):
             np.testing.assert_array_equal(bx, Xb[:, j])
 
 
+def test_free_running_ascent_follows_the_lock_step_trajectories():
+    """csrc/kernels_ascent.hip k_asc_step: every start point on its own schedule (no host decision between two evaluation
+    passes) against the lock-step driver (BOHIP_ASC_LOCKSTEP=1).  A start point's arithmetic never looks at another one, so with
+    room to converge the end points and values are identical bit for bit, and the free-running form needs no more passes."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np, bohip
+out = {}
+for N, d, R in ((700, 3, 10), (1100, 2, 37), (900, 4, 300)):
+    rng = np.random.default_rng(N)
+    X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
+    m = bohip.ElasticGPE(d, kernel=bohip.SEArd(np.full(d, -0.9), 0.2), logNoise=-2.0, capacity=N)
+    m.append_(X.T, y)
+    starts = np.asfortranarray(rng.random((d, R)))
+    for acq, p in (("UCB", [2.0]), ("EI", [float(y.max())])):
+        f, Xb, bf, bi, bx, ev = m.ascend(acq, p, np.zeros(d), np.ones(d), starts, maxeval=3000)
+        out["%%d-%%s" %% (N, acq)] = dict(f=f.tolist(), X=Xb.tolist(), bf=bf, bi=int(bi), bx=bx.tolist(), ev=int(ev))
+print("RESULT" + json.dumps(out))
+''' % ROOT
+    res = {}
+    for name, env in (("free", {}), ("lockstep", {"BOHIP_ASC_LOCKSTEP": "1"})):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, (name, o.stderr[-2000:])
+        res[name] = json.loads([l for l in o.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
+    for key, a in res["free"].items():
+        b = res["lockstep"][key]
+        assert a["f"] == b["f"] and a["X"] == b["X"], key
+        assert (a["bf"], a["bi"], a["bx"]) == (b["bf"], b["bi"], b["bx"]), key
+        assert 1 <= a["ev"] <= b["ev"], (key, a["ev"], b["ev"])
+
+
 def test_device_ascent_on_the_split_k_and_whole_k_schedules(bohip):
     """Restart counts beyond the row-wise path: 300 (split-K) and 1500 (whole-K jobs) starts at N = 1100."""
     from bohip.acquisition import _batched_lbfgs_ascent
