@@ -263,6 +263,8 @@ static int g_inv_overlap = 0;  // BOHIP_INV_OVERLAP=1: grow W = L^-1 block by bl
                                // down under the competition (2.90 -> 3.08 ms, 13.9 -> 17.7 ms), so it stays opt-in.
 static int g_bulk_pieces = 4;   // gated pieces of the side-stream bulk update per outer block (BOHIP_BULK_PIECES; 0/1: one launch)
 static int g_split = 1;   // split-K path for batches of a few hundred candidates (BOHIP_SPLIT=0 disables)
+static int g_asc_wg_nmax = 256;  // BOHIP_ASC_WG_NMAX: models up to this many observations run acquire_max as ONE launch, one workgroup per start point
+                                 // (kernels_ascent.hip k_ascent_wg); 0: never
 static int g_asc_lockstep = 0;   // BOHIP_ASC_LOCKSTEP=1: the lock-step driver of the device ascent (five launches + a stream synchronisation per
                                  // evaluation pass) instead of the free-running one (k_asc_step)
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
@@ -354,6 +356,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
     if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
+    if (const char* e = getenv("BOHIP_ASC_WG_NMAX")) g_asc_wg_nmax = std::max(0, atoi(e));
     if (const char* e = getenv("BOHIP_ASC_LOCKSTEP")) g_asc_lockstep = atoi(e) != 0;
     if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_MAX, std::max(0, atoi(e)));
     done = true;
@@ -2194,6 +2197,42 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
             if ((v[r] != 0) == (want != 0)) return true;
         return false;
     };
+    if (g_asc_wg_nmax > 0 && g->n <= std::min<int64_t>(g_asc_wg_nmax, AWG_NMAX - 1) && d <= 16 && !g_asc_lockstep) {
+        // small models: one workgroup per start point runs its whole ascent, ONE launch (kernels_ascent.hip k_ascent_wg)
+        AscWgParams pw{};
+        pw.W = g->dW; pw.WT = g->dWT; pw.X = g->dX; pw.alpha = g->dalpha; pw.ld = g->ld; pw.N = g->n;
+        pw.hp = make_hyper(g);
+        pw.ap = AcqParams{acq_id, 0.0, 0.0};
+        if (acq_params) {
+            if (acq_id != BOHIP_ACQ_MAXMEAN) pw.ap.p0 = acq_params[0];
+            if (acq_id == BOHIP_ACQ_MI) pw.ap.p1 = acq_params[1];
+        }
+        pw.beta = g->beta; pw.st = st; pw.starts = g->dXs; pw.lb = dlb; pw.ub = dub; pw.R = (int)R;
+        pw.maxeval = (int)std::min<int64_t>(maxeval, 1 << 30); pw.ftol_rel = ftol_rel; pw.xtol_abs = xtol_abs; pw.first_step_scale = 0.1 * span;
+        pw.max_ticks = g->asc_maxtime > 0.0 ? (unsigned long long)(g->asc_maxtime * 1e8) : 0ull;
+        pw.passes = st.accepted;
+        t_begin(g, "ascent_wg");
+        if (d <= 2) hipLaunchKernelGGL(k_ascent_wg<2>, dim3(nR), dim3(AWG_THREADS), 0, g->stream, pw);
+        else if (d <= 4) hipLaunchKernelGGL(k_ascent_wg<4>, dim3(nR), dim3(AWG_THREADS), 0, g->stream, pw);
+        else if (d <= 8) hipLaunchKernelGGL(k_ascent_wg<8>, dim3(nR), dim3(AWG_THREADS), 0, g->stream, pw);
+        else hipLaunchKernelGGL(k_ascent_wg<16>, dim3(nR), dim3(AWG_THREADS), 0, g->stream, pw);
+        HIPCHK(hipGetLastError());
+        t_end(g);
+        hipLaunchKernelGGL(k_asc_final, dim3(1), dim3(256), 0, g->stream, st, d, (int)R, g->asc_best, dbx);
+        HIPCHK(hipGetLastError());
+        std::vector<int> passes((size_t)R);
+        HIPCHK(hipMemcpyAsync(passes.data(), st.accepted, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+        if (f_out) HIPCHK(hipMemcpyAsync(f_out, st.best_f, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
+        if (x_out) HIPCHK(hipMemcpyAsync(x_out, st.best_X, (size_t)R * d * 8, hipMemcpyDeviceToHost, g->stream));
+        if (best) HIPCHK(hipMemcpyAsync(best, g->asc_best, sizeof(Best), hipMemcpyDeviceToHost, g->stream));
+        if (best_x) HIPCHK(hipMemcpyAsync(best_x, dbx, (size_t)d * 8, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        if (best && best_x && best->idx < 0)
+            for (int k = 0; k < d; ++k) best_x[k] = lb[k];   // :56  maxx = lowerbounds when nothing beat -Inf
+        if (evals_out) *evals_out = *std::max_element(passes.begin(), passes.end());
+        t_collect(g);
+        return 0;
+    }
     hipLaunchKernelGGL(k_asc_start, dim3(nR), dim3(64), 0, g->stream, st, d, g->dXs, dlb, dub);
     CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
     hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d);

@@ -48,8 +48,7 @@ __global__ __launch_bounds__(64) void k_asc_start(AscentState st, int d, const d
     st.Xt[(int64_t)r * d + k] = x;
 }
 
-__global__ __launch_bounds__(64) void k_asc_adopt(AscentState st, int d) {
-    const int r = blockIdx.x, k = threadIdx.x;
+__device__ __forceinline__ void asc_adopt_one(const AscentState& st, int r, int k, int d) {
     const double f = st.ft[r];
     if (k < d) {
         st.G[(int64_t)r * d + k] = st.Gt[(int64_t)r * d + k];
@@ -63,12 +62,11 @@ __global__ __launch_bounds__(64) void k_asc_adopt(AscentState st, int d) {
         st.h_active[r] = a;
     }
 }
+__global__ __launch_bounds__(64) void k_asc_adopt(AscentState st, int d) { asc_adopt_one(st, blockIdx.x, threadIdx.x, d); }
 
 // nh curvature pairs are valid; the newest sits in slot (newest), older ones in the slots before it (ring of ASC_M)
-__global__ __launch_bounds__(64) void k_asc_direction(AscentState st, int d, int R, int nh, int newest,
-                                                      const double* __restrict__ lb, const double* __restrict__ ub,
-                                                      double first_step_scale) {
-    const int r = blockIdx.x, k = threadIdx.x;
+__device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, int k, int d, int R, int nh, int newest,
+                                                  const double* __restrict__ lb, const double* __restrict__ ub, double first_step_scale) {
     const bool on = k < d;
     const int64_t o = (int64_t)r * d + k;
     const double x = on ? st.X[o] : 0.0, g = on ? st.G[o] : 0.0;
@@ -127,6 +125,11 @@ __global__ __launch_bounds__(64) void k_asc_direction(AscentState st, int d, int
         st.accepted[r] = acc;
         st.h_accepted[r] = acc;
     }
+}
+__global__ __launch_bounds__(64) void k_asc_direction(AscentState st, int d, int R, int nh, int newest,
+                                                      const double* __restrict__ lb, const double* __restrict__ ub,
+                                                      double first_step_scale) {
+    asc_direction_one(st, blockIdx.x, threadIdx.x, d, R, nh, newest, lb, ub, first_step_scale);
 }
 
 __global__ __launch_bounds__(64) void k_asc_linesearch(AscentState st, int d, const double* __restrict__ lb,
@@ -192,10 +195,9 @@ __global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R,
 // point waits for the slowest line search of the batch, and the HOST takes no decision between two passes: it enqueues pass
 // after pass and reads, two passes behind, how many start points were still active (a pinned word written by the last
 // workgroup of a pass).  Lock-step: five launches + a stream synchronisation per pass, 94-117 us at N = 3000 with 10 starts.
-__global__ __launch_bounds__(64) void k_asc_step(AscentState st, int d, int R, const double* __restrict__ lb,
-                                                 const double* __restrict__ ub, double first_step_scale, double ftol_rel,
-                                                 double xtol_abs, int ring_slot) {
-    const int r = blockIdx.x, k = threadIdx.x;
+// (one wave: lane k = coordinate k of start point r; ring_slot < 0: no pass bookkeeping -- the one-workgroup-per-start kernel)
+__device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k, int d, int R, const double* __restrict__ lb,
+                                             const double* __restrict__ ub, double ftol_rel, double xtol_abs, int ring_slot) {
     const bool on = k < d;
     const int64_t o = (int64_t)r * d + k;
     int active = st.active[r];
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(64) void k_asc_step(AscentState st, int d, int R, c
             if (k == 0) st.active[r] = active;
         }
     }
-    if (k == 0) {
+    if (k == 0 && ring_slot >= 0) {
         if (active) atomicAdd(st.nact + ring_slot, 1u);
         __threadfence();
         const unsigned t = atomicAdd(st.ticket + ring_slot, 1u);
@@ -299,6 +301,223 @@ __global__ __launch_bounds__(64) void k_asc_step(AscentState st, int d, int R, c
             __hip_atomic_store(st.h_cnt + ring_slot, (int)n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+}
+__global__ __launch_bounds__(64) void k_asc_step(AscentState st, int d, int R, const double* __restrict__ lb,
+                                                 const double* __restrict__ ub, double first_step_scale, double ftol_rel,
+                                                 double xtol_abs, int ring_slot) {
+    asc_step_one(st, blockIdx.x, threadIdx.x, d, R, lb, ub, ftol_rel, xtol_abs, ring_slot);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// SMALL MODELS: the whole ascent of one start point inside ONE workgroup, ONE launch for the whole acquire_max.
+// Below N ~ 800 a pass of the free-running form is six kernels of 6-15 us that each move a megabyte or less: 45-49 us per pass
+// at N = 500 whatever the arithmetic.  A start point's ascent never looks at another start point, so here workgroup r
+// (512 threads) runs start r from the first evaluation to convergence: K* of its trial point, V = W k* (row N of W is
+// alpha: mu comes with it), q = sum V^2, U = W'V, the analytic gradient, the L-BFGS step (asc_adopt_one / asc_direction_one /
+// asc_step_one on wave 0) -- phases separated by workgroup barriers only, W and W' from L2 (2 x 1 MB at N = 500, shared by
+// the R workgroups).  No flags, no atomics, no host decision.  Summation orders differ from the kernels of the batched paths
+// (a row of W is one wave's strided sum + butterfly), so values agree with them to rounding, not bit for bit.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int AWG_THREADS = 512, AWG_WAVES = AWG_THREADS / 64, AWG_NMAX = 1024;   // (1024 threads: 128 VGPRs per thread, the inlined two-loop recursion spills)
+struct AscWgParams {
+    const double *W, *WT, *X, *alpha;   // resident model: W (row N = alpha'), W', observations [N][d], alpha
+    int64_t ld, N;
+    KernelHyper hp;
+    AcqParams ap;
+    double beta;
+    AscentState st;
+    const double *starts, *lb, *ub;
+    int R, maxeval;
+    double ftol_rel, xtol_abs, first_step_scale;
+    unsigned long long max_ticks;       // maxtime in wall_clock64 ticks (0: none)
+    int* passes;                        // [R] evaluation passes start r needed
+};
+template <int DT>
+__global__ __launch_bounds__(AWG_THREADS) void k_ascent_wg(AscWgParams p) {
+#pragma clang fp contract(off)
+    __shared__ double ks[AWG_NMAX + 1], V[AWG_NMAX + 1], U[AWG_NMAX];
+    __shared__ double red[AWG_WAVES][2 * DT];
+    __shared__ double s_q, s_il2[DT];
+    __shared__ int s_go;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = p.hp.d;
+    if (tid < DT) s_il2[tid] = tid < d ? p.hp.il2[tid] : 0.0;   // (indexed from the kernel arguments the weights cost > 100 scalar-register spills)
+    const int64_t N = p.N, ld = p.ld;
+    // The start point's whole state lives in LDS: the bookkeeping functions are the batched drivers' (they take an AscentState of
+    // pointers), handed a state whose pointers lead here, with r = 0 of R = 1 start points -- in HBM every one of their dozen
+    // dependent loads was a ~1 us round trip, 20 us per pass whatever N.  Only the best point goes back to the global state.
+    __shared__ double s_state[(9 + 2 * ASC_M) * DT + 8];
+    __shared__ int s_ints[8];
+    AscentState st;
+    {
+        double* q = s_state;
+        st.X = q; q += DT; st.G = q; q += DT; st.Xt = q; q += DT; st.Gt = q; q += DT; st.Xn = q; q += DT; st.Gn = q; q += DT;
+        st.D = q; q += DT; st.Gp = q; q += DT; st.best_X = q; q += DT;
+        st.S = q; q += ASC_M * DT; st.Y = q; q += ASC_M * DT;
+        st.f = q++; st.ft = q++; st.fn = q++; st.step = q++; st.best_f = q++;
+        st.active = s_ints; st.accepted = s_ints + 1; st.it = s_ints + 2; st.bt = s_ints + 3; st.h_accepted = s_ints + 4; st.h_active = s_ints + 5;
+        st.nact = nullptr; st.ticket = nullptr; st.h_cnt = nullptr;
+    }
+    const unsigned long long t_begin = wall_clock64();
+    if (tid < 64) {   // k_asc_start
+        if (tid < d) {
+            const double x = asc_clip(p.starts[(int64_t)r * d + tid], p.lb[tid], p.ub[tid]);
+            st.X[tid] = x;
+            st.Xt[tid] = x;
+        }
+        if (tid == 0) { st.it[0] = 0; st.bt[0] = 0; }
+    }
+    __syncthreads();
+    int pass = 0;
+    for (;;) {
+        // ---- one evaluation of the trial point: value and gradient of the acquisition
+        double xs[DT];
+#pragma unroll
+        for (int k = 0; k < DT; ++k) xs[k] = k < d ? st.Xt[k] : 0.0;
+        for (int64_t j = tid; j <= N; j += AWG_THREADS) {
+            double rr = 0.0;
+#pragma unroll
+            for (int k = 0; k < DT; ++k) {
+                const double t = ((k < d && j < N) ? p.X[j * d + k] : 0.0) - xs[k];
+                rr += s_il2[k] * (t * t);
+            }
+            ks[j] = j < N ? cov_from_r_fast(p.hp.kern, p.hp.sigma2, rr) : 0.0;
+        }
+        __syncthreads();
+        // V[i] = sum_{k <= i} W[i][k] k*[k]   (row N: alpha).  A wave takes FOUR of its rows at a time (rows i, i + 8, i + 16, i + 24):
+        // one row at a time was a chain of dependent L2 round trips, ~0.8 us per row, 50 us per product at N = 500
+        for (int64_t i0 = wave; i0 <= N; i0 += 4 * AWG_WAVES) {
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+            int64_t kend[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + (int64_t)u * AWG_WAVES;
+                kend[u] = i > N ? -1 : (i < N ? i : N - 1);
+            }
+            int64_t kmax = kend[0];
+#pragma unroll
+            for (int u = 1; u < 4; ++u) kmax = kend[u] > kmax ? kend[u] : kmax;
+#pragma unroll 2
+            for (int64_t k = lane; k <= kmax; k += 64) {
+                const double kv = ks[k];
+                double wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wv[u] = k <= kend[u] ? p.W[(i0 + (int64_t)u * AWG_WAVES) * ld + k] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += wv[u] * kv;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double t = asc_wsum(s[u]);
+                if (lane == 0 && kend[u] >= 0) V[i0 + (int64_t)u * AWG_WAVES] = t;
+            }
+        }
+        __syncthreads();
+        {   // q = sum_{i < N} V[i]^2 in a fixed order
+            double s = 0.0;
+            for (int64_t i = tid; i < N; i += AWG_THREADS) s += V[i] * V[i];
+            s = asc_wsum(s);
+            if (lane == 0) red[wave][0] = s;
+        }
+        for (int64_t j0 = wave; j0 < N; j0 += 4 * AWG_WAVES) {     // U[j] = sum_{i >= j} W'[j][i] V[i], four rows of W' at a time
+            double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+            for (int64_t i = j0 + lane; i < N; i += 64) {   // (row j0 starts first; the later rows skip their first entries)
+                const double vv = V[i];
+                double wv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t j = j0 + (int64_t)u * AWG_WAVES;
+                    wv[u] = (j < N && i >= j) ? p.WT[j * ld + i] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += wv[u] * vv;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double t = asc_wsum(s[u]);
+                const int64_t j = j0 + (int64_t)u * AWG_WAVES;
+                if (lane == 0 && j < N) U[j] = t;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double q = 0.0;
+            for (int wv = 0; wv < AWG_WAVES; ++wv) q += red[wv][0];
+            s_q = q;
+        }
+        __syncthreads();
+        const double q = s_q;
+        double s2 = p.hp.sigma2 - q;
+        if (s2 < 0.0) s2 = 0.0;                              // predict_f: max(sigma2, 0)
+        const double mu = p.beta + V[N];
+        __syncthreads();                                     // (red is reused below)
+        double gm[DT], gv[DT];
+#pragma unroll
+        for (int k = 0; k < DT; ++k) { gm[k] = 0.0; gv[k] = 0.0; }
+        for (int64_t j = tid; j < N; j += AWG_THREADS) {    // gradient: sum_j dk*_j/dx (alpha_j, U_j)   (k_grad_finish)
+            double rr = 0.0;
+#pragma unroll
+            for (int k = 0; k < DT; ++k)
+                if (k < d) {
+                    const double t = xs[k] - p.X[j * d + k];
+                    rr += s_il2[k] * (t * t);
+                }
+            double fac;
+            if (p.hp.kern == KERN_MAT52ARD) {
+                const double sq = sqrt(5.0) * sqrt(rr);
+                fac = -(5.0 / 3.0) * p.hp.sigma2 * (1.0 + sq) * exp(-sq);
+            } else {
+                fac = -(p.hp.sigma2 * exp(-0.5 * rr));
+            }
+            const double a = p.alpha[j], uj = U[j];
+#pragma unroll
+            for (int k = 0; k < DT; ++k)
+                if (k < d) {
+                    const double dk = fac * (xs[k] - p.X[j * d + k]) * s_il2[k];
+                    gm[k] += dk * a;
+                    gv[k] += dk * uj;
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < DT; ++k)
+            if (k < d) {
+                const double a = asc_wsum(gm[k]), b = asc_wsum(gv[k]);
+                if (lane == 0) { red[wave][2 * k] = a; red[wave][2 * k + 1] = b; }
+            }
+        __syncthreads();
+        if (tid < 64) {
+            const int k = tid;
+            if (k < d) {
+                double a = 0.0, b = 0.0;
+                for (int wv = 0; wv < AWG_WAVES; ++wv) { a += red[wv][2 * k]; b += red[wv][2 * k + 1]; }
+                double dmu, ds2;
+                acq_partials(p.ap, mu, s2, dmu, ds2);
+                st.Gt[k] = dmu * a + (s2 > 0.0 ? ds2 * (-2.0 * b) : 0.0);
+            }
+            if (k == 0) st.ft[0] = acq_eval(p.ap, mu, s2);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");   // (LDS state: lane 0's scalars are visible to the wave)
+            // ---- the ascent's bookkeeping for this start point (same code as the batched drivers, on the LDS state)
+            if (pass == 0) {
+                asc_adopt_one(st, 0, k, d);
+                asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
+                asc_direction_one(st, 0, k, d, 1, 0, 0, p.lb, p.ub, p.first_step_scale);
+            } else {
+                asc_step_one(st, 0, k, d, 1, p.lb, p.ub, p.ftol_rel, p.xtol_abs, -1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
+            if (k == 0) {
+                const bool time_up = p.max_ticks != 0ull && wall_clock64() - t_begin > p.max_ticks;
+                s_go = (st.active[0] != 0 && pass + 1 < p.maxeval && !time_up) ? 1 : 0;
+            }
+        }
+        ++pass;
+        __syncthreads();
+        if (!s_go) break;
+    }
+    if (tid < d) p.st.best_X[(int64_t)r * d + tid] = st.best_X[tid];
+    if (tid == 0) { p.st.best_f[r] = st.best_f[0]; p.passes[r] = pass; }
 }
 
 // (value desc, index asc) over best_f; NaN never wins.  One workgroup.

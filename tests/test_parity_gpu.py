@@ -645,6 +645,52 @@ print("RESULT" + json.dumps(out))
         assert 1 <= a["ev"] <= b["ev"], (key, a["ev"], b["ev"])
 
 
+def test_one_workgroup_per_start_ascent_against_the_batched_driver():
+    """csrc/kernels_ascent.hip k_ascent_wg (models up to 256 observations: the whole acquire_max is ONE launch, one workgroup per start
+    point) against the free-running batched driver (BOHIP_ASC_WG_NMAX=0).  Same search code, different summation orders in the
+    posterior: same maxima to optimiser tolerance, same winner, and the returned value is the score at the returned point."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = r'''
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np, bohip
+out = {}
+for N, d, R, kern in ((40, 2, 10, "SEArd"), (200, 3, 33, "SEArd"), (256, 8, 10, "Mat52Ard"), (130, 12, 17, "SEArd"), (1, 1, 5, "SEArd")):
+    rng = np.random.default_rng(N)
+    X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
+    K = getattr(bohip, kern)
+    m = bohip.ElasticGPE(d, mean=bohip.MeanConst(0.3), kernel=K(np.full(d, -0.9), 0.2), logNoise=-2.0, capacity=N)
+    m.append_(X.T, y)
+    starts = np.asfortranarray(rng.random((d, R)) * 1.4 - 0.2)      # partly outside the box
+    for acq, p in (("UCB", [2.0]), ("EI", [float(y.max())]), ("PI", [float(y.max())]), ("MaxMean", [])):
+        f, Xb, bf, bi, bx, ev = m.ascend(acq, p, np.zeros(d), np.ones(d), starts, maxeval=400)
+        fchk, _ = m.score_grad(acq, p, Xb)
+        out["%%d-%%s" %% (N, acq)] = dict(f=f.tolist(), X=Xb.tolist(), bf=bf, bi=int(bi), bx=bx.tolist(), ev=int(ev), fchk=fchk.tolist())
+print("RESULT" + json.dumps(out))
+''' % ROOT
+    res = {}
+    for name, env in (("wg", {}), ("batched", {"BOHIP_ASC_WG_NMAX": "0"})):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert o.returncode == 0, (name, o.stderr[-2000:])
+        res[name] = json.loads([l for l in o.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
+    for key, a in res["wg"].items():
+        b = res["batched"][key]
+        fa, fb = np.array(a["f"]), np.array(b["f"])
+        Xa = np.array(a["X"])
+        assert np.all(Xa >= 0.0) and np.all(Xa <= 1.0), key
+        np.testing.assert_allclose(np.array(a["fchk"]), fa, rtol=1e-9, atol=1e-12, err_msg=key)   # value at the returned point
+        np.testing.assert_allclose(fa, fb, rtol=1e-5, atol=1e-8, err_msg=key)                     # same local maxima
+        assert a["bf"] == pytest.approx(b["bf"], rel=1e-6, abs=1e-9), key
+        assert a["bf"] == fa[a["bi"]] and a["bx"] == Xa[:, a["bi"]].tolist(), key                # first maximum wins
+        assert 1 <= a["ev"] <= 400, key
+
+
 def test_device_ascent_on_the_split_k_and_whole_k_schedules(bohip):
     """Restart counts beyond the row-wise path: 300 (split-K) and 1500 (whole-K jobs) starts at N = 1100."""
     from bohip.acquisition import _batched_lbfgs_ascent
