@@ -111,6 +111,9 @@ struct bohip_gp {
     AscentState asc{};
     double* asc_block = nullptr;   // one allocation behind all double arrays of asc
     int* asc_ints = nullptr;       // active, accepted
+    double* asc_hio = nullptr;     // pinned staging of the one-launch ascent: [lb | ub | starts] in, the packed result out
+    double* asc_dio = nullptr;     // its device mirror
+    size_t asc_io_cap = 0;
     int* asc_hints = nullptr;      // pinned: h_accepted, h_active
     double* asc_bounds = nullptr;  // lb, ub, best_x (3 d doubles) + starts staging is dXs
     Best* asc_best = nullptr;
@@ -1778,6 +1781,8 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->asc_block) hipFree(g->asc_block);
     if (g->asc_ints) hipFree(g->asc_ints);
     if (g->asc_hints) hipHostFree(g->asc_hints);
+    if (g->asc_hio) hipHostFree(g->asc_hio);
+    if (g->asc_dio) hipFree(g->asc_dio);
     if (g->asc_bounds) hipFree(g->asc_bounds);
     if (g->asc_best) hipFree(g->asc_best);
     if (g->dthompson) hipFree(g->dthompson);
@@ -2186,9 +2191,12 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     double* dlb = g->asc_bounds;
     double* dub = dlb + DMAX;
     double* dbx = dub + DMAX;
-    HIPCHK(hipMemcpyAsync(dlb, lb, (size_t)d * 8, hipMemcpyHostToDevice, g->stream));
-    HIPCHK(hipMemcpyAsync(dub, ub, (size_t)d * 8, hipMemcpyHostToDevice, g->stream));
-    HIPCHK(hipMemcpyAsync(g->dXs, starts, (size_t)R * d * 8, hipMemcpyHostToDevice, g->stream));
+    const bool use_wg = g_asc_wg_nmax > 0 && g->n <= std::min<int64_t>(g_asc_wg_nmax, AWG_NMAX - 1) && d <= 16 && !g_asc_lockstep;
+    if (!use_wg) {
+        HIPCHK(hipMemcpyAsync(dlb, lb, (size_t)d * 8, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(dub, ub, (size_t)d * 8, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(g->dXs, starts, (size_t)R * d * 8, hipMemcpyHostToDevice, g->stream));
+    }
     double span = INFINITY;
     for (int k = 0; k < d; ++k) span = std::min(span, ub[k] - lb[k] + 1e-300);
     const unsigned nR = (unsigned)R;
@@ -2197,7 +2205,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
             if ((v[r] != 0) == (want != 0)) return true;
         return false;
     };
-    if (g_asc_wg_nmax > 0 && g->n <= std::min<int64_t>(g_asc_wg_nmax, AWG_NMAX - 1) && d <= 16 && !g_asc_lockstep) {
+    if (use_wg) {
         // small models: one workgroup per start point runs its whole ascent, ONE launch (kernels_ascent.hip k_ascent_wg)
         AscWgParams pw{};
         pw.W = g->dW; pw.WT = g->dWT; pw.X = g->dX; pw.alpha = g->dalpha; pw.ld = g->ld; pw.N = g->n;
@@ -2207,7 +2215,21 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
             if (acq_id != BOHIP_ACQ_MAXMEAN) pw.ap.p0 = acq_params[0];
             if (acq_id == BOHIP_ACQ_MI) pw.ap.p1 = acq_params[1];
         }
-        pw.beta = g->beta; pw.st = st; pw.starts = g->dXs; pw.lb = dlb; pw.ub = dub; pw.R = (int)R;
+        // one pinned block in ([lb | ub | starts]), one pinned block out (k_asc_final's packed result)
+        const size_t n_in = (size_t)(2 + R) * d, n_out = (size_t)2 + d + R + (size_t)R * d + R, n_io = std::max(n_in, n_out);
+        if (n_io > g->asc_io_cap) {
+            if (g->asc_hio) HIPCHK(hipHostFree(g->asc_hio));
+            if (g->asc_dio) HIPCHK(hipFree(g->asc_dio));
+            g->asc_hio = nullptr; g->asc_dio = nullptr; g->asc_io_cap = 0;
+            HIPCHK(hipHostMalloc((void**)&g->asc_hio, n_io * 2 * 8, hipHostMallocDefault));
+            HIPCHK(hipMalloc(&g->asc_dio, n_io * 2 * 8));
+            g->asc_io_cap = n_io * 2;
+        }
+        std::memcpy(g->asc_hio, lb, (size_t)d * 8);
+        std::memcpy(g->asc_hio + d, ub, (size_t)d * 8);
+        std::memcpy(g->asc_hio + 2 * d, starts, (size_t)R * d * 8);
+        HIPCHK(hipMemcpyAsync(g->asc_dio, g->asc_hio, n_in * 8, hipMemcpyHostToDevice, g->stream));
+        pw.beta = g->beta; pw.st = st; pw.starts = g->asc_dio + 2 * d; pw.lb = g->asc_dio; pw.ub = g->asc_dio + d; pw.R = (int)R;
         pw.maxeval = (int)std::min<int64_t>(maxeval, 1 << 30); pw.ftol_rel = ftol_rel; pw.xtol_abs = xtol_abs; pw.first_step_scale = 0.1 * span;
         pw.max_ticks = g->asc_maxtime > 0.0 ? (unsigned long long)(g->asc_maxtime * 1e8) : 0ull;
         pw.passes = st.accepted;
@@ -2218,18 +2240,21 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         else hipLaunchKernelGGL(k_ascent_wg<16>, dim3(nR), dim3(AWG_THREADS), 0, g->stream, pw);
         HIPCHK(hipGetLastError());
         t_end(g);
-        hipLaunchKernelGGL(k_asc_final, dim3(1), dim3(256), 0, g->stream, st, d, (int)R, g->asc_best, dbx);
+        double* dout = g->asc_dio + n_io;   // (second half of the device block: the inputs are still being read by the kernel above)
+        hipLaunchKernelGGL(k_asc_final, dim3(1), dim3(256), 0, g->stream, st, d, (int)R, g->asc_best, dbx, dout, st.accepted);
         HIPCHK(hipGetLastError());
-        std::vector<int> passes((size_t)R);
-        HIPCHK(hipMemcpyAsync(passes.data(), st.accepted, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, g->stream));
-        if (f_out) HIPCHK(hipMemcpyAsync(f_out, st.best_f, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
-        if (x_out) HIPCHK(hipMemcpyAsync(x_out, st.best_X, (size_t)R * d * 8, hipMemcpyDeviceToHost, g->stream));
-        if (best) HIPCHK(hipMemcpyAsync(best, g->asc_best, sizeof(Best), hipMemcpyDeviceToHost, g->stream));
-        if (best_x) HIPCHK(hipMemcpyAsync(best_x, dbx, (size_t)d * 8, hipMemcpyDeviceToHost, g->stream));
+        double* hout = g->asc_hio + n_io;
+        HIPCHK(hipMemcpyAsync(hout, dout, n_out * 8, hipMemcpyDeviceToHost, g->stream));
         HIPCHK(hipStreamSynchronize(g->stream));
-        if (best && best_x && best->idx < 0)
-            for (int k = 0; k < d; ++k) best_x[k] = lb[k];   // :56  maxx = lowerbounds when nothing beat -Inf
-        if (evals_out) *evals_out = *std::max_element(passes.begin(), passes.end());
+        if (best) { best->val = hout[0]; best->idx = (long long)hout[1]; }
+        if (best_x) for (int k = 0; k < d; ++k) best_x[k] = hout[1] >= 0.0 ? hout[2 + k] : lb[k];   // :56  maxx = lowerbounds when nothing beat -Inf
+        if (f_out) std::memcpy(f_out, hout + 2 + d, (size_t)R * 8);
+        if (x_out) std::memcpy(x_out, hout + 2 + d + R, (size_t)R * d * 8);
+        if (evals_out) {
+            double mx = 0.0;
+            for (int64_t r = 0; r < R; ++r) mx = std::max(mx, hout[2 + d + R + (size_t)R * d + r]);
+            *evals_out = (int64_t)mx;
+        }
         t_collect(g);
         return 0;
     }

@@ -521,8 +521,11 @@ __global__ __launch_bounds__(AWG_THREADS) void k_ascent_wg(AscWgParams p) {
 }
 
 // (value desc, index asc) over best_f; NaN never wins.  One workgroup.
+// packed != nullptr: everything the caller reads back in ONE block -- [best value, best index, best_x (d), f (R), X (R d), passes (R)]
+// (eight pageable copies per acquire_max were 0.1 ms of a 0.27 ms call on a small model)
 __global__ __launch_bounds__(256) void k_asc_final(AscentState st, int d, int R, Best* __restrict__ best,
-                                                   double* __restrict__ best_x) {
+                                                   double* __restrict__ best_x, double* __restrict__ packed = nullptr,
+                                                   const int* __restrict__ passes = nullptr) {
     __shared__ double sv[256];
     __shared__ long long si[256];
     double v = -INFINITY;
@@ -547,6 +550,15 @@ __global__ __launch_bounds__(256) void k_asc_final(AscentState st, int d, int R,
     const long long w = si[0];
     if (threadIdx.x == 0) { best->val = w >= 0 ? sv[0] : -INFINITY; best->idx = w; }
     if (w >= 0 && (int)threadIdx.x < d) best_x[threadIdx.x] = st.best_X[w * d + threadIdx.x];
+    if (packed) {
+        if (threadIdx.x == 0) { packed[0] = w >= 0 ? sv[0] : -INFINITY; packed[1] = (double)w; }
+        if ((int)threadIdx.x < d) packed[2 + threadIdx.x] = w >= 0 ? st.best_X[w * d + threadIdx.x] : 0.0;
+        for (int r = threadIdx.x; r < R; r += 256) {
+            packed[2 + d + r] = st.best_f[r];
+            packed[2 + d + R + (int64_t)R * d + r] = passes ? (double)passes[r] : 0.0;
+        }
+        for (int64_t e = threadIdx.x; e < (int64_t)R * d; e += 256) packed[2 + d + R + e] = st.best_X[e];
+    }
 }
 
 }  // namespace bohip
