@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bohip
 from bohip.acquisition import _batched_lbfgs_ascent
 rng = np.random.default_rng(0)
-for N, d in ((500, 2), (3000, 8), (10000, 16)):
+for N, d in ((50, 2), (200, 2), (500, 2), (3000, 8), (10000, 16)):   # (N <= 256: one launch, one workgroup per start point)
     X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
     m = bohip.ElasticGPE(d, kernel=bohip.SEArd(np.full(d, np.log(0.5)), 0.0), logNoise=-2.0, capacity=N)
     m.append_(X.T, y)
