@@ -773,6 +773,11 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
     // the executor's share ends one block earlier)
     auto e_of = [](int i, int c) { return i <= c + 2 ? i - 6 : c - 3; };
     std::vector<ExTask> q[EX_NQ];
+    {   // (rough upper bounds: growing the vectors record by record was a third of the 32 ms this takes at T = 79)
+        const size_t t1 = (size_t)T, t2 = t1 * t1, t3 = t2 * t1;
+        const size_t cap[EX_NQ] = {32 * t1, 4 * t2, 2 * t2, 6 * t2 + 64, t3 / 10 + t2 + 64, inv_g > 0 ? t3 / (2 * (size_t)inv_g) + t2 + 64 : 0};
+        for (int qi = 0; qi < EX_NQ; ++qi) q[qi].reserve(cap[qi]);
+    }
     struct Dep { uint32_t idx, want; };
     auto add = [&](int qi, const double* A, const double* B, double* C, const double* P, int kc_h0, int kc_h1, bool diag, int rmw,
                    std::initializer_list<Dep> deps, uint32_t s0, uint32_t s1, int kc_split = 0, Dep d2a = Dep{EX_NONE, 0},
@@ -954,6 +959,11 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
         }
     }
     all.clear();
+    {
+        size_t total = 0;
+        for (int qi = 0; qi < EX_NQ; ++qi) total += q[qi].size();
+        all.reserve(total);
+    }
     qbeg[0] = 0;
     for (int qi = 0; qi < EX_NQ; ++qi) {
         all.insert(all.end(), q[qi].begin(), q[qi].end());
