@@ -745,7 +745,8 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
     return 0;
 }
 
-// ---- A2, executor form (kernels_exec.hip): the chain + ONE persistent kernel that pulls tile tasks from three in-order queues.
+// ---- A2, executor form (kernels_exec.hip): the chain + ONE persistent kernel that pulls tile tasks from six in-order queues
+// (four feed the factorisation's pivot chain, two grow W = L^-1 behind it).
 // The records are a pure function of (buffer addresses, ld, T): built on the host at the first factorisation with this T,
 // then resident.  Layout of the counters inside the flag area (all zeroed per factorisation):
 //   tile (i, c), i >= c+2:  ver = xp[((c-1) T + i) 8 + 0], pver = xp[.. + 1]   (the chain uses xp[(k T + i) 8 + p] for i = k+1, k+2 only)

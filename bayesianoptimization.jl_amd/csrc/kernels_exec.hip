@@ -1,5 +1,5 @@
-// kernels_exec.hip -- the tile-task executor of the blocked Cholesky factorisation for LARGE T (row A2 of SURVEY.md section 8;
-// reference call sites: update!/fit! at src/models/gp.jl:11-18, i.e. the LAPACK potrf behind ElasticPDMats).
+// kernels_exec.hip -- the tile-task executor of the blocked Cholesky factorisation AND of the triangular inverse W = L^-1 (row A2 of
+// SURVEY.md section 8; reference call sites: update!/fit! at src/models/gp.jl:11-18, i.e. the LAPACK potrf behind ElasticPDMats).
 //
 // Why.  The second dataflow form (cholesky_dataflow2/3 in bohip.hip) feeds the persistent chain (k_chol_chain) from ~4 launches
 // per 128-block on three streams: every flagged launch parks hundreds of workgroups that spin on flags inside the kernel (at
@@ -7,41 +7,48 @@
 // in-order streams put a 1 ms bulk launch in front of the 0.1 ms one the chain needs next, and the left-looking column update
 // (K up to 1024, one workgroup per tile) sat on the critical path of every block: 11.7 ms for 333 GF.
 //
-// Here everything outside the chain is a TASK = one 128 x 64 half tile  C = beta C + alpha A B' (- P)  on the contraction engine
-// of gemm_core.h, described by an immutable 128-byte record the host writes once per (handle, T).  ONE persistent kernel
-// (k_chol_exec, 512 workgroups = two per CU) executes them: a workgroup that is free looks at the heads of four in-order
-// queues, highest priority first, CLAIMS the first head whose dependencies are met (compare-and-swap on the queue cursor)
-// and runs it.  Nobody ever holds a task it cannot run, so no workgroup slot is spent spinning, no launch boundary and no host
-// event sits between dependent tasks, and progress does not depend on how many executor workgroups are resident.
+// Here everything outside the chain is a TASK = one 128 x 64 half tile  C = C - A B' - P,  C = A B'  or  C = -A B'  (optionally
+// stored a second time, transposed) on the contraction engine of gemm_core.h, described by an immutable 128-byte record the host
+// writes once per (handle, T).  ONE persistent kernel (k_chol_exec, 512 workgroups = two per CU) executes them: a workgroup that
+// is free looks at the heads of six in-order queues, highest priority first, and claims from the first one whose head is
+// runnable with a fetch-and-add; a record it got a little ahead of its counters is HELD and polled (see k_chol_exec).  No launch
+// boundary and no host event sits between dependent tasks, and progress does not depend on how many executor workgroups are
+// resident.
 //
-//   queue 0  URGENT, per block k: Late(k) of the tiles the chain kernel itself reads next -- (k+3, k+1), (k+3, k+2), (k+3, k+3), which
-//            its followers and gated updates wait for, and (k+4 .. k+2+nsf, k+1), which its solve followers read.  Their own
-//            queue: queued behind the far rows of the block before (which wait for that block's inverse and row solves) they
-//            were claimed 40-80 us late, and a follower that starts late never catches up
+//   queue 0  URGENT, per block k: Late(k) of the tiles the chain kernel itself reads next -- (k+4 .. k+2+nsf, k+1), which its solve
+//            followers read, and the three tiles of row k+4 that its gated updates finish during block k+1 -- and the row steps of
+//            the next two rows.  Their own queue and their own 32 workgroups: queued behind the far rows of the block before
+//            (which wait for that block's inverse and row solves) they were claimed 40-80 us late, and a follower that starts
+//            late never catches up
 //   queue 1  per block k:  Solve(i, k) = A(i, k) W_kk'  for the rows the chain does not solve itself (W_kk: the chain's inverter
 //            workgroup), then Late(k) of column k+1 for those rows: blocks k-1 and k (K = 256) and the pre-summed older blocks P
 //   queue 2  Early(k): P(i, c) = sum over the window's blocks up to k of S(i, b) S(c, b)' for the tiles Late(k+2) will finish
 //            (K = 128 .. 640; depends on S only, two blocks of slack) -- takes the long contraction off the critical path
-//   queue 3  bulk: group m (blocks 4m .. 4m+3, K = 512) applied to every tile of the columns >= 4m+8, column-major, so that
+//   queue 3  the triangular inverse W = L^-1 (what the scoring path contracts with), ROW CHAIN.  W(i, j) = W_ii Z(i, j),
+//            Z(i, j) = -sum_{k=j}^{i-1} L(i, k) W(k, j): row i needs row i of L (final one block before pivot i) and the rows
+//            < i of W, so its work (~ i^2) becomes available as the factorisation's own work (~ (T-k)^2 per block) dries up: the
+//            two fill each other's idle time.  This queue holds what is serial from row to row: the last pieces of Z (the last
+//            one also stores Z' to the mirror tile of W -- strictly upper, read by nobody else) and the product with W_ii, which
+//            stores W(i, j) and the same entries as W'(j, i).  Little work: ABOVE the bulk, or it starts when the bulk ends
+//   queue 4  bulk: group m (blocks 4m .. 4m+3, K = 512) applied to every tile of the columns >= 4m+8, column-major, so that
 //            the four columns the chain reaches next are done first
-//   queue 4  the triangular inverse W = L^-1 (what the scoring path contracts with), grown row by row BEHIND the chain instead
-//            of after the factorisation: W(i, j) = W_ii Z(i, j), Z(i, j) = -sum_{k=j}^{i-1} L(i, k) W(k, j).  Row i needs row i of L
-//            (final one block before pivot i) and the rows < i of W, so its work (~ i^2) becomes available as the factorisation's
-//            own work (~ (T-k)^2 per block) dries up: the two fill each other's idle time.  Nothing outside this queue ever
-//            waits for it.  Z is accumulated in place (pieces of <= G blocks, in order), its last piece also stores Z' to the
-//            mirror tile of W (strictly upper: never read by anybody else), from where the product with W_ii reads it as the
-//            K-major operand; that product stores W(i, j) and the same entries as W'(j, i).
+//   queue 5  the inverse's WAVES: chunk m of the contraction (G blocks) pushed to every row below it as soon as the chunk's rows
+//            of W are final -- most of the inverse's flops, thousands of independent tasks, lowest priority.  Nothing outside
+//            the queues 3 and 5 ever waits for them
 //
 // Dependencies are counters in the flag area (one word per producer granule, each finished task adds 8 = its waves):
 //   ver(i, c)   read-modify-write rounds completed on tile (i, c): bulk group m needs 16 m, Late needs 16 (number of groups)
 //   pver(i, c)  P(i, c) is complete (16)
 //   sver(i, k)  S(i, k) is complete (16)          [the words colr[k T + i] of CholFlags]
 //   solved[k], xp[..][7]   raised by the chain (inverse of the diagonal block; rows k+1, k+2 of L(:, k))
-//   rest[k]     48 = the three first-row tiles of Late(k): what the chain's followers and gated updates of block k+1 wait for
+//   pre3[4k+j]  16 = tile (k+3, k+1+j) carries every block before k (the executor's share): what the chain kernel's gated updates
+//               of row k+3 wait for before they add block k; THEY raise rest[k], which the chain's followers of block k+1 wait for
+//   zver / zt / wfin(i, j)   the inverse: rounds completed on Z(i, j) (16 each), Z' stored, W(i, j) and W'(j, i) final
 // Every datum a running kernel reads is written with agent-scope (sc1, write-through) 16-byte stores behind an explicit
 // s_waitcnt vmcnt(0); the read-modify-write operands (old tile value, P) are fetched with sc1 loads, which bypass the CU's
 // vector L1 -- the executor lives for the whole factorisation, so no kernel boundary ever invalidates that cache.  Operand
-// tiles that go through LDS-DMA (S, the finished A(i, k), W_kk) are written exactly once before anybody reads them.
+// tiles that go through LDS-DMA (S, the finished A(i, k), W_kk, Z', W') are never written again once a task has read them that
+// way (tests/test_exec_tasks.py asserts it for every record).
 #include "gemm_core.h"
 
 namespace bohip {
@@ -91,7 +98,7 @@ struct ExQueues {
 };
 
 // Claim the next task.  Run by the 64 lanes of wave 0: lane 8 q + d looks at dependency d of the head of queue q, so the heads
-// of all three queues are examined in one round of parallel loads (a one-lane version walked ~20 dependent memory round trips
+// of all queues are examined in one round of parallel loads (a one-lane version walked ~20 dependent memory round trips
 // per look, and as every free workgroup looked at the SAME head and only one compare-and-swap could win, the claims were
 // serialised at ~0.2 per microsecond: first light of this kernel ran at 1.2 TF/s).  A queue whose head is runnable is claimed
 // with ONE fetch-and-add; under contention the claimer gets a task a little behind the head it looked at and then waits for
