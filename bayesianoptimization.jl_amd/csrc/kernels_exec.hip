@@ -352,23 +352,25 @@ __device__ __forceinline__ int ex_run(const ExTask& t, const ExQueues& q, double
 //                     claim is a fetch-and-add, so under contention it lands a little behind the head that was seen runnable,
 //                     on a task whose counters may not be in yet.
 //   counters in       run it.
-//   counters not in   HOLD it (slot `pend`).  An urgent task (queue 0) is simply waited for.  Anything else is patient: while it
-//                     waits the workgroup looks at the bulk queue and, if its head is runnable, claims there too -- runs that
-//                     claim if its counters are in, else holds it in the second slot (`pend2`) -- and comes back to the held
-//                     tasks after everything it ran.  (Waiting idle cost ~90 of the ~490 resident workgroups during the
-//                     bulk-bound phase of N = 10^4: rows whose solve was claimed microseconds earlier, Early sums of rows not
-//                     solved yet.)  A workgroup NEVER blocks on one claim while it holds another: the first version of this
-//                     waited for the bulk claim and dead-locked -- a bulk task of the next group waits for blocks the chain can
-//                     only reach once the Early sum held in the other slot has run.  Held tasks are never given back; what a
-//                     held task waits for is running, held by a workgroup that keeps polling it, or the chain's.
+//   counters not in   HOLD it: one slot per kind -- `pend` (queues 1, 2), `pend2` (bulk), `pend3` (inverse).  An urgent task
+//                     (queue 0) is simply waited for.  A held record is usually microseconds from runnable (its producers were
+//                     claimed just before it), so for `patience` the workgroup only polls it; after that it takes what its free
+//                     slots allow -- a held inverse record restricts nothing but other inverse claims (nothing outside the
+//                     inverse ever waits for one); with `pend` occupied only fill-in work: inverse waves, bulk if asked for.
+//                     (Taking a 60-100 us task at once made held records start that much late: on a mostly idle chip the
+//                     inverse's rows fell 150-340 us behind the pivots, N = 6000 cost 5.4 instead of 4.9 ms.)  A workgroup NEVER
+//                     blocks on one claim while it holds another: the first version of this waited for the bulk claim and
+//                     dead-locked -- a bulk task of the next group waits for blocks the chain can only reach once the Early sum
+//                     held in the other slot has run.  Held tasks are never given back; what a held task waits for is running,
+//                     held by a workgroup that keeps polling it, or the chain's.
 __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     __shared__ int s_task, s_cnt, s_cut;
     // the workgroup's scheduling state lives in LDS (wave 0 reads and writes it between tasks): in registers it would be alive
     // across the contraction loop, which has none to spare
     __shared__ int s_look;     // what the look during the previous task's epilogue found ((queue << 24) | head), -1 nothing
-    __shared__ int s_pend;     // a claimed task of the queues 1 .. EX_NQ-2 whose counters were not in when last looked at
-    __shared__ int s_pend2;    // the same for a bulk claim (queue EX_NQ-1)
+    __shared__ int s_pend;     // a claimed task of the queues 1, 2 whose counters were not in when last looked at
+    __shared__ int s_pend2;    // the same for a bulk claim (queue EX_QBULK)
     __shared__ int s_pend2n;   //   records of that bulk claim still to run (0: the whole claim)
     __shared__ int s_pend3;    // a claimed record of the inverse queue whose counters are not in: held in a slot of its own that
                                // restricts nothing -- no other queue and not the chain ever waits for an inverse record, so a
