@@ -3,7 +3,7 @@ src/acquisition.jl.  The functors keep the reference's formulas verbatim (host v
 points and documentation); batches are scored on the device through ``model.score``.
 
 Where the reference runs R sequential NLopt ascents (src/acquisition.jl:58-66), ``acquire_max`` scores /
-ascends ALL R Latin-hypercube starts in lock-step on the GPU:
+ascends ALL R Latin-hypercube starts together on the GPU:
     method :LD_*  -> batched projected L-BFGS driven by the device's analytic gradient (score_grad)
     method :GN_* / :LN_* -> derivative-free: ``maxeval`` candidates scored in one batch
 """
@@ -270,7 +270,7 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None, setparams
     acq, p = a.acq_id, a.params()
     if derivative:
         starts = latin_hypercube_sampling(lb, ub, restarts, rng)
-        # maxeval: NLopt counts objective evaluations per start; the lock-step ascent spends one evaluation of EVERY
+        # maxeval: NLopt counts objective evaluations per start; the batched ascent spends one evaluation of EVERY
         # start per device pass, so the same number bounds the passes.  No other cap.
         iters = max(2, maxeval)
 

@@ -227,7 +227,7 @@ class ElasticGPE:
 
     def ascend(self, acq, params, lowerbounds, upperbounds, starts, maxeval=2000, ftol_rel=1e-10, xtol_abs=1e-10):
         """Local search of acquire_max on the device (src/acquisition.jl:48-68 with :LD_LBFGS and bounds): every start
-        column is refined by a projected L-BFGS ascent, all columns in lock step.  Returns
+        column is refined by a projected L-BFGS ascent, all columns in the same device passes.  Returns
         (f[R], X[d, R], best_f, best_index, best_x[d], evaluations)."""
         starts = _cols(starts, self.dim)
         R = starts.shape[1]

@@ -117,8 +117,8 @@ int bohip_gp_score_grad(bohip_gp *gp, int acq_id, const double *acq_params, cons
 /* ---- acquire_max(acquisition, model, lowerbounds, upperbounds, restarts) for the gradient-based methods (reference
  * src/acquisition.jl:48-68; nlopt_setup :23-35: method :LD_LBFGS, bounds, maxeval, ftol_rel, xtol_abs).
  * starts: d x R start columns (the reference draws them with latin_hypercube_sampling, src/utils.jl:101-120, from
- * Julia's global RNG, so they are an input).  Every start is refined by a projected L-BFGS ascent; all starts advance in
- * lock step, one value+gradient pass of the model per evaluation, the state stays on the device.
+ * Julia's global RNG, so they are an input).  Every start is refined by a projected L-BFGS ascent on the device, each on its
+ * own schedule, one value+gradient pass of the model per evaluation, the state stays on the device.
  * x_out (d x R), f_out (R): best point seen per start (nullable).  best / best_x: the maximiser over the starts under
  * strict '>' (first maximum wins, :58-66); idx = -1 and best_x = lowerbounds if nothing beat -Inf (:55-56).
  * maxeval bounds the number of model passes (NLopt counts per start; here every start consumes one per pass).      */
