@@ -989,6 +989,7 @@ static int build_exec_tasks(bohip_gp* g, int T) {
     return 0;
 }
 
+static int device_cus();
 static int cholesky_exec(bohip_gp* g, int T) {
     const int64_t ld = g->ld;
     CHK(build_exec_tasks(g, T));
@@ -1009,13 +1010,17 @@ static int cholesky_exec(bohip_gp* g, int T) {
         q.ld = ld;
         q.spin_ticks = g_chol_spin_ticks;
         q.fill = g_chol_exec_fill;
-        q.nurgent = std::min(g_chol_exec_wgs / 2, g_chol_exec_urgent);
+        // executor workgroups: two per CU that the chain kernel leaves free (a small partition must not fill its slots with the
+        // urgent queue's own workgroups: nobody would serve the other queues until the time-out)
+        const int cus_free = std::max(1, device_cus() - (9 + g_chol_nsf + 6));
+        const int exec_wgs = std::max(2, std::min(g_chol_exec_wgs, 2 * cus_free));
+        q.nurgent = std::min(exec_wgs / 8, g_chol_exec_urgent);
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
         q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
         q.fill_inv = g_chol_exec_fill_inv;
         q.patience_ticks = (unsigned)g_chol_exec_patience_us * 100u;
         HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
-        hipLaunchKernelGGL(k_chol_exec, dim3(g_chol_exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
+        hipLaunchKernelGGL(k_chol_exec, dim3(exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g->ev_inv, g->col_stream));
         HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
