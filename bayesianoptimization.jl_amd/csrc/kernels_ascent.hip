@@ -28,7 +28,7 @@ struct AscentState {
     // free-running form (k_asc_step): per start point its own iteration count and backtracking count, and per evaluation pass a
     // ring slot: how many start points are still active after it (device counters + the word the host polls, value + 1)
     int *it, *bt;
-    unsigned *nact, *ticket;    // [ASC_RING]
+    unsigned *nact, *ticket;    // nact: [ASC_RING] 64-bit counters (arrivals | active << 32), 8-byte aligned; ticket: unused half
     int *h_cnt;                 // [ASC_RING] pinned
 };
 constexpr int ASC_RING = 8;
@@ -290,14 +290,13 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
         }
     }
     if (k == 0 && ring_slot >= 0) {
-        if (active) atomicAdd(st.nact + ring_slot, 1u);
-        __threadfence();
-        const unsigned t = atomicAdd(st.ticket + ring_slot, 1u);
-        if (t == (unsigned)R - 1u) {   // the last workgroup of this pass publishes the count and clears the slot for its next use
-            __threadfence();
-            const unsigned n = atomicAdd(st.nact + ring_slot, 0u);
-            st.nact[ring_slot] = 0u;
-            st.ticket[ring_slot] = 0u;
+        // ONE 64-bit counter per pass: arrivals in the low word, still-active start points in the high word -- no fence between
+        // two counters (a __threadfence() is an L2 write-back here: microseconds per workgroup)
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(st.nact) + ring_slot;
+        const unsigned long long before = atomicAdd(cnt, 1ull + ((unsigned long long)(active ? 1 : 0) << 32));
+        if ((unsigned)(before & 0xffffffffull) == (unsigned)R - 1u) {   // the last workgroup of this pass publishes the count and clears the slot
+            const unsigned n = (unsigned)(before >> 32) + (active ? 1u : 0u);
+            __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(st.h_cnt + ring_slot, (int)n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }

@@ -485,22 +485,23 @@ __global__ __launch_bounds__(256) void k_small_finish(const double* __restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        q[r] = red[0];
-        mu_raw[r] = v[N];
-        __threadfence();
+        // agent-scope stores + an explicit wait instead of __threadfence(): the fence is an L2 write-back on this chip (7-60 us for
+        // a device-wide hand-over, tools/ubench_gridbar.hip), the write-through stores cost nothing beside it
+        __hip_atomic_store(q + r, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mu_raw + r, v[N], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         is_last = atomicAdd(counter, 1u) == (unsigned)(R - 1);
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
     if (threadIdx.x == 0) *counter = 0u;
     double f_best = -INFINITY;
     long long idx = -1;
     if ((int)threadIdx.x < R) {
         const int c = threadIdx.x;
-        double s2 = sigma2 - ((const volatile double*)q)[c];
+        double s2 = sigma2 - __hip_atomic_load(q + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s2 < 0.0) s2 = 0.0;  // predict_f: max(sigma2, 0)
-        const double mu = beta + ((const volatile double*)mu_raw)[c];
+        const double mu = beta + __hip_atomic_load(mu_raw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (mu_out) mu_out[c] = mu;
         if (var_out) var_out[c] = s2;
         const double f = acq_eval(ap, mu, s2);
@@ -635,13 +636,13 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
     if (S > 1) {
         double* mine = parts + ((int64_t)blockIdx.x * S + sp) * 2 * DT;
         if (threadIdx.x < 2 * d)
-            mine[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        __threadfence();
+            __hip_atomic_store(mine + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (agent-scope stores + this wait, not __threadfence(): see k_small_finish)
         __syncthreads();
         if (threadIdx.x == 0) is_last = atomicAdd(&counters[blockIdx.x], 1u) == (unsigned)(S - 1);
         __syncthreads();
         if (!is_last) return;
-        __threadfence();
         if (threadIdx.x == 0) counters[blockIdx.x] = 0u;
     }
     if (threadIdx.x < d) {
@@ -649,8 +650,11 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
         double a, b;
         if (S > 1) {
             a = 0.0; b = 0.0;
-            const volatile double* all = parts + (int64_t)blockIdx.x * S * 2 * DT;
-            for (int q = 0; q < S; ++q) { a += all[q * 2 * DT + 2 * k]; b += all[q * 2 * DT + 2 * k + 1]; }
+            const double* all = parts + (int64_t)blockIdx.x * S * 2 * DT;
+            for (int q = 0; q < S; ++q) {
+                a += __hip_atomic_load(all + q * 2 * DT + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b += __hip_atomic_load(all + q * 2 * DT + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             a = (red[0][2 * k] + red[1][2 * k]) + (red[2][2 * k] + red[3][2 * k]);
             b = (red[0][2 * k + 1] + red[1][2 * k + 1]) + (red[2][2 * k + 1] + red[3][2 * k + 1]);
