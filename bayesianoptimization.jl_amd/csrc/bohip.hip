@@ -1404,7 +1404,9 @@ static int ensure_xs(bohip_gp* g, int64_t R) {
 
 template <int DT>
 static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, int64_t Npad, const KernelHyper& hp) {
-    const int rb = 16;  // 16 candidates per block: N/256 x R/16 blocks keep >= 8 waves per SIMD in flight (latency-bound loop)
+    // 16 candidates per block: N/256 x R/16 blocks keep >= 8 waves per SIMD in flight (latency-bound loop); a handful of candidates:
+    // two per block (ten in a row on 12 workgroups were a serial chain of ten `exp`s per thread)
+    const int rb = r1 - r0 <= 32 ? 2 : 16;
     dim3 grid((Npad + 255) / 256, (r1 - r0 + rb - 1) / rb);
     hipLaunchKernelGGL(k_kstar<DT>, grid, dim3(256), 0, g->stream, g->dX, g->n, Npad, dXs, r0, r1, hp, g->dKsT, g->ld, rb);
 }

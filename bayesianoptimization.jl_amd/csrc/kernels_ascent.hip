@@ -200,27 +200,37 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
                                              const double* __restrict__ ub, double ftol_rel, double xtol_abs, int ring_slot) {
     const bool on = k < d;
     const int64_t o = (int64_t)r * d + k;
+    // everything the step may need, in ONE round of loads (taken one by one as the branches reach them they were a chain of
+    // five or six dependent memory round trips: 8 us for a few hundred flops)
     int active = st.active[r];
+    const double lo = on ? lb[k] : 0.0, hi = on ? ub[k] : 0.0;
+    const double x = on ? st.X[o] : 0.0, xt = on ? st.Xt[o] : 0.0, gpo = on ? st.Gp[o] : 0.0;
+    const double g_old = on ? st.G[o] : 0.0, g_trial = on ? st.Gt[o] : 0.0, d_old = on ? st.D[o] : 0.0;
+    const double ft = st.ft[r], f = st.f[r], step_old = st.step[r], best_before = st.best_f[r];
+    const int bt = st.bt[r], it = st.it[r];
+    double sv[ASC_M], yv[ASC_M];   // the curvature pairs (slot order), also in flight now
+#pragma unroll
+    for (int i = 0; i < ASC_M; ++i) {
+        const int64_t ho = ((int64_t)i * R + r) * d + k;
+        sv[i] = on ? st.S[ho] : 0.0;
+        yv[i] = on ? st.Y[ho] : 0.0;
+    }
     if (active) {
-        const double lo = on ? lb[k] : 0.0, hi = on ? ub[k] : 0.0;
-        const double x = on ? st.X[o] : 0.0, xt = on ? st.Xt[o] : 0.0, gpo = on ? st.Gp[o] : 0.0;
         const double dot = asc_wsum(on ? gpo * (xt - x) : 0.0);
-        const double ft = st.ft[r], f = st.f[r];
         const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
-        const int bt = st.bt[r];
         if (!ok && bt < 11) {
-            const double step = st.step[r] * 0.5;
-            if (on) st.Xt[o] = asc_clip(x + step * st.D[o], lo, hi);
+            const double step = step_old * 0.5;
+            if (on) st.Xt[o] = asc_clip(x + step * d_old, lo, hi);
             if (k == 0) { st.step[r] = step; st.bt[r] = bt + 1; }
         } else {
             // ---- the iteration ends (k_asc_update with Xn = the accepted trial, or X itself after 12 failures)
-            const double g = on ? st.G[o] : 0.0;
-            const double xn = ok ? xt : x, gn = ok ? (on ? st.Gt[o] : 0.0) : g, fn = ok ? ft : f;
-            const double s = xn - x, y = -(gn - g), df = fn - f, best_before = st.best_f[r];
+            const double g = g_old;
+            const double xn = ok ? xt : x, gn = ok ? g_trial : g, fn = ok ? ft : f;
+            const double s = xn - x, y = -(gn - g), df = fn - f;
             const double moved = sqrt(asc_wsum(s * s));
             const bool good = asc_wsum(s * y) > 1e-14;
             active = (df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs) ? 1 : 0;
-            const int it = st.it[r], slot = it % ASC_M;
+            const int slot = it % ASC_M;
             const double s_new = good ? s : 0.0, y_new = good ? y : 0.0;
             if (on) {
                 const int64_t ho = ((int64_t)slot * R + r) * d + k;
@@ -239,19 +249,31 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
             double xt_new = xn;
             if (active) {
                 // ---- the next direction (k_asc_direction at x = xn, g = gn; the newest pair is the one just written: taken
-                // from registers, the older ones from memory -- every lane reads only elements it wrote itself)
+                // from registers, the older ones were loaded up front by slot -- every lane reads only elements it wrote itself)
                 const int nh = it + 1 < ASC_M ? it + 1 : ASC_M, newest = slot;
+                auto pair_s = [&](int i) {   // i-th newest pair (i = 0: the one just made)
+                    const int sl = (newest - i + ASC_M) % ASC_M;
+                    double v = 0.0;
+#pragma unroll
+                    for (int t = 0; t < ASC_M; ++t) v = t == sl ? sv[t] : v;
+                    return i == 0 ? s_new : v;
+                };
+                auto pair_y = [&](int i) {
+                    const int sl = (newest - i + ASC_M) % ASC_M;
+                    double v = 0.0;
+#pragma unroll
+                    for (int t = 0; t < ASC_M; ++t) v = t == sl ? yv[t] : v;
+                    return i == 0 ? y_new : v;
+                };
                 double q = gn;
                 double al[ASC_M], rho[ASC_M];
 #pragma unroll
                 for (int i = 0; i < ASC_M; ++i) {   // newest -> oldest
                     if (i >= nh) break;
-                    const int sl = (newest - i + ASC_M) % ASC_M;
-                    const int64_t ho = ((int64_t)sl * R + r) * d + k;
-                    const double sv = i == 0 ? s_new : (on ? st.S[ho] : 0.0), yv = i == 0 ? y_new : (on ? st.Y[ho] : 0.0);
-                    rho[i] = 1.0 / fmax(asc_wsum(yv * sv), 1e-300);
-                    al[i] = rho[i] * asc_wsum(sv * q);
-                    q -= al[i] * yv;
+                    const double ps = pair_s(i), py = pair_y(i);
+                    rho[i] = 1.0 / fmax(asc_wsum(py * ps), 1e-300);
+                    al[i] = rho[i] * asc_wsum(ps * q);
+                    q -= al[i] * py;
                 }
                 {
                     const double sy = asc_wsum(s_new * y_new), yy = fmax(asc_wsum(y_new * y_new), 1e-300);
@@ -260,11 +282,9 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
 #pragma unroll
                 for (int i = ASC_M - 1; i >= 0; --i) {   // oldest -> newest
                     if (i >= nh) continue;
-                    const int sl = (newest - i + ASC_M) % ASC_M;
-                    const int64_t ho = ((int64_t)sl * R + r) * d + k;
-                    const double sv = i == 0 ? s_new : (on ? st.S[ho] : 0.0), yv = i == 0 ? y_new : (on ? st.Y[ho] : 0.0);
-                    const double b = rho[i] * asc_wsum(yv * q);
-                    q += (al[i] - b) * sv;
+                    const double ps = pair_s(i), py = pair_y(i);
+                    const double b = rho[i] * asc_wsum(py * q);
+                    q += (al[i] - b) * ps;
                 }
                 double D = q;
                 if ((xn <= lo && D < 0.0) || (xn >= hi && D > 0.0)) D = 0.0;
