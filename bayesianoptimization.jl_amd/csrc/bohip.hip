@@ -1445,7 +1445,7 @@ static int launch_kstar_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t 
 // Small-batch posterior (R <= SMALL_R): V' rows into dApp[0..R), q and mu_raw; optionally U' = V' W into dApp[APP_UT_ROW0..).
 static int ensure_small_counters(bohip_gp* g) {
     if (g->dgparts) return 0;
-    HIPCHK(hipMalloc(&g->dgparts, (size_t)SMALL_MAX * 16 * 2 * DMAX * 8));
+    HIPCHK(hipMalloc(&g->dgparts, (size_t)SMALL_MAX * 16 * (2 * DMAX + 2) * 8));
     HIPCHK(hipMalloc(&g->dgcount, (SMALL_MAX + 1) * sizeof(unsigned)));   // [0, SMALL_MAX): k_grad_finish, [SMALL_MAX]: k_small_finish
     HIPCHK(hipMemsetAsync(g->dgcount, 0, (SMALL_MAX + 1) * sizeof(unsigned), g->stream));
     return 0;
@@ -1628,7 +1628,7 @@ static int score_core(bohip_gp* g, int acq_id, const double* acq_params, const d
 
 template <int DT>
 static void launch_grad(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, const KernelHyper& hp, const AcqParams& ap,
-                        double* d_grad, const double* UT, int S) {
+                        double* d_grad, const double* UT, int S, const GradQ& gq) {
     if constexpr (DT <= 16) {   // large batches: 4 candidates per workgroup share the observation stream
         if (r1 - r0 > SMALL_MAX) {
             hipLaunchKernelGGL(k_grad_finish_tiled<DT>, dim3((unsigned)((r1 - r0 + GC - 1) / GC)), dim3(256), 0, g->stream, g->dX, g->n,
@@ -1637,20 +1637,20 @@ static void launch_grad(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, 
         }
     }
     hipLaunchKernelGGL(k_grad_finish<DT>, dim3((unsigned)(r1 - r0), (unsigned)S), dim3(256), 0, g->stream, g->dX, g->n, dXs, r0, r1,
-                       hp, g->dalpha, UT, g->ld, g->dmu, g->dvar, ap, d_grad, g->dgparts, g->dgcount);
+                       hp, g->dalpha, UT, g->ld, g->dmu, g->dvar, ap, d_grad, g->dgparts, g->dgcount, gq);
 }
 static int launch_grad_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, const KernelHyper& hp, const AcqParams& ap,
-                           double* d_grad, const double* UT) {
+                           double* d_grad, const double* UT, const GradQ& gq = GradQ{}) {
     // small batches: split the observations over S workgroups per candidate (see k_grad_finish)
     int S = 1;
     if (r1 - r0 <= SMALL_MAX) S = (int)std::min<int64_t>(16, std::max<int64_t>(1, g->n / 768));
     if (S > 1) CHK(ensure_small_counters(g));
-    if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
-    else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
-    else if (g->d <= 8) launch_grad<8>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
-    else if (g->d <= 16) launch_grad<16>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
-    else if (g->d <= 32) launch_grad<32>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
-    else launch_grad<64>(g, dXs, r0, r1, hp, ap, d_grad, UT, S);
+    if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad, UT, S, gq);
+    else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad, UT, S, gq);
+    else if (g->d <= 8) launch_grad<8>(g, dXs, r0, r1, hp, ap, d_grad, UT, S, gq);
+    else if (g->d <= 16) launch_grad<16>(g, dXs, r0, r1, hp, ap, d_grad, UT, S, gq);
+    else if (g->d <= 32) launch_grad<32>(g, dXs, r0, r1, hp, ap, d_grad, UT, S, gq);
+    else launch_grad<64>(g, dXs, r0, r1, hp, ap, d_grad, UT, S, gq);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1674,9 +1674,21 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
     if (path_R(g, R) <= small_limit(g) && R <= SMALL_MAX) {  // the reference's default: a handful of L-BFGS restarts per call
-        CHK(small_posterior(g, dXs, 0, R, true, ap, g->dmu, g->dvar, d_score, nullptr));
+        // K*' -> V' = K*' W' rows (row-wise) -> U' = V' W rows -> ONE finishing kernel: q, mu, sigma^2, value and gradient
+        CHK(ensure_small_counters(g));
+        t_begin(g, "kstar");
+        CHK(launch_kstar_any(g, dXs, 0, R, Npad, hp));
+        t_end(g);
+        t_begin(g, "small_V");
+        CHK(launch_rows_trimv(g, g->dW, N + 1, g->dKsT, (int)R, g->dApp, 0));
+        t_end(g);
+        g->q_tiles = 1;
+        t_begin(g, "small_U");
+        CHK(launch_rows_trimv(g, g->dWT, N, g->dApp, (int)R, g->dApp + (int64_t)APP_UT_ROW0 * g->ld, 1));
+        t_end(g);
         t_begin(g, "grad");
-        CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld));
+        GradQ gq{g->dApp, g->ld, std::exp(2.0 * g->logsig), g->beta, g->dmu, g->dvar, d_score};
+        CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld, gq));
         t_end(g);
         return 0;
     }

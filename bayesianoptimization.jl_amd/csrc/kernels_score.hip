@@ -575,6 +575,34 @@ __device__ __forceinline__ void acq_partials(const AcqParams& a, double mu, doub
     }
 }
 
+// Small batches: the posterior finish (q = sum V^2, mu, sigma^2, acquisition value: what k_small_finish does) rides on this kernel --
+// one launch (~7 us, whatever it does) less per value+gradient pass.  VT == nullptr: off (mu / var come from the caller).
+// q = sum_j V'[r][j]^2, sigma^2 and mu in EXACTLY the operations and order of k_small_finish (256 lane-strided sums, halving tree,
+// no contraction): the value path and the gradient path agree on the scores bit for bit (tests/test_parity_gpu.py test_score_grad_vs_oracle)
+__device__ __forceinline__ double sumsq_like_small_finish(const double* __restrict__ v, int64_t N, double* red) {
+#pragma clang fp contract(off)
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < N; j += 256) s += v[j] * v[j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    return red[0];
+}
+__device__ __forceinline__ void posterior_like_small_finish(double sigma2, double beta, double q, double mu_raw, double& mu, double& s2) {
+#pragma clang fp contract(off)
+    s2 = sigma2 - q;
+    if (s2 < 0.0) s2 = 0.0;  // predict_f: max(sigma2, 0)
+    mu = beta + mu_raw;
+}
+struct GradQ {
+    const double* VT;   // [R][ldv]  V' rows; entry N of a row is mu - beta
+    int64_t ldv;
+    double sigma2, beta;
+    double *mu_out, *var_out, *score_out;
+};
 template <int DT>
 __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ X, int64_t N,
                                                      const double* __restrict__ Xs, int64_t r_begin, int64_t r_end,
@@ -582,14 +610,15 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
                                                      const double* __restrict__ UT, int64_t ldu,
                                                      const double* __restrict__ mu, const double* __restrict__ var,
                                                      AcqParams ap, double* __restrict__ grad,
-                                                     double* __restrict__ parts, unsigned* __restrict__ counters) {
+                                                     double* __restrict__ parts, unsigned* __restrict__ counters, GradQ gq) {
     // workgroup (r, sp): candidate r, observations [sp len, (sp + 1) len): 256 threads stride them, 2d sums reduced in
     // a fixed order.  gridDim.y = 1 for large batches (one workgroup per candidate is plenty); for a handful of
     // candidates the observations are split over gridDim.y workgroups (a single workgroup walking N = 10^4
     // observations is latency-bound: 140 us), the LAST one to finish adds the partial sums in split order -- the
     // result depends on (N, gridDim.y) only, never on the batch -- and leaves the counter at zero for the next call.
-    __shared__ double red[4][2 * DT];
+    __shared__ double red[4][2 * DT + 2];
     __shared__ int is_last;
+    constexpr int PS = 2 * DT + 2;   // partial record of one split: 2 DT gradient sums + the split's part of q
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r = r_begin + blockIdx.x;
     if (r >= r_end) return;
@@ -601,6 +630,7 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
 #pragma unroll
     for (int k = 0; k < DT; ++k) { gm[k] = 0.0; gv[k] = 0.0; }
     const double* u = UT + (r - r_begin) * ldu;
+    const double* vq = gq.VT ? gq.VT + (r - r_begin) * gq.ldv : nullptr;
     for (int64_t j = j_lo + threadIdx.x; j < j_hi; j += 256) {
         double t[DT], rr = 0.0;
 #pragma unroll
@@ -634,10 +664,11 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
         }
     __syncthreads();
     if (S > 1) {
-        double* mine = parts + ((int64_t)blockIdx.x * S + sp) * 2 * DT;
+        double* mine = parts + ((int64_t)blockIdx.x * S + sp) * PS;
         if (threadIdx.x < 2 * d)
             __hip_atomic_store(mine + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (agent-scope stores + this wait, not __threadfence(): see k_small_finish)
         __syncthreads();
         if (threadIdx.x == 0) is_last = atomicAdd(&counters[blockIdx.x], 1u) == (unsigned)(S - 1);
@@ -645,22 +676,38 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
         if (!is_last) return;
         if (threadIdx.x == 0) counters[blockIdx.x] = 0u;
     }
+    double q_all = 0.0;
+    if (vq) {
+        __shared__ double redq[256];
+        q_all = sumsq_like_small_finish(vq, N, redq);
+    }
     if (threadIdx.x < d) {
         const int k = threadIdx.x;
         double a, b;
         if (S > 1) {
             a = 0.0; b = 0.0;
-            const double* all = parts + (int64_t)blockIdx.x * S * 2 * DT;
+            const double* all = parts + (int64_t)blockIdx.x * S * PS;
             for (int q = 0; q < S; ++q) {
-                a += __hip_atomic_load(all + q * 2 * DT + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                b += __hip_atomic_load(all + q * 2 * DT + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a += __hip_atomic_load(all + q * PS + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b += __hip_atomic_load(all + q * PS + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
             a = (red[0][2 * k] + red[1][2 * k]) + (red[2][2 * k] + red[3][2 * k]);
             b = (red[0][2 * k + 1] + red[1][2 * k + 1]) + (red[2][2 * k + 1] + red[3][2 * k + 1]);
         }
         double dmu, ds2;
-        const double m = mu[r], v = var[r];
+        double m, v;
+        if (vq) {   // the posterior finish of k_small_finish, per candidate: the reference's clamp and formulas
+            posterior_like_small_finish(gq.sigma2, gq.beta, q_all, vq[N], m, v);
+            if (k == 0) {
+                if (gq.mu_out) gq.mu_out[r] = m;
+                if (gq.var_out) gq.var_out[r] = v;
+                if (gq.score_out) gq.score_out[r] = acq_eval(ap, m, v);
+            }
+        } else {
+            m = mu[r];
+            v = var[r];
+        }
         acq_partials(ap, m, v, dmu, ds2);
         // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
         grad[r * d + k] = dmu * a + (v > 0.0 ? ds2 * (-2.0 * b) : 0.0);
