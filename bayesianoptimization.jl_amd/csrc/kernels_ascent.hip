@@ -317,7 +317,7 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
         if ((unsigned)(before & 0xffffffffull) == (unsigned)R - 1u) {   // the last workgroup of this pass publishes the count and clears the slot
             const unsigned n = (unsigned)(before >> 32) + (active ? 1u : 0u);
             __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(st.h_cnt + ring_slot, (int)n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(st.h_cnt + ring_slot, (int)n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host reads nothing else on the strength of it: no release, which would be a cache write-back)
         }
     }
 }
