@@ -318,6 +318,7 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) w16s[i * 16 + cc] = wv[i];
+            if (tid == PF_THREADS && k_blk == 1) CH_MARK(3584 + 8 * jb + 5);
         }
         if (act && tid < m) {  // row solves below the pivot block
             const int i = base + tid;
@@ -332,6 +333,7 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
             }
 #pragma unroll
             for (int c = 0; c < 16; ++c) a[(P + c) * PF_LD + i] = x[c];
+            if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 6);
         }
         __syncthreads();
         if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 0);

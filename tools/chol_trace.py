@@ -48,3 +48,7 @@ print("block 1, pivot workgroup, per panel (us since the block's pivot start): r
       "factor16 done (wave 0) | trailing done (wave 1) | panel end")
 for p_ in range(8):
     print("  panel", p_, [round((ph[p_][i] - b1) / 100.0, 2) if ph[p_][i] > 0 else None for i in (0, 1, 3, 4, 2)])
+
+print("block 1, per panel (us since the block's pivot start): W16 done (wave 4) | row solve done (thread 0, before the barrier) | barrier passed")
+for jb in range(8):
+    print("  panel", jb, [None if ph[jb][c] == 0 else round((ph[jb][c] - t[3072 + 2]) / 100.0, 2) for c in (5, 6, 0)])
