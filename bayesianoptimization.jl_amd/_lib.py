@@ -18,6 +18,7 @@ KERN = {"SEArd": 0, "SEIso": 1, "Mat52Ard": 2}
 ACQ = {"EI": 0, "PI": 1, "UCB": 2, "MI": 3, "MaxMean": 4}
 INFO_PIVOT, INFO_CAPACITY, INFO_REFITS, INFO_APPENDS = 0, 1, 2, 3
 INFO_CHOL_FORM, INFO_CHOL_FALLBACKS, INFO_CHOL_ABORT_TILES, INFO_JITTER_STEPS = 4, 5, 6, 7
+INFO_SCORE_LAUNCHES, INFO_SCORE_CHUNK = 8, 9
 MGP_INFO_DEVICES, MGP_INFO_SHARDS, MGP_INFO_EXCHANGES, MGP_INFO_RCCL_VERSION = 0, 1, 2, 3
 UNIQUE_ID_BYTES = 128
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     "bohip_gp_acquire_max": (C.c_int, [_gp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                       _dp, _dp, C.POINTER(Best), _dp, _i64p]),
     "bohip_gp_set_maxtime": (C.c_int, [_gp, C.c_double]),
+    "bohip_gp_set_ascent_stop": (C.c_int, [_gp, C.c_double, C.c_double, C.c_double]),
     "bohip_gp_set_jitter": (C.c_int, [_gp, C.c_double, C.c_int]),
     "bohip_gp_predict": (C.c_int, [_gp, _dp, C.c_int64, _dp, _dp]),
     "bohip_gp_score": (C.c_int, [_gp, C.c_int, _dp, _dp, C.c_int64, _dp, C.POINTER(Best)]),
@@ -72,6 +74,7 @@ SIGNATURES = {
     "bohip_gp_get_factor": (C.c_int, [_gp, _dp]),
     "bohip_gp_get_alpha": (C.c_int, [_gp, _dp]),
     "bohip_gp_info": (C.c_int, [_gp, C.c_int, _i64p]),
+    "bohip_debug_set_chol_inv_g": (C.c_int, [C.c_int]),
     "bohip_gp_enable_timing": (C.c_int, [_gp, C.c_int]),
     "bohip_gp_get_timing": (C.c_int, [_gp, C.POINTER(C.c_char_p), _dp, C.c_int]),
     # multi-GPU: one process, a device list (in-library RCCL)
@@ -87,6 +90,7 @@ SIGNATURES = {
     "bohip_mgp_acquire_max": (C.c_int, [_mgp, C.c_int, _dp, _dp, _dp, _dp, C.c_int64, C.c_int64, C.c_double, C.c_double,
                                        _dp, _dp, C.POINTER(Best), _dp, _i64p]),
     "bohip_mgp_set_maxtime": (C.c_int, [_mgp, C.c_double]),
+    "bohip_mgp_set_ascent_stop": (C.c_int, [_mgp, C.c_double, C.c_double, C.c_double]),
     "bohip_mgp_set_jitter": (C.c_int, [_mgp, C.c_double, C.c_int]),
     "bohip_mgp_handle": (_gp, [_mgp, C.c_int]),
     "bohip_mgp_info": (C.c_int, [_mgp, C.c_int, _i64p]),

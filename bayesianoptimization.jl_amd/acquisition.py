@@ -152,7 +152,8 @@ def defaultoptions(model_type, acq_type):                    # :4-9
     return dict(method="LD_LBFGS", restarts=10, maxeval=2000)
 
 
-def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-10, history=8):
+def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-10, history=8, ftol_abs=0.0, xtol_rel=0.0,
+                          stopval=math.inf):
     """Lock-step projected L-BFGS ascent of R independent d-dimensional problems (role of NLopt :LD_LBFGS
     with lower/upper bounds, src/acquisition.jl:23-35).  fg(X) -> (f[R], G[d,R]) is ONE device call.
     Returns (f, X) at the best point seen per column."""
@@ -208,6 +209,10 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
         df = fn - f
         moved = np.sqrt(np.einsum("dr,dr->r", s_, s_))
         active = active & (df > ftol_rel * np.maximum(np.abs(fn), 1e-300)) & (moved > xtol_abs)
+        # NLopt's other stop tests (kernels_ascent.hip asc_goes_on): ftol_abs, xtol_rel per coordinate, stopval
+        active = active & (df > ftol_abs) & ~(fn >= stopval)
+        if xtol_rel > 0.0:
+            active = active & (np.abs(s_) > xtol_rel * np.abs(Xn)).any(axis=0)
         good = np.einsum("dr,dr->r", s_, y_) > 1e-14
         S.append(np.where(good, s_, 0.0)); Y.append(np.where(good, y_, 0.0))
         if len(S) > history:
@@ -221,9 +226,8 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
 # NLopt.Opt properties the reference forwards with setproperty! (src/acquisition.jl:24-27).  The device ascent
 # implements the first group; the second is accepted by NLopt but has no counterpart here (a warning says so);
 # anything else raises, as setproperty! on an NLopt.Opt does.
-_OPTS_USED = {"method", "restarts", "maxeval", "maxtime", "ftol_rel", "xtol_abs"}
-_OPTS_NLOPT_ONLY = {"ftol_abs", "xtol_rel", "stopval", "initial_step", "population", "vector_storage", "seed",
-                    "local_optimizer", "default_initial_step"}
+_OPTS_USED = {"method", "restarts", "maxeval", "maxtime", "ftol_rel", "xtol_abs", "ftol_abs", "xtol_rel", "stopval"}
+_OPTS_NLOPT_ONLY = {"initial_step", "population", "vector_storage", "seed", "local_optimizer", "default_initial_step"}
 
 
 def _check_options(opts):
@@ -275,9 +279,13 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None, setparams
         iters = max(2, maxeval)
 
         ftol, xtol = float(opts.get("ftol_rel", 1e-10)), float(opts.get("xtol_abs", 1e-10))
+        # ftol_abs / xtol_rel / stopval with NLopt's defaults (off); the reference's own test passes ftol_abs = eps() (test/acquisition.jl:6,9)
+        fabs_, xrel, sval = float(opts.get("ftol_abs", 0.0)), float(opts.get("xtol_rel", 0.0)), float(opts.get("stopval", math.inf))
         if hasattr(model, "ascend"):                              # device model: the whole search runs in libbohip
             if hasattr(model, "set_maxtime"):
                 model.set_maxtime(maxtime)                        # NLopt maxtime: per optimize call = per acquire_max here
+            if hasattr(model, "set_ascent_stop"):
+                model.set_ascent_stop(fabs_, xrel, sval)
             f, X, bf, bi, bx, _ = model.ascend(acq, p, lb, ub, starts, iters, ftol, xtol)
             if bi >= 0:
                 return float(bf), np.array(bx)
@@ -287,7 +295,8 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None, setparams
         def fg(X):                                                # host restatement of the same search (test models)
             return model.score_grad(acq, p, X)
 
-        f, X = _batched_lbfgs_ascent(fg, starts, lb, ub, iters, ftol_rel=ftol, xtol_abs=xtol)
+        f, X = _batched_lbfgs_ascent(fg, starts, lb, ub, iters, ftol_rel=ftol, xtol_abs=xtol, ftol_abs=fabs_, xtol_rel=xrel,
+                                     stopval=sval)
     else:
         n = max(restarts, min(maxeval * restarts, 1 << 20))
         X = latin_hypercube_sampling(lb, ub, n, rng)

@@ -86,7 +86,9 @@ struct bohip_gp {
     bool w_done = false;       // the last factorisation also produced W = L^-1 (executor form with its inverse queue)
     // scoring scratch
     double* dKsT = nullptr;
-    int64_t kst_rows = 0;
+    int64_t kst_rows = 0;        // rows the K*' chunk buffer holds
+    int64_t chunk_now = 0;       // candidates per K*' chunk of the current call (chunk_rows(R) <= kst_rows)
+    int64_t score_launches = 0;  // k_trigemm_sq launches of the last posterior pass (BOHIP_INFO_SCORE_LAUNCHES)
     double *dVT = nullptr, *dUT = nullptr;  // gradient path: V' and U' = V' W chunks, candidate-major
     int64_t vt_rows = 0;
     double *dq = nullptr, *dmu_raw = nullptr, *dXs = nullptr, *dmu = nullptr, *dvar = nullptr, *dscore = nullptr;
@@ -98,6 +100,7 @@ struct bohip_gp {
     int64_t fz_cap = 0;
     bool fz_dirty = false;         // a fused call failed between its launches: clear the counters before the next one
     double* dgrad = nullptr;   // d x R gradient staging of the host-pointer entry point
+    double asc_ftol_abs = 0.0, asc_xtol_rel = 0.0, asc_stopval = INFINITY;   // bohip_gp_set_ascent_stop (NLopt's ftol_abs / xtol_rel / stopval)
     double asc_maxtime = 0.0;    // bohip_gp_set_maxtime: wall-clock budget of one acquire_max call in seconds (NLopt maxtime), 0 = none
     int64_t batch_hint = 0;      // bohip_gp_set_batch_hint: choose the scoring path as if the batch had at least this many candidates
     double* dsplit = nullptr;    // split-K partial planes (batches of a few hundred candidates)
@@ -751,7 +754,7 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
 // then resident.  Layout of the counters inside the flag area (all zeroed per factorisation):
 //   tile (i, c), i >= c+2:  ver = xp[((c-1) T + i) 8 + 0], pver = xp[.. + 1]   (the chain uses xp[(k T + i) 8 + p] for i = k+1, k+2 only)
 //   tile (c+1, c):          ver = farall[c], pver = fol[c];      tile (c, c):  ver = colall[c], pver = col[c]
-//   sver(i, k) = colr[k T + i];   queue cursors = the four words behind the abort word
+//   sver(i, k) = colr[k T + i];   queue cursors = the EX_NQ = 6 words behind the abort word
 static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsigned* flag_base, int64_t ld, int T, int CH_NSF, int inv_g,
                            std::vector<ExTask>& all, int* qbeg) {
     const CholFlags fl = chol_flags_layout_at(flag_base, nullptr, T);
@@ -1014,7 +1017,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
         // urgent queue's own workgroups: nobody would serve the other queues until the time-out)
         const int cus_free = std::max(1, device_cus() - (9 + g_chol_nsf + 6));
         const int exec_wgs = std::max(2, std::min(g_chol_exec_wgs, 2 * cus_free));
-        q.nurgent = std::min(exec_wgs / 8, g_chol_exec_urgent);
+        q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));   // queue 0 is served by these only: never zero
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
         q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
         q.fill_inv = g_chol_exec_fill_inv;
@@ -1089,11 +1092,12 @@ static int refit_once(bohip_gp* g, double jitter) {
     // (the chain's fill the LDS): the chain's 8-9 (+ solve followers), form 1's T - 3 row followers and 2 (T - 3) column
     // updaters.  On a device (or partition: CPX mode exposes 32 CUs) that cannot hold them the launch chain is used.
     const int cus = device_cus();
+    const bool df_size = (g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP);
     bool paused = false;
-    for (int sk = g_chol_df_skip.load(std::memory_order_relaxed); sk > 0;)
-        if (g_chol_df_skip.compare_exchange_weak(sk, sk - 1, std::memory_order_relaxed)) { paused = true; break; }
-    const bool want_df = !paused &&
-                         ((g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP));
+    if (df_size)   // the pause after a time-out counts refits that WOULD have used a dataflow form, nothing else
+        for (int sk = g_chol_df_skip.load(std::memory_order_relaxed); sk > 0;)
+            if (g_chol_df_skip.compare_exchange_weak(sk, sk - 1, std::memory_order_relaxed)) { paused = true; break; }
+    const bool want_df = !paused && df_size;
     const int exec_min = g_chol_exec_min >= 0 ? g_chol_exec_min : (g_chol_inv_g > 0 ? 4 : 32);
     const bool exec_ok = g_chol_exec && T >= std::max(4, exec_min) && cus >= 9 + g_chol_nsf + 6 + 8;
     const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
@@ -1144,6 +1148,10 @@ static int refit_once(bohip_gp* g, double jitter) {
         g->stale = false;
         g->n_factored = N;
         g->refits++;
+        // a dataflow refit went through: the next time-out starts from half the pause (one transient episode late in a long
+        // process must not cost 1024 refits on the slow form)
+        for (int bo = g_chol_df_backoff.load(std::memory_order_relaxed); bo > 0;)
+            if (g_chol_df_backoff.compare_exchange_weak(bo, bo / 2, std::memory_order_relaxed)) break;
         return 0;
     }
     g->chol_form_last = 0;
@@ -1293,7 +1301,9 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
     CHK(one_time_kernel_setup());
     const int64_t N1 = N0 + p, Npad1 = round_up(N1 + 1, TILE), ld = g->ld;
     const KernelHyper hp = make_hyper(g);
-    const double noise = std::exp(2.0 * g->lognoise) + std::numeric_limits<double>::epsilon();
+    // (a refit that needed jitter J put J on every diagonal entry: the appended rows carry it too, so that the factor
+    // stays the factor of ONE matrix -- cK + J I -- that the oracle's fit_with_jitter reproduces)
+    const double noise = std::exp(2.0 * g->lognoise) + std::numeric_limits<double>::epsilon() + g->jitter_last;
     HIPCHK(hipMemsetAsync(g->dinfo, 0, sizeof(int), g->stream));
     t_begin(g, "append_cov_rows");
     hipLaunchKernelGGL(k_cov_rows, dim3((Npad1 + 255) / 256, Npad1 - N0), dim3(256), 0, g->stream, g->dX, N0, N1, Npad1,
@@ -1330,16 +1340,32 @@ static int ensure_fresh(bohip_gp* g) {
 }
 
 // ---- scoring --------------------------------------------------------------------------------------
-static int64_t chunk_rows(const bohip_gp* g) {
-    // keep the K*' chunk around 128 MB so it stays in the 256 MB Infinity Cache next to W
+static int64_t chunk_cap(const bohip_gp* g) {
+    // keep the K*' chunk around 128 MB so it stays in the 256 MB Infinity Cache next to W; a multiple of 512 candidates
+    // (8 XCDs x one 64-wide candidate tile: k_trigemm_sq deals candidate tiles to XCDs round-robin)
     int64_t rows = (int64_t)(128.0 * 1024 * 1024 / (8.0 * g->ld));
-    rows = std::max<int64_t>(1024, std::min<int64_t>(8192, rows / TILE * TILE));
+    rows = std::max<int64_t>(1024, std::min<int64_t>(8192, rows / 512 * 512));
     return rows;
+}
+// Chunks of ONE batch are equal-sized multiples of 512 candidates: R = 32768 at N = 3000 is 8 x 4096, not 6 x 5376 + 512
+// (a ragged last chunk is a launch with a few candidate tiles per XCD -- all tail; measured 5.39 against 5.08 ms).  Among the
+// chunk counts that fit the cap the one that leaves the least padding wins, fewer chunks on a tie.
+static int64_t chunk_rows(const bohip_gp* g, int64_t R) {
+    const int64_t cap = chunk_cap(g), R512 = round_up(std::max<int64_t>(R, 1), 512);
+    if (R512 <= cap) return round_up(std::max<int64_t>(R, 1), TILE);   // one chunk (its buffer keeps the 128-row granularity)
+    const int64_t nmin = (R512 + cap - 1) / cap;
+    int64_t best_rows = cap, best_pad = INT64_MAX;
+    for (int64_t n = nmin; n <= nmin + 4; ++n) {
+        const int64_t rows = round_up((R512 + n - 1) / n, 512), pad = n * rows - R512;
+        if (rows <= cap && pad < best_pad) { best_pad = pad; best_rows = rows; }
+    }
+    return best_rows;
 }
 static int ensure_score_scratch(bohip_gp* g, int64_t R) {
     const int64_t Rpad = round_up(std::max<int64_t>(R, 1), TILE);
     const int64_t T = g->ld / TILE;
-    const int64_t rc = std::min(chunk_rows(g), Rpad);
+    const int64_t rc = chunk_rows(g, R);
+    g->chunk_now = rc;
     const int64_t SLACK = TILE;  // head-room so tile-granular writes past the last candidate stay inside the buffers
     if (g->kst_rows < rc || g->dKsT == nullptr) {
         if (g->dKsT) hipFree(g->dKsT);
@@ -1494,9 +1520,11 @@ static int posterior_pass(bohip_gp* g, const double* dXs, int64_t R, const FuseP
     const int T = (int)(Npad / TILE);
     g->q_tiles = T;
     const KernelHyper hp = make_hyper(g);
-    const int64_t rc = g->kst_rows;
+    const int64_t rc = g->chunk_now;
+    g->score_launches = 0;
     for (int64_t r0 = 0; r0 < R; r0 += rc) {
         const int64_t r1 = std::min(R, r0 + rc);
+        ++g->score_launches;
         t_begin(g, "kstar");
         CHK(launch_kstar_any(g, dXs, r0, r1, Npad, hp));
         t_end(g);
@@ -1703,7 +1731,7 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
         return 0;
     }
     CHK(ensure_grad_scratch(g));
-    const int64_t rc = g->kst_rows;
+    const int64_t rc = g->chunk_now;
     for (int64_t r0 = 0; r0 < R; r0 += rc) {
         const int64_t r1 = std::min(R, r0 + rc);
         t_begin(g, "kstar");
@@ -2044,8 +2072,8 @@ int bohip_gp_predict_cov(bohip_gp* g, const double* Xs, int64_t R, double* mu, d
     CHK(ensure_fresh(g));
     CHK(ensure_xs(g, R));
     CHK(ensure_score_scratch(g, R));
-    if (R > g->kst_rows)
-        return fail(BOHIP_E_UNSUPPORTED, "predict_cov: R exceeds one candidate chunk (" + std::to_string(g->kst_rows) + ")");
+    if (R > g->chunk_now)
+        return fail(BOHIP_E_UNSUPPORTED, "predict_cov: R exceeds one candidate chunk (" + std::to_string(chunk_cap(g)) + ")");
     CHK(ensure_grad_scratch(g));
     CHK(one_time_kernel_setup());
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), Rpad = round_up(R, TILE) + TILE, Rp = round_up(R, TILE);
@@ -2218,6 +2246,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     CHK(ensure_score_scratch(g, R));
     CHK(ensure_ascent(g, R));
     AscentState& st = g->asc;
+    st.ftol_abs = g->asc_ftol_abs; st.xtol_rel = g->asc_xtol_rel; st.stopval = g->asc_stopval;
     double* dlb = g->asc_bounds;
     double* dub = dlb + DMAX;
     double* dbx = dub + DMAX;
@@ -2441,6 +2470,8 @@ int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
         case BOHIP_INFO_CHOL_FALLBACKS: *value = g->chol_fallbacks; return 0;
         case BOHIP_INFO_CHOL_ABORT_TILES: *value = g->chol_abort_T; return 0;
         case BOHIP_INFO_JITTER_STEPS: *value = g->jitter_steps_last; return 0;
+        case BOHIP_INFO_SCORE_LAUNCHES: *value = g->score_launches; return 0;
+        case BOHIP_INFO_SCORE_CHUNK: *value = g->chunk_now; return 0;
         default: return fail(BOHIP_E_ARG, "unknown info id");
     }
 }
@@ -2458,6 +2489,13 @@ int bohip_gp_set_jitter(bohip_gp* g, double rel, int max_tries) {
 int bohip_gp_set_maxtime(bohip_gp* g, double seconds) {
     if (!g || !(seconds >= 0.0)) return fail(BOHIP_E_ARG, "bad arguments");
     g->asc_maxtime = seconds;
+    return 0;
+}
+int bohip_gp_set_ascent_stop(bohip_gp* g, double ftol_abs, double xtol_rel, double stopval) {
+    if (!g || !(ftol_abs >= 0.0) || !(xtol_rel >= 0.0) || stopval != stopval) return fail(BOHIP_E_ARG, "bad arguments");
+    g->asc_ftol_abs = ftol_abs;
+    g->asc_xtol_rel = xtol_rel;
+    g->asc_stopval = stopval;
     return 0;
 }
 int bohip_gp_enable_timing(bohip_gp* g, int on) {
@@ -2496,7 +2534,7 @@ int bohip_debug_read_w(bohip_gp* g, int which, double* out) {
 }
 // test hook (tests/test_exec_tasks.py): the executor's task records for T row tiles with the three matrices at the fake
 // addresses base_L/S/W (bytes) and flag word 0 at index 0 -- the CPU test replays them against a model of the chain.
-// out: n x 16 uint64 words (the 128-byte records); returns the number of records, qbeg[0..4] the queue boundaries,
+// out: n x 16 uint64 words (the 128-byte records); returns the number of records, qbeg[0..EX_NQ] (EX_NQ + 1 = 7 ints) the queue boundaries,
 // layout[0..9] the word offsets of panel, solved, crit, rest, col, farall, fol, colall, colr, xp inside the flag area;
 // layout[10] the number of solve-follower workgroups of the chain kernel (CH_NSF).
 int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base_S, uint64_t base_W, uint64_t base_WT, int inv_g, uint64_t* out,
@@ -2504,14 +2542,17 @@ int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base
     std::vector<bohip::ExTask> all;
     int qb[bohip::EX_NQ + 1];
     unsigned* fb = reinterpret_cast<unsigned*>(uintptr_t(1) << 40);
+    // the follower count the records are built for = the one reported in layout[10]: the env knob is read HERE (the library's
+    // one-time setup may not have run yet), and the process-wide setting is left alone
+    int nsf = g_chol_nsf;
+    if (const char* e = getenv("BOHIP_CHOL_NSF")) nsf = std::min(bohip::CH_NSF_MAX, std::max(1, atoi(e)));
     exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W),
-                   reinterpret_cast<double*>(base_WT), fb, ld, T, g_chol_nsf, inv_g, all, qb);
+                   reinterpret_cast<double*>(base_WT), fb, ld, T, nsf, inv_g, all, qb);
     for (int i = 0; i <= bohip::EX_NQ; ++i) qbeg[i] = qb[i];
     const bohip::CholFlags fl = chol_flags_layout_at(fb, nullptr, T);
     const unsigned* ptrs[10] = {fl.panel, fl.solved, fl.crit, fl.rest, fl.col, fl.farall, fl.fol, fl.colall, fl.colr, fl.xp};
     for (int i = 0; i < 10; ++i) layout[i] = ptrs[i] - fb;
-    if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(bohip::CH_NSF_MAX, std::max(1, atoi(e)));
-    layout[10] = g_chol_nsf;
+    layout[10] = nsf;
     layout[11] = (int64_t)chol_inv_word(T);
     layout[12] = (int64_t)chol_xp3_word(T);
     if ((int64_t)all.size() <= cap && out) std::memcpy(out, all.data(), all.size() * sizeof(bohip::ExTask));

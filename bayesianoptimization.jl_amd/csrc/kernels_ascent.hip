@@ -30,13 +30,25 @@ struct AscentState {
     int *it, *bt;
     unsigned *nact, *ticket;    // nact: [ASC_RING] 64-bit counters (arrivals | active << 32), 8-byte aligned; ticket: unused half
     int *h_cnt;                 // [ASC_RING] pinned
+    // NLopt's remaining stop criteria (bohip_gp_set_ascent_stop; the reference forwards them, src/acquisition.jl:24-27, and its own
+    // test sets ftol_abs = eps(), test/acquisition.jl:6,9): 0 / 0 / +Inf = off
+    double ftol_abs, xtol_rel, stopval;
 };
-constexpr int ASC_RING = 8;
-
 __device__ __forceinline__ double asc_wsum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// Does start point r go on after an iteration that moved it by s (this lane's coordinate, new value xn) and changed the value by
+// df to fn?  NLopt's tests for a maximisation: ftol_rel, ftol_abs on the improvement, xtol_abs on the step (its norm, as before),
+// xtol_rel per coordinate (stop when EVERY |dx_k| <= xtol_rel |x_k|), stopval.  Wave-uniform (the sums are butterflies).
+__device__ __forceinline__ bool asc_goes_on(const AscentState& st, bool on, double s, double xn, double df, double fn, double moved,
+                                            double ftol_rel, double xtol_abs) {
+    const double n_big = asc_wsum((on && fabs(s) > st.xtol_rel * fabs(xn)) ? 1.0 : 0.0);   // coordinates that moved by more than xtol_rel |x|
+    return df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs && df > st.ftol_abs && (st.xtol_rel <= 0.0 || n_big > 0.0) &&
+           !(fn >= st.stopval);
+}
+constexpr int ASC_RING = 8;
+
 __device__ __forceinline__ double asc_clip(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
 __global__ __launch_bounds__(64) void k_asc_start(AscentState st, int d, const double* __restrict__ starts,
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R,
     const double moved = sqrt(asc_wsum(s * s));
     const bool good = asc_wsum(s * y) > 1e-14;
     int active = st.active[r];
-    active = (active && df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs) ? 1 : 0;
+    active = (active && asc_goes_on(st, on, s, xn, df, fn, moved, ftol_rel, xtol_abs)) ? 1 : 0;
     if (on) {
         const int64_t ho = ((int64_t)slot * R + r) * d + k;
         st.S[ho] = good ? s : 0.0;
@@ -229,7 +241,7 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
             const double s = xn - x, y = -(gn - g), df = fn - f;
             const double moved = sqrt(asc_wsum(s * s));
             const bool good = asc_wsum(s * y) > 1e-14;
-            active = (df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs) ? 1 : 0;
+            active = asc_goes_on(st, on, s, xn, df, fn, moved, ftol_rel, xtol_abs) ? 1 : 0;
             const int slot = it % ASC_M;
             const double s_new = good ? s : 0.0, y_new = good ? y : 0.0;
             if (on) {
@@ -376,6 +388,7 @@ __global__ __launch_bounds__(AWG_THREADS) void k_ascent_wg(AscWgParams p) {
         st.f = q++; st.ft = q++; st.fn = q++; st.step = q++; st.best_f = q++;
         st.active = s_ints; st.accepted = s_ints + 1; st.it = s_ints + 2; st.bt = s_ints + 3; st.h_accepted = s_ints + 4; st.h_active = s_ints + 5;
         st.nact = nullptr; st.ticket = nullptr; st.h_cnt = nullptr;
+        st.ftol_abs = p.st.ftol_abs; st.xtol_rel = p.st.xtol_rel; st.stopval = p.st.stopval;
     }
     const unsigned long long t_begin = wall_clock64();
     if (tid < 64) {   // k_asc_start

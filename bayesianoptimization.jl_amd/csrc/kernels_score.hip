@@ -130,7 +130,7 @@ __device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, co
 
 // BOHIP_TRACE (tools only, default 0 in gemm_core.h): per-workgroup start/end clocks of k_trigemm_sq (tools/trace_trigemm.py)
 #if BOHIP_TRACE
-__device__ unsigned long long g_trace[4 * 8192];
+__device__ unsigned long long g_trace[6 * 8192];   // per workgroup: wall start, wall end, HW_ID, XCC_ID, core-clock start, core-clock end
 #endif
 // position `sq` of the heaviest-first row-tile sequence.  Job length = K extent = rt + 1 units, except that a last row tile
 // with <= 64 live rows runs in the loop's half mode and costs (rt + 1) / 2: it is issued where a job of that length belongs
@@ -211,19 +211,19 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2 * KS) void k_trigemm_sq(const 
                                                                 double* __restrict__ VT, int64_t ldv, FuseParams fz) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
 #if BOHIP_TRACE
-    const unsigned long long t_start = wall_clock64();
+    const unsigned long long t_start = wall_clock64(), c_start = clock64();
     struct TraceEnd {
-        unsigned long long t0;
+        unsigned long long t0, c0;
         __device__ ~TraceEnd() {
             if (threadIdx.x == 0) {
                 unsigned hw, xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                unsigned long long* t = g_trace + 4 * (size_t)blockIdx.x;
-                t[0] = t0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;
+                unsigned long long* t = g_trace + 6 * (size_t)blockIdx.x;
+                t[0] = t0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc; t[4] = c0; t[5] = clock64();
             }
         }
-    } trace_end{t_start};
+    } trace_end{t_start, c_start};
 #endif
     // blocks are dealt to XCDs round-robin (block b runs on XCD b % 8): an XCD owns the candidate tiles ct = xcd (mod 8) and
     // walks the row tiles together, heaviest first

@@ -525,6 +525,11 @@ int bohip_mgp_set_maxtime(bohip_mgp* m, double seconds) {
     for (int i = 0; i < m->nd; ++i) CHK(bohip_gp_set_maxtime(m->h[i], seconds));
     return 0;
 }
+int bohip_mgp_set_ascent_stop(bohip_mgp* m, double ftol_abs, double xtol_rel, double stopval) {
+    if (!m) return fail(BOHIP_E_ARG, "null handle");
+    for (int i = 0; i < m->nd; ++i) CHK(bohip_gp_set_ascent_stop(m->h[i], ftol_abs, xtol_rel, stopval));
+    return 0;
+}
 int bohip_mgp_set_jitter(bohip_mgp* m, double rel, int max_tries) {
     if (!m) return fail(BOHIP_E_ARG, "null handle");
     for (int i = 0; i < m->nd; ++i) CHK(bohip_gp_set_jitter(m->h[i], rel, max_tries));

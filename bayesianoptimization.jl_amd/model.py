@@ -219,6 +219,10 @@ class ElasticGPE:
         """NLopt's maxtime for the device ascent (0 = unlimited)."""
         check(self._lib.bohip_gp_set_maxtime(self._h, float(seconds)))
 
+    def set_ascent_stop(self, ftol_abs=0.0, xtol_rel=0.0, stopval=float("inf")):
+        """NLopt's ftol_abs / xtol_rel / stopval for the device ascent (0 / 0 / +Inf = off), reference src/acquisition.jl:24-27."""
+        check(self._lib.bohip_gp_set_ascent_stop(self._h, float(ftol_abs), float(xtol_rel), float(stopval)))
+
     def set_jitter(self, rel, max_tries=10):
         """Jitter escalation on a failed factorisation (the role of GaussianProcesses.jl's make_posdef! behind update!,
         src/models/gp.jl:11,16 -- UPSTREAM-UNVERIFIED, off by default): a refit that fails is repeated with

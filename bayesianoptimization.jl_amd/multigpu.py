@@ -122,6 +122,10 @@ class MultiGPE:
         """NLopt's maxtime for the device ascent, on every replica (0 = unlimited)."""
         check(self._lib.bohip_mgp_set_maxtime(self._h, float(seconds)))
 
+    def set_ascent_stop(self, ftol_abs=0.0, xtol_rel=0.0, stopval=float("inf")):
+        """NLopt's ftol_abs / xtol_rel / stopval for the device ascent, on every replica"""
+        check(self._lib.bohip_mgp_set_ascent_stop(self._h, float(ftol_abs), float(xtol_rel), float(stopval)))
+
     def set_jitter(self, rel, max_tries=10):
         """see ElasticGPE.set_jitter; applied to every replica"""
         check(self._lib.bohip_mgp_set_jitter(self._h, float(rel), int(max_tries)))

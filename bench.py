@@ -125,6 +125,58 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
     }
 
 
+def traffic_child():
+    """`bench.py --traffic-child` (run by measure_traffic under `rocprofv3 --pmc ...`): the headline model and a few steps of the
+    headline call, nothing else -- no torch, no CPU baseline, no output."""
+    import bohip
+
+    X, y = synth(0)
+    m = bohip.ElasticGPE(DIM, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(np.full(DIM, np.log(0.5)), 0.0), logNoise=-2.0, capacity=N_OBS)
+    m.append_(X.T, y)
+    Xs = lhs(R_PER_GPU, seed=1)
+    for _ in range(6):
+        m.score("EI", [float(y.max())], Xs.T, want_scores=False)
+
+
+def measure_traffic():
+    """roofline.traffic measured IN THIS RUN: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass,
+    MI355X_MICROARCH.md) over a child process that repeats the headline call; per-launch average of k_trigemm_sq, FETCH_SIZE x 2
+    (the guide's gfx950 correction), both counters in KiB.  Returns (bytes per launch or None, source text)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("BOHIP_BENCH_TRAFFIC") == "0":
+        return None, "rocprofv3 not on PATH" if exe is None else "disabled (BOHIP_BENCH_TRAFFIC=0)"
+    raw = {}
+    tmp = tempfile.mkdtemp(prefix="bohip_traffic_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR="/tmp", BOHIP_BENCH_TRAFFIC="0")
+            r = subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--", sys.executable,
+                                os.path.join(ROOT, "bench.py"), "--traffic-child"], cwd="/tmp", env=env, capture_output=True,
+                               text=True, timeout=300)
+            vals = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_trigemm_sq" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"rocprofv3 --pmc {ctr} produced no k_trigemm_sq rows (rc {r.returncode}): {r.stderr[-200:]!r}"
+            raw[ctr] = sum(vals[1:]) / max(1, len(vals) - 1) if len(vals) > 1 else vals[0]   # (first launch: cold caches)
+    except Exception as e:      # noqa: BLE001
+        return None, f"rocprofv3 pass failed: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = raw["FETCH_SIZE"] * 1024.0 * 2.0 + raw["WRITE_SIZE"] * 1024.0
+    return total, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --traffic-child` (5 launches each); "
+                   f"FETCH_SIZE {raw['FETCH_SIZE']:.0f} KiB x 2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE {raw['WRITE_SIZE']:.0f} KiB")
+
+
 _OUT_FD = None
 
 
@@ -158,10 +210,8 @@ def r_per_gpu(args, world):
 def set_inverse_queues(on):
     """The executor form grows W = L^-1 behind the factorisation's pivot chain (one stage `cholesky+inverse`); switched off, the
     factorisation runs alone and the inverse follows as its own stage -- the way to time the Cholesky against its own flop count."""
-    import ctypes as C
     from bohip import _lib
-    lib = C.CDLL(_lib.LIB_PATH)
-    return lib.bohip_debug_set_chol_inv_g(8 if on is True else int(on))
+    return _lib.load().bohip_debug_set_chol_inv_g(8 if on is True else int(on))   # declared in include/bohip.h (benchmarks only)
 
 
 def refit_figures(model, N, reps):
@@ -205,18 +255,24 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
     value = R_total * args.steps / elapsed
     stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
     tg_ms = stage_ms.get("trigemm_sq", float("nan"))
-    # one launch covers one K*' chunk (<= 8192 candidates); a shard of more candidates is several launches per step
-    launches = max(1, -(-R_GPU // 8192))
+    # one launch covers one K*' chunk; the library says how many chunks the shard's call is cut into (equal-sized multiples of 512
+    # candidates, BOHIP_INFO_SCORE_LAUNCHES) -- `launches` arrives in `extra` from the caller that holds the handle
+    launches = int((extra or {}).pop("_launches", 0)) or max(1, -(-R_GPU // 4096))
     flops_per_launch = (R_GPU / launches) * (N_OBS * N_OBS + 2.0 * N_OBS)  # triangular contraction + mu row
     tg_ms = tg_ms / launches
     achieved = flops_per_launch / (tg_ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_trigemm_sq.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    traffic, traffic_source = (None, "not measured on this rank")
+    if world == 1 and not args.strong:
+        traffic, traffic_source = measure_traffic()
+    if traffic is None:
+        tpath = os.path.join(ROOT, "profiles", "traffic_trigemm_sq.json")
+        why = traffic_source
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic_source = f"profiles/traffic_trigemm_sq.json (earlier rocprofv3 --pmc passes of this command; NOT measured in this run: {why})"
+            except Exception:
+                traffic = None
     out = {
         "metric": "acquisition-candidates/sec (N=3000,d=8)", "value": value, "unit": "candidates/s",
         "n_gpus": world if n_devices is None else n_devices, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -230,8 +286,7 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
                                    f"candidates sharded x{world}, one 16-byte RCCL all-gather + device-side reduce ({mode})")},
         "roofline": {"bound": "mfma", "kernel": "k_trigemm_sq", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_source": "profiles/traffic_trigemm_sq.json (separate rocprofv3 --pmc passes of this command; "
-                                       "NOT measured in this run)",
+                     "traffic_source": traffic_source,
                      "avg_launch_ms": tg_ms, "flops_per_launch": flops_per_launch, "launches_per_step": launches,
                      "step_over_kernel": ms_per_step / (tg_ms * launches)},
         "stage_ms": {**{k: v for k, v in info_ms.items() if k != "trigemm_sq"}, **stage_ms},
@@ -247,6 +302,8 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
         # TEST mode (BOHIP_LOGICAL_SHARDS=1): `world` logical shards on n_devices GPU(s) -- NOT a multi-GPU measurement
         out["logical_shards"] = world
         out["test_mode"] = f"{world} logical shards on {n_devices} GPU(s): exercises the sharded path, says nothing about {world} GPUs"
+    if "exchange" in info_ms:   # the all-gather of the 16-byte records + the device-side reduce, by HIP events (warm-up steps)
+        out["exchange_us"] = info_ms["exchange"] * 1e3
     if extra:
         out.update(extra)
     if world == 1 and not args.no_cpu_baseline:
@@ -343,7 +400,15 @@ def main_single_process(args):
         stage_sum = {}
         for name, ms in model.timing(4096):
             stage_sum[name] = stage_sum.get(name, 0.0) + ms
-        extra = {"value_host_buffers": R_total * args.steps / el_h, "ms_per_step_host_buffers": el_h / args.steps * 1e3,
+        # UNTIMED: one more second of the same step, so that a coarse GPU-activity sampler around this process sees the device busy
+        # (the timed region is ~20 ms of a run whose remainder is the CPU baseline)
+        model.enable_timing(0)
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 1.0:
+            step()
+        n_launch = C.c_int64(0)
+        _lib.check(lib.bohip_gp_info(model._h, _lib.INFO_SCORE_LAUNCHES, C.byref(n_launch)))
+        extra = {"_launches": int(n_launch.value), "value_host_buffers": R_total * args.steps / el_h, "ms_per_step_host_buffers": el_h / args.steps * 1e3,
                  "host_buffers_note": "same workload through bohip_gp_score: host X* in (pageable, 256 KB H2D inside the "
                                       "call), 16-byte record out; `value` is the HBM-resident rate",
                  "host_buffers_same_winner": bool(hv == val and hi == idx)}
@@ -395,7 +460,10 @@ def main_single_process(args):
     for name, ms in timing0():
         stage_sum[name] = stage_sum.get(name, 0.0) + ms / spd   # per shard launch
     mode = f"one process, {len(devices)} device(s) x {spd} shard(s), in-library RCCL {model.info(_lib.MGP_INFO_RCCL_VERSION)}"
-    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, n_devices=len(devices))
+    n_launch = C.c_int64(0)
+    lib.bohip_gp_info(g0, _lib.INFO_SCORE_LAUNCHES, C.byref(n_launch))
+    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, {"_launches": int(n_launch.value)},
+           n_devices=len(devices))
 
 
 def default_usage(model, tau):
@@ -480,7 +548,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strong", action="store_true", help="strong scaling: R = 32768 candidates in total (BASELINE configs[2]) at every --gpus")
     ap.add_argument("--no-c4", action="store_true", help="skip the N=10000 model-update figure (cholesky_c4)")
+    ap.add_argument("--traffic-child", action="store_true", help="(internal) the child process of measure_traffic()")
     args = ap.parse_args()
+    if args.traffic_child:
+        return traffic_child()
     if args.strong and STRONG_R_TOTAL % args.gpus:
         raise SystemExit("--strong needs --gpus to divide 32768")
     quiet_stdout()
@@ -613,7 +684,7 @@ def main():
     if rank == 0:
         mode = ("one process per GPU, in-library RCCL (bohip_gp_score_sharded_dev)" if in_library
                 else f"one process per GPU, TEST exchange through torch.distributed/{backend}")
-        report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode)
+        report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, {"_launches": model.info(_lib.INFO_SCORE_LAUNCHES)})
     if in_library:
         model.comm_destroy()
     dist.destroy_process_group()

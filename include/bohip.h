@@ -129,6 +129,13 @@ int bohip_gp_acquire_max(bohip_gp *gp, int acq_id, const double *acq_params, con
 /* NLopt's maxtime option (forwarded by the reference at src/acquisition.jl:24-27): wall-clock budget in seconds of ONE
  * bohip_gp_acquire_max call, checked once per ascent iteration; 0 (default) = unlimited.                          */
 int bohip_gp_set_maxtime(bohip_gp *gp, double seconds);
+/* The other NLopt stop criteria the reference forwards with setproperty! (src/acquisition.jl:24-27; its own test sets
+ * ftol_abs = eps(), test/acquisition.jl:6,9).  With NLopt's meaning, per start point, for a MAXIMISATION:
+ *   ftol_abs  stop when an iteration improves the value by <= ftol_abs          (0 = NLopt's default: criterion off)
+ *   xtol_rel  stop when |dx_k| <= xtol_rel |x_k| in EVERY coordinate             (0 = off)
+ *   stopval   stop as soon as a value >= stopval is reached                      (+Inf = off)
+ * They apply to every later bohip_gp_acquire_max call of the handle, beside its ftol_rel / xtol_abs arguments.      */
+int bohip_gp_set_ascent_stop(bohip_gp *gp, double ftol_abs, double xtol_rel, double stopval);
 /* Jitter escalation when the factorisation fails (the role of GaussianProcesses.jl's make_posdef! behind update!/fit!,
  * src/models/gp.jl:11,16 -- UPSTREAM-UNVERIFIED, so OFF by default and BOHIP_E_NOTPD reports the failing pivot): with
  * max_tries > 0 a failed refit is repeated with rel x mean(diag cK) added to the diagonal, x10 per further try.
@@ -168,7 +175,14 @@ int bohip_gp_get_alpha(bohip_gp *gp, double *alpha);
 #define BOHIP_INFO_CHOL_FALLBACKS 5   /* refits of this handle that timed out on a dependency and were redone launch-chained */
 #define BOHIP_INFO_CHOL_ABORT_TILES 6 /* row tiles of the last factorisation that timed out (0: never)  */
 #define BOHIP_INFO_JITTER_STEPS 7 /* jitter tries the last refit needed (0: none; see bohip_gp_set_jitter) */
+#define BOHIP_INFO_SCORE_LAUNCHES 8 /* K*' chunks (= k_trigemm_sq launches) of the last whole-K scoring pass */
+#define BOHIP_INFO_SCORE_CHUNK 9  /* candidates per K*' chunk of the last scoring call (equal-sized multiples of 512) */
 int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
+/* Benchmarks only (bench.py, tools/): the executor form of the factorisation grows W = L^-1 behind the pivot chain in
+ * pieces of `blocks` 128-blocks (default 8).  0 switches those queues off -- the factorisation then runs alone and can
+ * be timed against its own N^3/3 flops, the inverse follows as a stage of its own.  PROCESS-wide (every handle),
+ * returns the previous value.  Same effect as env BOHIP_CHOL_INV_G at load time.                                  */
+int bohip_debug_set_chol_inv_g(int blocks);
 /* Sharded scoring: candidates are scored by one of three summation schedules chosen by batch size
  * (row-wise, split-K, whole-K MFMA jobs); they agree to ~1e-11 relative but not bit for bit.  A rank that scores a
  * shard of a larger candidate set announces the size of the WHOLE set here, so that every shard takes the schedule
@@ -220,6 +234,7 @@ int bohip_mgp_acquire_max(bohip_mgp *mgp, int acq_id, const double *acq_params, 
                           int64_t *evals_out);
 /* the per-handle options of bohip_gp_set_maxtime / bohip_gp_set_jitter, applied to every replica */
 int bohip_mgp_set_maxtime(bohip_mgp *mgp, double seconds);
+int bohip_mgp_set_ascent_stop(bohip_mgp *mgp, double ftol_abs, double xtol_rel, double stopval);
 int bohip_mgp_set_jitter(bohip_mgp *mgp, double rel, int max_tries);
 bohip_gp *bohip_mgp_handle(bohip_mgp *mgp, int i); /* replica on the i-th listed device (borrowed, for dims/maxy/get_xy/mll...) */
 #define BOHIP_MGP_INFO_DEVICES 0

@@ -70,6 +70,8 @@ c_gp_score(h, acq, p, Xs, R, sc, best) = ccall((:bohip_gp_score, libbohip), Cint
 c_gp_score_grad(h, acq, p, Xs, R, sc, g) = ccall((:bohip_gp_score_grad, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}), h, acq, p, Xs, R, sc, g)
 c_gp_acquire_max(h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev) = ccall((:bohip_gp_acquire_max, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Best}, Ptr{Float64}, Ptr{Int64}), h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev)
 c_gp_set_maxtime(h, s) = ccall((:bohip_gp_set_maxtime, libbohip), Cint, (Ptr{Cvoid}, Float64), h, s)
+c_gp_set_ascent_stop(h, fa, xr, sv) = ccall((:bohip_gp_set_ascent_stop, libbohip), Cint, (Ptr{Cvoid}, Float64, Float64, Float64), h, fa, xr, sv)
+c_debug_set_chol_inv_g(blocks) = ccall((:bohip_debug_set_chol_inv_g, libbohip), Cint, (Cint,), blocks)
 c_gp_set_jitter(h, rel, tries) = ccall((:bohip_gp_set_jitter, libbohip), Cint, (Ptr{Cvoid}, Float64, Cint), h, rel, tries)
 c_gp_thompson(h, Xs, R, S, seed, j0, best) = ccall((:bohip_gp_thompson, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, UInt64, Int64, Ptr{Best}), h, Xs, R, S, seed, j0, best)
 c_thompson_normal(seed, s, j) = ccall((:bohip_thompson_normal, libbohip), Float64, (UInt64, Int64, Int64), seed, s, j)
@@ -95,6 +97,7 @@ c_mgp_score_resident(h, acq, p, best) = ccall((:bohip_mgp_score_resident, libboh
 c_mgp_thompson(h, Xs, R, S, seed, best) = ccall((:bohip_mgp_thompson, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, UInt64, Ptr{Best}), h, Xs, R, S, seed, best)
 c_mgp_acquire_max(h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev) = ccall((:bohip_mgp_acquire_max, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Best}, Ptr{Float64}, Ptr{Int64}), h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev)
 c_mgp_set_maxtime(h, s) = ccall((:bohip_mgp_set_maxtime, libbohip), Cint, (Ptr{Cvoid}, Float64), h, s)
+c_mgp_set_ascent_stop(h, fa, xr, sv) = ccall((:bohip_mgp_set_ascent_stop, libbohip), Cint, (Ptr{Cvoid}, Float64, Float64, Float64), h, fa, xr, sv)
 c_mgp_set_jitter(h, rel, tries) = ccall((:bohip_mgp_set_jitter, libbohip), Cint, (Ptr{Cvoid}, Float64, Cint), h, rel, tries)
 c_mgp_handle(h, i) = ccall((:bohip_mgp_handle, libbohip), Ptr{Cvoid}, (Ptr{Cvoid}, Cint), h, i)
 c_mgp_info(h, what, out) = ccall((:bohip_mgp_info, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}), h, what, out)
@@ -291,10 +294,10 @@ function score_grad(m::AbstractBOHipModel, a::AbstractAcquisition, X::AbstractMa
     sc, g
 end
 
-const _NLOPT_ONLY = (:ftol_abs, :xtol_rel, :stopval, :initial_step, :population, :vector_storage, :local_optimizer)
+const _NLOPT_ONLY = (:initial_step, :population, :vector_storage, :local_optimizer)
 function _check_options(options)
     for k in keys(options)
-        k in (:method, :restarts, :maxeval, :maxtime, :ftol_rel, :xtol_abs) && continue
+        k in (:method, :restarts, :maxeval, :maxtime, :ftol_rel, :xtol_abs, :ftol_abs, :xtol_rel, :stopval) && continue
         k in _NLOPT_ONLY ? @warn("acquisition option $k is an NLopt setting the device search does not implement; ignored") :
                            throw(ArgumentError("unknown acquisition option $k"))          # NLopt.Opt rejects unknown properties too
     end
@@ -316,6 +319,9 @@ function acquire_max_device(a::AbstractAcquisition, m::AbstractBOHipModel, lower
         ftol = Float64(get(options, :ftol_rel, 1e-10)); xtol = Float64(get(options, :xtol_abs, 1e-10))
         m isa BOHipGPE && check(c_gp_set_maxtime(m.handle, Float64(get(options, :maxtime, 0.0))))
         m isa BOHipMultiGPE && check(c_mgp_set_maxtime(m.handle, Float64(get(options, :maxtime, 0.0))))
+        fabs_ = Float64(get(options, :ftol_abs, 0.0)); xrel = Float64(get(options, :xtol_rel, 0.0)); sval = Float64(get(options, :stopval, Inf))
+        m isa BOHipGPE && check(c_gp_set_ascent_stop(m.handle, fabs_, xrel, sval))        # NLopt's defaults = off (test/acquisition.jl:6,9 sets ftol_abs = eps())
+        m isa BOHipMultiGPE && check(c_mgp_set_ascent_stop(m.handle, fabs_, xrel, sval))
         rc = m isa BOHipMultiGPE ?
              c_mgp_acquire_max(m.handle, acqid(a), acqparams(a), lb, ub, starts, size(starts, 2), options.maxeval, ftol, xtol,
                                C_NULL, C_NULL, best, bx, ev) :

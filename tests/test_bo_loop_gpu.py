@@ -30,7 +30,10 @@ def test_acquire_max_maxmean_single_observation(bo):                    # test/a
     model = bo.GPE(np.array([1.0]), np.array([2.0]), bo.MeanZero(), bo.SEIso(1.0, 0.0))
     ac = bo.MaxMean()
     opts = {**bo.defaultoptions(type(model), type(ac)), **dict(maxtime=3.0, ftol_abs=np.finfo(float).eps)}
-    maxf, maxx = bo.acquire_max(ac, model, [-5.0], [5.0], {**opts, "restarts": 10}, np.random.default_rng(0))
+    import warnings
+    with warnings.catch_warnings():                                      # maxtime AND ftol_abs are honoured by the device ascent: no "ignored" warning
+        warnings.simplefilter("error")
+        maxf, maxx = bo.acquire_max(ac, model, [-5.0], [5.0], {**opts, "restarts": 10}, np.random.default_rng(0))
     assert maxx == pytest.approx([1.0], abs=1e-5)                       # @test maxx ≈ [1.0]
     assert maxf == pytest.approx(2 / (1 + math.exp(-4.0)), rel=1e-9)
 

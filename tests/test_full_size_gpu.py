@@ -1,8 +1,10 @@
 """BASELINE.json configs[2] and configs[4] at FULL size, and the SURVEY.md 8-D1 stress variant at configs[1] size,
 through the C ABI on one MI355X.  The 8-GPU partition is exercised as 8 logical shards behind a one-rank RCCL
 communicator (bohip_mgp_*, shards_per_device = 8): same partition, same exchange, same reduction kernel.
-Oracle = oracle/gp_oracle.c on a bounded sample (the winner plus random others) at full N."""
+Oracle = oracle/gp_oracle.c at full N: on ALL candidates for configs[2] (arg-max asserted against the oracle's own), on a
+bounded sample where a full comparison is out of a test's reach (the stress variant's factor, Thompson's S x R draws)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -71,17 +73,18 @@ def test_full_size_c3_sharded_x8(bohip, orc):
         recs.append((v_g, i_g + lo))
     one.set_batch_hint(0)
     assert reduce_best(*zip(*recs)) == (bv, bi)
-    # oracle at full N on the winner + 95 others
+    # the oracle at full N on ALL 32768 candidates (every host core: ~9 s on the GPU box's 128 threads): scores, mu, sigma^2 within
+    # tolerance everywhere, and the winner of the device (sharded and unsharded) IS the first arg-max of the oracle's scores
     mu, var = one.predict_f(Xs.T)
     L, alpha = orc.fit(X, y, ll, 0.0, -2.0, 0.0)
-    sel = np.unique(np.concatenate([[bi], np.argsort(sc)[-8:], np.random.default_rng(3).choice(R, 88, replace=False)]))
-    assert len(sel) >= 64
-    sc_o, _, _ = orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], Xs[sel], nthreads=8)
-    check_scores(sc[sel], sc_o, mu_floor(alpha, 1.0) + 1e-13)
-    assert sel[int(np.argmax(sc_o))] == bi                               # the oracle ranks the device's winner first in the sample
-    mu_o, var_o = orc.predict(X, ll, 0.0, 0.0, L, alpha, Xs[sel], nthreads=8)
-    assert np.all(np.abs(var[sel] - var_o) <= var_tol(var_o, N, 1.0))
-    assert np.all(np.abs(mu[sel] - mu_o) <= 1e-6 * np.abs(mu_o) + mu_floor(alpha, 1.0))
+    nth = min(128, os.cpu_count() or 8)
+    sc_o, bv_o, bi_o = orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], Xs, nthreads=nth)
+    check_scores(sc, sc_o, mu_floor(alpha, 1.0) + 1e-13)
+    assert bi == bi_o == int(np.argmax(sc_o)), (bi, bi_o, np.sort(sc_o)[-3:])
+    assert abs(bv - bv_o) <= 1e-6 * abs(bv_o)
+    mu_o, var_o = orc.predict(X, ll, 0.0, 0.0, L, alpha, Xs, nthreads=nth)
+    assert np.all(np.abs(var - var_o) <= var_tol(var_o, N, 1.0))
+    assert np.all(np.abs(mu - mu_o) <= 1e-6 * np.abs(mu_o) + mu_floor(alpha, 1.0))
 
 
 def test_full_size_c5_thompson_1024_draws_x_65536_candidates(bohip, orc):

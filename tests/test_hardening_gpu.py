@@ -111,7 +111,7 @@ def test_jitter_escalation_switch_against_its_oracle_twin(bohip, orc):
     X = np.repeat(pos, 5, axis=0)
     y = -(((X - 1) ** 2).sum(1) + rng.standard_normal(len(X)))
     ll, lsig, lnoise = np.zeros(2), 5.0, -25.0
-    m = bohip.ElasticGPE(2, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, lsig), logNoise=lnoise, capacity=len(y))
+    m = bohip.ElasticGPE(2, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, lsig), logNoise=lnoise, capacity=len(y) + 8)
     with pytest.raises(bohip.BohipError) as e:                       # default: the failing pivot is reported, nothing is added
         m.append_(X.T, y)
     assert e.value.code == _lib.E_NOTPD and m.info(_lib.INFO_PIVOT) > 0 and m.info(_lib.INFO_JITTER_STEPS) == 0
@@ -129,6 +129,17 @@ def test_jitter_escalation_switch_against_its_oracle_twin(bohip, orc):
     mu_o, var_o = orc.predict(X, ll, lsig, 0.0, L_o, alpha_o, Xs)
     np.testing.assert_allclose(mu, mu_o, rtol=1e-5, atol=1e-5 * np.abs(mu_o).max())
     np.testing.assert_allclose(var, var_o, rtol=1e-5, atol=1e-6 * np.exp(2 * lsig))
+    # an incremental append after a jittered refit carries the same jitter on its new diagonal entries: the factor stays the
+    # factor of ONE matrix, cK + J I
+    Xa = rng.random((3, 2)) * 10 - 5
+    ya = -(((Xa - 1) ** 2).sum(1))
+    n_app = m.info(_lib.INFO_APPENDS)
+    m.append_(Xa.T, ya)
+    assert m.info(_lib.INFO_APPENDS) == n_app + 1                    # the incremental path, not a refit
+    X2 = np.vstack([X, Xa])
+    cK2 = orc.build_cK(X2, ll, lsig, lnoise) + added_o * np.eye(len(X2))
+    L2 = m.factor()
+    np.testing.assert_allclose(L2 @ L2.T, cK2, rtol=0, atol=1e-9 * np.abs(cK2).max())
     m.set_jitter(0.0, 0)                                             # and off again
     m.set_params_(logNoise=lnoise)
     with pytest.raises(bohip.BohipError):

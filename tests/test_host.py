@@ -273,8 +273,26 @@ def test_acquisition_options_are_checked_like_nlopt(orc):
     m = OracleModel(orc, np.array([[1.0]]), np.array([2.0]), [1.0])
     with pytest.raises(ValueError):
         bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxevil=10))
-    with pytest.warns(UserWarning):
-        bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=10, ftol_abs=1e-3))
+    with pytest.warns(UserWarning):                                    # an NLopt setting without a counterpart here
+        bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=10, initial_step=0.1))
+    # ftol_abs / xtol_rel / stopval ARE implemented (the reference's test passes ftol_abs = eps(), test/acquisition.jl:6,9):
+    # no warning, and a loose ftol_abs / a reachable stopval stops the search after fewer evaluations than the default
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("error")
+        m.calls.clear()
+        bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=300, ftol_abs=np.finfo(float).eps))
+        n_eps = len(m.calls)
+        m.calls.clear()
+        f_loose, _ = bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=300, ftol_abs=0.5))
+        n_loose = len(m.calls)
+        m.calls.clear()
+        f_stop, _ = bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=300, stopval=0.1))
+        n_stop = len(m.calls)
+        m.calls.clear()
+        bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=300, xtol_rel=0.5))
+        n_xrel = len(m.calls)
+    assert n_loose <= n_eps and n_stop <= n_eps and n_xrel <= n_eps and f_stop >= 0.1
     # maxeval is honoured as given (no hidden cap): 300 evaluations allowed, the search stops on its own tolerance first
     m.calls.clear()
     bohip.acquire_max(bohip.MaxMean(), m, [-5.0], [5.0], dict(method="LD_LBFGS", restarts=2, maxeval=300))

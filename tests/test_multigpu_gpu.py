@@ -226,3 +226,97 @@ def test_two_real_devices_if_present(bohip):
         assert (bvg, big) == (bv1, bi1)
     mg.set_candidates(Xs.T)
     assert mg.score_resident("EI", [tau]) == one.score("EI", [tau], Xs.T)[1:]
+
+
+_TWO_RANK_CODE = r'''
+import json, os, sys, time
+sys.path.insert(0, %r)
+import numpy as np
+import bohip
+from bohip import _lib
+from conftest_free import synth
+rank, idfile, outfile = int(sys.argv[1]), sys.argv[2], sys.argv[3]
+res = {"rank": rank}
+try:
+    if rank == 0:
+        uid = bytes(bohip.comm_unique_id())
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(idfile + ".tmp", idfile)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            if time.time() - t0 > 120: raise SystemExit("no unique id from rank 0")
+            time.sleep(0.02)
+        uid = open(idfile, "rb").read()
+    X, y, Xs = synth(500, 4, 2048, seed=9)
+    ll = np.full(4, -0.6)
+    m = bohip.ElasticGPE(4, mean=bohip.MeanConst(0.0), kernel=bohip.SEArd(ll, 0.0), logNoise=-2.0, capacity=len(y))
+    m.append_(X.T, y)
+    tau = float(y.max())
+    t0 = time.time()
+    try:
+        m.comm_init(uid, rank, 2)            # ncclCommInitRank with nranks = 2: collective, both processes are in it now
+        res["init"] = "ok"
+    except bohip.BohipError as e:
+        res["init"] = "error"; res["code"] = e.code; res["text"] = str(e)
+    res["init_s"] = time.time() - t0
+    if res["init"] == "ok":
+        import torch
+        lo, hi = (0, 1024) if rank == 0 else (1024, 2048)
+        dXs = torch.from_numpy(np.ascontiguousarray(Xs[lo:hi])).cuda()
+        best = torch.zeros(2, dtype=torch.int64).pin_memory()
+        t_ex = []
+        for it in range(6):
+            t1 = time.perf_counter()
+            m.score_sharded_dev("EI", [tau], dXs.data_ptr(), hi - lo, lo, 2048, best.data_ptr())
+            m.synchronize()
+            t_ex.append(time.perf_counter() - t1)
+        res["best"] = [float(best.numpy()[:1].view(np.float64)[0]), int(best.numpy()[1])]
+        res["call_ms"] = 1e3 * min(t_ex)
+        _, bv, bi = m.score("EI", [tau], Xs.T)
+        res["single"] = [float(bv), int(bi)]
+        m.comm_destroy()
+except BaseException as e:      # noqa: BLE001
+    res["exception"] = repr(e)
+json.dump(res, open(outfile, "w"))
+'''
+
+
+def test_two_processes_one_device_through_rccl_itself(bohip, tmp_path):
+    """bohip_comm_unique_id + bohip_gp_comm_init with TWO ranks (two processes, both on GPU 0): the one-process-per-GPU exchange
+    of libbohip driven through RCCL's own bootstrap with nranks = 2 -- the closest a one-GPU box gets to the 8-GPU launch.
+    RCCL may refuse two ranks on one device ("Duplicate GPU detected"): then BOTH ranks must come back with BOHIP_E_COMM and
+    RCCL's own error text within the time limit (no hang, no crash), which still proves that the id exchange, ncclCommInitRank and
+    the error path work across processes.  If this RCCL build accepts it, the in-library all-gather + reduce run for real and
+    every rank must hold the winner of the unsharded call."""
+    helper = tmp_path / "conftest_free.py"
+    helper.write_text("import sys\nsys.path.insert(0, %r)\nfrom conftest import synth\n" % os.path.join(ROOT, "tests"))
+    code = tmp_path / "rank.py"
+    code.write_text(_TWO_RANK_CODE % ROOT)
+    idfile = str(tmp_path / "uid.bin")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path) + os.pathsep + os.environ.get("PYTHONPATH", ""), NCCL_DEBUG="WARN",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(code), str(r), idfile, str(tmp_path / f"out{r}.json")], env=env, cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in (0, 1)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=300))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two-rank RCCL initialisation did not return within 300 s")
+    res = [json.load(open(tmp_path / f"out{r}.json")) for r in (0, 1)]
+    for r in res:
+        assert "exception" not in r, (r, outs)
+    if all(r["init"] == "ok" for r in res):
+        for r in res:
+            assert r["best"] == r["single"], r                                   # both ranks hold the unsharded winner, bit for bit
+        print(f"RCCL accepted two ranks on one device: sharded call {res[0]['call_ms']:.3f} / {res[1]['call_ms']:.3f} ms")
+    else:
+        from bohip import _lib
+        for r in res:
+            assert r["init"] == "error" and r["code"] == _lib.E_COMM, (r, outs)
+            assert "CommInitRank" in r["text"], r                                # the failing call and RCCL's own error string
+        print("RCCL refuses two ranks on one device:", res[0]["text"][:200])

@@ -23,11 +23,16 @@ try:
     T = (N_OBS + 1 + 127) // 128
     CT = (R + 63) // 64
     nb = 8 * ((CT + 7) // 8) * T
-    buf = (C.c_ulonglong * (4 * nb))()
+    buf = (C.c_ulonglong * (6 * nb))()
     lib.bohip_debug_trace_read.restype = C.c_int
-    assert lib.bohip_debug_trace_read(buf, C.c_int64(4 * nb)) == 0
-    t = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 4).astype(np.int64)
-    t0, t1, hw, xcc_reg = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+    assert lib.bohip_debug_trace_read(buf, C.c_int64(6 * nb)) == 0
+    t = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 6).astype(np.int64)
+    t0, t1, hw, xcc_reg = t[:, 0].copy(), t[:, 1].copy(), t[:, 2], t[:, 3]
+    # core clock while the kernel runs: s_memtime (clock64) against s_memrealtime (wall_clock64, 100 MHz), per workgroup
+    dw, dc = (t[:, 1] - t[:, 0]).astype(np.float64), (t[:, 5] - t[:, 4]).astype(np.float64)
+    okc = (t[:, 1] > 0) & (dw > 500)
+    mhz = dc[okc] / dw[okc] * 100.0
+    print(f"core clock from clock64 / wall_clock64 over {okc.sum()} workgroups: mean {mhz.mean():.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}")
     xcc = xcc_reg & 0xF
     print('XCC_ID register values seen:', sorted(set(xcc_reg.tolist()))[:16], ' agreement with blockIdx%8:', np.mean((xcc_reg & 7) == xcc))
     ok = t1 > 0
