@@ -86,6 +86,12 @@ struct bohip_gp {
     bool w_done = false;       // the last factorisation also produced W = L^-1 (executor form with its inverse queue)
     // scoring scratch
     double* dKsT = nullptr;
+    unsigned long long* dclk = nullptr;   // [2] core-clock / wall-clock ticks of sampled k_trigemm_sq workgroups (timing runs)
+    int* dpieces = nullptr;      // k_trigemm_sq's row pieces, heaviest first (trigemm_pieces)
+    std::vector<int> hpieces;
+    int n_pieces = 0, pieces_T = -1;
+    int64_t pieces_cap = 0;
+    int64_t pieces_alpha = -1;
     int64_t kst_rows = 0;        // rows the K*' chunk buffer holds
     int64_t chunk_now = 0;       // candidates per K*' chunk of the current call (chunk_rows(R) <= kst_rows)
     int64_t score_launches = 0;  // k_trigemm_sq launches of the last posterior pass (BOHIP_INFO_SCORE_LAUNCHES)
@@ -143,7 +149,7 @@ struct bohip_gp {
     int jitter_tries = 0;              // 0 = report BOHIP_E_NOTPD at once (the default)
     int jitter_steps_last = 0;         // BOHIP_INFO_JITTER_STEPS: tries the last refit needed (0: none)
     double jitter_last = 0.0;          // what it added to the diagonal
-    int q_tiles = 0;  // number of q_part rows the last posterior pass produced (T, or 1 on the small-batch path)
+    int q_tiles = 0;  // row tiles behind dq after the last posterior pass (two partial sums each); 0: dq[r] is the finished sum (row-wise / split-K paths)
     bool timing = false;
     bool t_open = false;
     bool timing_dominant_only = false;   // enable_timing(2): only the dominant kernel (k_trigemm_sq) is bracketed by events
@@ -308,7 +314,7 @@ static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
 static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
-static int g_trigemm_pull = 0;  // BOHIP_TRIGEMM_PULL=1: persistent k_trigemm_sq_pull (512 workgroups pull jobs) instead of one workgroup per job -- measured slower (0.622 vs 0.596 ms at C2)
+static int g_halve_lo = -1, g_halve_hi = -1;   // BOHIP_TRIGEMM_HALVE (see trigemm_pieces)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr, bool hi = false) {
     if (p.mt <= 0 || p.nt64 <= 0 || p.kc <= 0 || batch <= 0) return 0;
@@ -329,7 +335,6 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<1>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq<2>, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
-    HIPCHK(hipFuncSetAttribute((const void*)k_trigemm_sq_pull, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_chol_chain, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_inv128, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_pair, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
@@ -357,7 +362,10 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_INV_G")) g_chol_inv_g = std::min(64, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
-    if (const char* e = getenv("BOHIP_TRIGEMM_PULL")) g_trigemm_pull = atoi(e);
+    if (const char* e = getenv("BOHIP_TRIGEMM_HALVE")) {   // "lo,hi": row tiles lo <= rt < hi go as two 64-row halves ("0,0": none)
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= a) { g_halve_lo = a; g_halve_hi = b; }
+    }
     if (const char* e = getenv("BOHIP_FUSE_FINISH")) g_fuse_finish = atoi(e);
     if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
@@ -1373,11 +1381,11 @@ static int ensure_score_scratch(bohip_gp* g, int64_t R) {
         HIPCHK(hipMalloc(&g->dKsT, (size_t)(rc + SLACK) * g->ld * 8));
         g->kst_rows = rc;
     }
-    if (g->q_cap < T * (Rpad + SLACK)) {
+    if (g->q_cap < 2 * T * (Rpad + SLACK)) {   // two partial sums per row tile (k_trigemm_sq's row pieces)
         if (g->dq) hipFree(g->dq);
         g->dq = nullptr;
-        HIPCHK(hipMalloc(&g->dq, (size_t)(T * (Rpad + SLACK)) * 8));
-        g->q_cap = T * (Rpad + SLACK);
+        HIPCHK(hipMalloc(&g->dq, (size_t)(2 * T * (Rpad + SLACK)) * 8));
+        g->q_cap = 2 * T * (Rpad + SLACK);
     }
     if (g->r_cap < Rpad) {
         for (double** p : {&g->dmu_raw, &g->dmu, &g->dvar, &g->dscore})
@@ -1437,19 +1445,71 @@ static void launch_kstar(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1,
     hipLaunchKernelGGL(k_kstar<DT>, grid, dim3(256), 0, g->stream, g->dX, g->n, Npad, dXs, r0, r1, hp, g->dKsT, g->ld, rb);
 }
 
+// The row pieces of k_trigemm_sq (kernels_score.hip), heaviest first: which row tiles go as two 64-row halves is a function
+// of the number of row tiles and of where the alpha row sits -- nothing else, so a candidate's score does not depend on the batch it
+// is scored in.  Default: NONE (whole tiles; only a last tile whose live rows fit its upper half runs as a half piece, as it always
+// did).  BOHIP_TRIGEMM_HALVE="lo,hi" halves the tiles lo <= rt < hi -- the round-4 experiment: tools/sim_trigemm_tail.py predicted
+// -3.7 % for the shortest third of the tiles (the launch ends evenly: idle tail 3.2 -> 0.4 % in the model), the chip gave 0.0 %
+// (profiles/r04_trigemm_halve_sweep.txt: "0,8" 609 us against 609; "0,12" 621; all halves 665): MI355X clocks to its power
+// budget, CUs that idle at the end of the launch hand their share of it to the ones still working, and a half job spends more
+// LDS reads per flop.
+static void trigemm_pieces(int T, int64_t alpha_row, std::vector<int>& out) {
+    int lo = 0, hi = 0;
+    if (g_halve_lo >= 0) { lo = std::min(g_halve_lo, T); hi = std::min(std::max(g_halve_hi, lo), T); }
+    struct P { double cost; int code; };
+    std::vector<P> ps;
+    for (int rt = 0; rt < T; ++rt) {
+        const int64_t live = alpha_row + 1 - (int64_t)rt * TILE;   // live rows of this tile (the last one: up to the alpha row)
+        if (live <= TILE / 2) { ps.push_back({(rt + 0.5) / 2.0, rt | PIECE_UPPER_SOLO << 16}); continue; }
+        if (rt >= lo && rt < hi) {
+            ps.push_back({(rt + 0.5) / 2.0, rt | PIECE_UPPER << 16});
+            ps.push_back({(rt + 1.0) / 2.0, rt | PIECE_LOWER << 16});
+        } else {
+            ps.push_back({rt + 1.0, rt | PIECE_WHOLE << 16});
+        }
+    }
+    std::stable_sort(ps.begin(), ps.end(), [](const P& a, const P& b) { return a.cost > b.cost; });
+    out.clear();
+    for (const P& q : ps) out.push_back(q.code);
+}
+static int ensure_pieces(bohip_gp* g, int T, int64_t alpha_row) {
+    if (g->pieces_T == T && g->pieces_alpha == alpha_row && g->dpieces) return 0;
+    std::vector<int> ps;
+    trigemm_pieces(T, alpha_row, ps);
+    if (T > 65535) return fail(BOHIP_E_UNSUPPORTED, "too many row tiles");
+    if ((int64_t)ps.size() > g->pieces_cap) {
+        if (g->dpieces) { HIPCHK(hipStreamSynchronize(g->stream)); HIPCHK(hipFree(g->dpieces)); g->dpieces = nullptr; }
+        g->pieces_cap = 2 * (int64_t)ps.size() + 64;
+        HIPCHK(hipMalloc(&g->dpieces, (size_t)g->pieces_cap * sizeof(int)));
+    }
+    // (stream-ordered: a launch of an earlier call may still be reading the old table)
+    g->hpieces = ps;
+    HIPCHK(hipMemcpyAsync(g->dpieces, g->hpieces.data(), ps.size() * sizeof(int), hipMemcpyHostToDevice, g->stream));
+    g->n_pieces = (int)ps.size();
+    g->pieces_T = T; g->pieces_alpha = alpha_row;
+    return 0;
+}
+
 // V = W K* with the fused epilogue (k_trigemm_sq): one launch per K*' chunk.
 static int launch_trigemm(bohip_gp* g, int T, int64_t ncand, int64_t N, int64_t Rpad, int64_t r0, double* VT,
-                          const FuseParams& fz = FuseParams{}) {
+                          FuseParams fz = FuseParams{}) {
     const int CT = (int)((ncand + CTILE - 1) / CTILE), n_local = (CT + 7) / 8;
-    if (g_ks8 && g_trigemm_pull && g->dfz_cnt && 8 * n_local * T > 512)
-        hipLaunchKernelGGL(k_trigemm_sq_pull, dim3(512), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz, g->dfz_cnt + g->fz_cap + 1);
-    else if (g_ks8)
-        hipLaunchKernelGGL(k_trigemm_sq<2>, dim3(8 * n_local * T), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz);
+    CHK(ensure_pieces(g, T, N));
+    const int NP = g->n_pieces;
+    fz.T = T;
+    if (g->timing) {   // core clock under the dominant kernel (BOHIP_INFO_KERNEL_CLOCK_MHZ)
+        if (!g->dclk) {
+            HIPCHK(hipMalloc(&g->dclk, 2 * sizeof(unsigned long long)));
+            HIPCHK(hipMemsetAsync(g->dclk, 0, 2 * sizeof(unsigned long long), g->stream));
+        }
+        fz.clk = g->dclk;
+    }
+    if (g_ks8)
+        hipLaunchKernelGGL(k_trigemm_sq<2>, dim3(8 * n_local * NP), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, g->dpieces, NP, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz);
     else
-        hipLaunchKernelGGL(k_trigemm_sq<1>, dim3(8 * n_local * T), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, g->dW,
-                           g->ld, g->dKsT, g->ld, T, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz);
+        hipLaunchKernelGGL(k_trigemm_sq<1>, dim3(8 * n_local * NP), dim3(GEMM_THREADS), glds3_lds_bytes<4>(), g->stream, g->dW,
+                           g->ld, g->dKsT, g->ld, g->dpieces, NP, CT, N, g->dq, Rpad, g->dmu_raw, r0, VT, g->ld, fz);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1504,7 +1564,7 @@ static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r
                        d_var ? d_var + r0 : nullptr, d_score ? d_score + r0 : nullptr, d_best, (long long)best_off);
     HIPCHK(hipGetLastError());
     t_end(g);
-    g->q_tiles = 1;
+    g->q_tiles = 0;
     if (want_u) {
         t_begin(g, "small_U");
         // U'[r][c] = sum_{k>=c} W'[c][k] V'[r][k]
@@ -1586,7 +1646,7 @@ static int split_posterior(bohip_gp* g, const double* dXs, int64_t R, const Spli
                        g->dmu_raw, want_u ? g->dVT : nullptr, ld);
     HIPCHK(hipGetLastError());
     t_end(g);
-    g->q_tiles = 1;
+    g->q_tiles = 0;
     if (want_u) {
         t_begin(g, "split_U");
         GemmNTParams u{};   // partial U'[r][j] = sum over the slice's i of V'[r][i] W'[j][i]   (B = W' upper-triangular: i >= j)
@@ -1710,7 +1770,7 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
         t_begin(g, "small_V");
         CHK(launch_rows_trimv(g, g->dW, N + 1, g->dKsT, (int)R, g->dApp, 0));
         t_end(g);
-        g->q_tiles = 1;
+        g->q_tiles = 0;
         t_begin(g, "small_U");
         CHK(launch_rows_trimv(g, g->dWT, N, g->dApp, (int)R, g->dApp + (int64_t)APP_UT_ROW0 * g->ld, 1));
         t_end(g);
@@ -1724,7 +1784,7 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     if (sp.nsl > 0) {
         CHK(split_posterior(g, dXs, R, sp, true));
         t_begin(g, "score+grad");
-        hipLaunchKernelGGL(k_score, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, g->stream, g->dq, Rpad, 1, g->dmu_raw, R,
+        hipLaunchKernelGGL(k_score, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, g->stream, g->dq, Rpad, 0, g->dmu_raw, R,
                            std::exp(2.0 * g->logsig), g->beta, ap, g->dmu, g->dvar, d_score, (Best*)nullptr);
         CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dUT));
         t_end(g);
@@ -1831,6 +1891,8 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dbest) hipFree(g->dbest);
     if (g->dfz_cnt) hipFree(g->dfz_cnt);
     if (g->dfz_best) hipFree(g->dfz_best);
+    if (g->dpieces) hipFree(g->dpieces);
+    if (g->dclk) hipFree(g->dclk);
     if (g->dgrad) hipFree(g->dgrad);
     if (g->dgparts) hipFree(g->dgparts);
     if (g->dsplit) hipFree(g->dsplit);
@@ -2472,6 +2534,16 @@ int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
         case BOHIP_INFO_JITTER_STEPS: *value = g->jitter_steps_last; return 0;
         case BOHIP_INFO_SCORE_LAUNCHES: *value = g->score_launches; return 0;
         case BOHIP_INFO_SCORE_CHUNK: *value = g->chunk_now; return 0;
+        case BOHIP_INFO_KERNEL_CLOCK_MHZ: {   // since the previous read; synchronises the handle's stream
+            *value = 0;
+            if (!g->dclk) return 0;
+            unsigned long long c[2] = {0, 0};
+            if (hipSetDevice(g->device) != hipSuccess || hipStreamSynchronize(g->stream) != hipSuccess ||
+                hipMemcpy(c, g->dclk, sizeof(c), hipMemcpyDeviceToHost) != hipSuccess || hipMemset(g->dclk, 0, sizeof(c)) != hipSuccess)
+                return fail(BOHIP_E_HIP, "reading the clock sample failed");
+            if (c[1] > 0) *value = (int64_t)((double)c[0] / (double)c[1] * 100.0 + 0.5);   // wall_clock64 ticks at 100 MHz
+            return 0;
+        }
         default: return fail(BOHIP_E_ARG, "unknown info id");
     }
 }
@@ -2557,6 +2629,15 @@ int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base
     layout[12] = (int64_t)chol_xp3_word(T);
     if ((int64_t)all.size() <= cap && out) std::memcpy(out, all.data(), all.size() * sizeof(bohip::ExTask));
     return (int64_t)all.size();
+}
+// tools only (tools/trace_trigemm.py): the row pieces k_trigemm_sq runs for T row tiles with the alpha row at alpha_row, in issue order
+// (piece = rt | mode << 16, see kernels_score.hip); returns their number
+int bohip_debug_trigemm_pieces(int T, int64_t alpha_row, int* out, int cap) {
+    one_time_kernel_setup();
+    std::vector<int> ps;
+    trigemm_pieces(T, alpha_row, ps);
+    for (int i = 0; i < (int)ps.size() && i < cap; ++i) out[i] = ps[i];
+    return (int)ps.size();
 }
 // tools and bench.py: switch the executor's inverse queues at run time (returns the previous chunk size; 0 = off: the factorisation
 // alone can then be timed against its own flop count)

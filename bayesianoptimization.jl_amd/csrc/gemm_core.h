@@ -265,6 +265,12 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a_src1 + (int64_t)kc * KC), (lds_void_ptr)(a_dst1 + buf * AT), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(b_src + (int64_t)kc * KC), (lds_void_ptr)(b_dst + buf * BT), 16, 0, 0);
     };
+    // HALF mode reads rows 0..63 of the A tile only: pieces 8..15 (rows 64..127, a_src1) are not fetched -- two DMA pieces per
+    // wave and chunk instead of three (and the rows behind a 64-row half job need not exist)
+    auto issue_h = [&](int kc, int buf) {
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(a_src0 + (int64_t)kc * KC), (lds_void_ptr)(a_dst0 + buf * AT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(b_src + (int64_t)kc * KC), (lds_void_ptr)(b_dst + buf * BT), 16, 0, 0);
+    };
     const int k = lane >> 4, b = (lane >> 2) & 3, t = lane & 3;
     const int r7a = 4 * (b >> 1) + t, r7b = 4 * (b & 1) + t;
     const int oa = ((4 * khalf + k) ^ r7a) << 1, ob = ((4 * khalf + k) ^ r7b) << 1;
@@ -278,12 +284,22 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
     const int a_frag = (wre * 64 + r7a) * GL_ROW + oa, b_frag = (wc * 8 * NJ + r7b) * GL_ROW + ob;
     const bool wave_active = half || wr * 64 < active_rows;
     const int skip0 = __builtin_amdgcn_readfirstlane(khalf - 8 * wre);   // wave-uniform: keep it in an SGPR
-    issue(kc_begin, 0);
-    if (kc_begin + 1 < kc_end) {
-        issue(kc_begin + 1, 1);
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if (half) {
+        issue_h(kc_begin, 0);
+        if (kc_begin + 1 < kc_end) {
+            issue_h(kc_begin + 1, 1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        issue(kc_begin, 0);
+        if (kc_begin + 1 < kc_end) {
+            issue(kc_begin + 1, 1);
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __builtin_amdgcn_s_barrier();
     // the chunk loop exists three times (both / even / odd members): a choice INSIDE the loop costs 40 VGPRs of copies
@@ -298,7 +314,11 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
 #endif
             const int nxt2 = cur == 0 ? 2 : cur - 1;
             const bool more2 = kc + 2 < kc_end;
-            if (more2 && !(ABL & 1)) issue(kc + 2, nxt2);
+            constexpr bool HALF = decltype(xy_tag)::value != 0;
+            if (more2 && !(ABL & 1)) {
+                if constexpr (HALF) issue_h(kc + 2, nxt2);
+                else issue(kc + 2, nxt2);
+            }
             if (wave_active) {
                 const double* ap = As + cur * AT + a_frag;
                 const double* bp = Bs + cur * BT + b_frag;
@@ -310,8 +330,12 @@ __device__ __forceinline__ void gemm_tile_loop_glds3_ks(const double* __restrict
             const unsigned long long tB = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            if (more2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (more2) {
+                if constexpr (HALF) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if BOHIP_TRACE
             const unsigned long long tC = __builtin_amdgcn_s_memtime();

@@ -118,12 +118,14 @@ struct FuseParams {
     unsigned* total_cnt;     // [1] finished candidate tiles
     Best* tile_best;         // [candidate tiles]
     int tiles_total;         // candidate tiles of the whole batch (all chunks)
+    int T;                   // row tiles (the finish adds two partial sums per tile)
     int64_t R_total;         // candidates of the whole batch
     double sigma2, beta;
     AcqParams ap;
     double *mu_out, *var_out, *score_out;   // nullable, indexed by the global candidate number
     Best* best_out;          // nullable: the batch's arg-max record
     long long best_off;      // added to the winner's index (sharded scoring)
+    unsigned long long* clk; // nullable: [2] core-clock and 100 MHz wall-clock ticks summed over a sample of workgroups (timing runs)
 };
 __device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, const double* q_part, int64_t ldq,
                                      const double* mu_raw);
@@ -132,20 +134,26 @@ __device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, co
 #if BOHIP_TRACE
 __device__ unsigned long long g_trace[6 * 8192];   // per workgroup: wall start, wall end, HW_ID, XCC_ID, core-clock start, core-clock end
 #endif
-// position `sq` of the heaviest-first row-tile sequence.  Job length = K extent = rt + 1 units, except that a last row tile
-// with <= 64 live rows runs in the loop's half mode and costs (rt + 1) / 2: it is issued where a job of that length belongs
-__device__ __forceinline__ int trigemm_row_tile(int sq, int T, int64_t alpha_row) {
-    if (alpha_row + 1 - (int64_t)(T - 1) * TILE <= TILE / 2 && T > 2) {
-        const int n_before = T - 1 - T / 2;   // row tiles rt <= T-2 that are longer than T / 2 units
-        return sq < n_before ? T - 2 - sq : sq == n_before ? T - 1 : T - 1 - sq;
-    }
-    return T - 1 - sq;
-}
+// ---- row pieces ------------------------------------------------------------------------------------------------------
+// A job is one ROW PIECE of W against one 64-wide candidate tile.  A piece is a whole 128-row tile (job length = its K extent:
+// rt + 1 units) or one 64-row HALF of a tile, run in the loop's half mode (both wave rows work on the 64 rows, even / odd
+// members of every contraction-index pair, partial sums added at the end): half the rows, so about half the time.
+// Why halves: with whole tiles only the launch ends raggedly -- the jobs in flight when the queue runs dry are 1 to 8 units
+// long (two co-resident workgroups: up to 160 us), CUs finish over an 80 us window and idle 5 % of the launch on average
+// (tools/trace_trigemm.py).  With the shortest third of the row tiles issued as halves the last jobs are a few units at most
+// (tools/sim_trigemm_tail.py: idle tail 3.2 % -> 0.4 % in the model).  The HOST lists the pieces heaviest-first
+// (trigemm_pieces in bohip.hip; the list depends on the number of row tiles and the position of the alpha row ONLY, never on
+// the batch: scores stay batch- and shard-independent) and the kernel reads its piece from that table.
+// Encoding: piece = rt | mode << 16;  mode 0 whole tile, 1 rows 0..63, 2 rows 64..127, 3 rows 0..63 of a tile whose rows 64..127
+// are all padding (the last tile when the alpha row sits in its upper half): no sibling piece exists.
+// q_part holds TWO partial sums per row tile (rows 0..63 and 64..127, [2 rt + h][r]); the finish adds (q[2t] + q[2t+1]) tile
+// by tile -- for a whole-tile job exactly the sum it used to store, so a list without halves reproduces the old bits.
+constexpr int PIECE_WHOLE = 0, PIECE_UPPER = 1, PIECE_LOWER = 2, PIECE_UPPER_SOLO = 3;
 
-// one job: row tile rt of W against candidate tile ct of the chunk (all arguments wave-uniform)
+// one job: row piece (rt, mode) of W against candidate tile ct of the chunk (all arguments wave-uniform)
 template <int KS>
-__device__ __forceinline__ void trigemm_job(int rt, int ct, const double* __restrict__ W, int64_t ldw,
-                                            const double* __restrict__ KsT, int64_t ldk, int T, int64_t alpha_row,
+__device__ __forceinline__ void trigemm_job(int rt, int mode, int ct, const double* __restrict__ W, int64_t ldw,
+                                            const double* __restrict__ KsT, int64_t ldk, int NP, int64_t alpha_row,
                                             double* __restrict__ q_part, int64_t ldq, double* __restrict__ mu_raw, int64_t r_off,
                                             double* __restrict__ VT, int64_t ldv, const FuseParams& fz, double* smem, int tid) {
     constexpr int NJ = 4, CW = CTILE;
@@ -154,18 +162,23 @@ __device__ __forceinline__ void trigemm_job(int rt, int ct, const double* __rest
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = 0.0;
-    const int active_rows = (int)min((int64_t)TILE, alpha_row + 1 - (int64_t)rt * TILE);  // rows past alpha' are padding
+    const int h = mode == PIECE_LOWER ? 1 : 0;                 // which half the piece starts at
+    const int64_t row_base = (int64_t)rt * TILE + 64 * h;
+    // rows past alpha' are padding; a half piece has at most 64 live rows (-> the loop's half mode)
+    const int active_rows = (int)min((int64_t)(mode == PIECE_WHOLE ? TILE : TILE / 2), alpha_row + 1 - row_base);
+    const int tri_kc = rt * (TILE / KC) + 4 * h;              // first chunk of the piece's triangular block
+    const int kc_end = mode == PIECE_WHOLE ? (rt + 1) * (TILE / KC) : tri_kc + 4;
     if constexpr (KS == 2)
-        gemm_tile_loop_glds3_ks<NJ, BOHIP_ABL, true>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
-                                    (rt + 1) * (TILE / KC), smem, acc, active_rows, rt * (TILE / KC), tid);
+        gemm_tile_loop_glds3_ks<NJ, BOHIP_ABL, true>(W + row_base * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
+                                    kc_end, smem, acc, active_rows, tri_kc, tid);
     else
-        gemm_tile_loop_glds3<NJ>(W + (int64_t)rt * TILE * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0,
-                                 (rt + 1) * (TILE / KC), smem, acc, active_rows);
+        gemm_tile_loop_glds3<NJ>(W + row_base * ldw, ldw, KsT + (int64_t)ct * CW * ldk, ldk, 0, kc_end, smem, acc, active_rows);
     const int lane = tid & 63, wave = tid >> 6, wr = (wave & 3) >> 1, wc = wave & 1;
     __syncthreads();     // (the raw-barrier loops end on s_barrier; make the reuse of smem below explicit)
     double* red = smem;  // [2][CW]
+    // half mode leaves the piece's 64 rows in wave row 0; wave row 1 holds zeros that belong to NO row of this piece
+    const bool rows_mine = mode == PIECE_WHOLE || wr == 0;
     if (wave < 4) {
-    const int64_t row_base = (int64_t)rt * TILE;
 #pragma unroll
     for (int nj = 0; nj < NJ; ++nj) {
         double s = 0.0;
@@ -173,12 +186,12 @@ __device__ __forceinline__ void trigemm_job(int rt, int ct, const double* __rest
         for (int mi = 0; mi < 8; ++mi) {
             const int64_t grow = row_base + acc_row(lane, wr, mi);
             const double v = acc[mi][nj];
-            if (grow == alpha_row) {
+            if (grow == alpha_row && rows_mine) {
                 __hip_atomic_store(mu_raw + r_off + (int64_t)ct * CW + acc_col<NJ>(lane, wc, nj), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 s += v * v;
             }
-            if (VT != nullptr && grow < alpha_row)
+            if (VT != nullptr && grow < alpha_row && rows_mine)
                 VT[((int64_t)ct * CW + acc_col<NJ>(lane, wc, nj)) * ldv + grow] = v;
         }
         s += __shfl_xor(s, 8);
@@ -188,24 +201,27 @@ __device__ __forceinline__ void trigemm_job(int rt, int ct, const double* __rest
     }
     }
     __syncthreads();
-    if (tid < CW)
-        __hip_atomic_store(q_part + (int64_t)rt * ldq + r_off + (int64_t)ct * CW + tid, red[tid] + red[CW + tid],
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 2 * CW) {   // thread t < 64: the sum over the piece's first 64 rows; t >= 64: over rows 64..127 of a whole tile
+        const int hh = tid >> 6, c = tid & (CW - 1);
+        double* dst = q_part + (int64_t)(2 * rt + (mode == PIECE_WHOLE ? hh : h)) * ldq + r_off + (int64_t)ct * CW + c;
+        if (mode == PIECE_WHOLE || hh == 0) __hip_atomic_store(dst, red[hh * CW + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else if (mode == PIECE_UPPER_SOLO) __hip_atomic_store(dst + ldq, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no sibling: its slot is zero
+    }
     if (fz.tile_cnt != nullptr) {
         __shared__ int s_last;
         const int tile_g = (int)(r_off / CW) + ct;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the agent-scope stores above have landed (a workgroup-scope fence emits no such wait)
         __syncthreads();
-        if (tid == 0) s_last = atomicAdd(fz.tile_cnt + tile_g, 1u) == (unsigned)(T - 1);
+        if (tid == 0) s_last = atomicAdd(fz.tile_cnt + tile_g, 1u) == (unsigned)(NP - 1);
         __syncthreads();
-        if (s_last && tid < 64) trigemm_fused_finish(fz, tile_g, T, q_part, ldq, mu_raw);
+        if (s_last && tid < 64) trigemm_fused_finish(fz, tile_g, fz.T, q_part, ldq, mu_raw);
     }
 }
 
 template <int KS>  // 1: 4 waves; 2: 8 waves, contraction index halved inside the workgroup (default)
 __global__ __launch_bounds__(KS * GEMM_THREADS, 2 * KS) void k_trigemm_sq(const double* __restrict__ W, int64_t ldw,
                                                                 const double* __restrict__ KsT, int64_t ldk,
-                                                                int T, int CT, int64_t alpha_row,
+                                                                const int* __restrict__ pieces, int NP, int CT, int64_t alpha_row,
                                                                 double* __restrict__ q_part, int64_t ldq,
                                                                 double* __restrict__ mu_raw, int64_t r_off,
                                                                 double* __restrict__ VT, int64_t ldv, FuseParams fz) {
@@ -226,58 +242,21 @@ __global__ __launch_bounds__(KS * GEMM_THREADS, 2 * KS) void k_trigemm_sq(const 
     } trace_end{t_start, c_start};
 #endif
     // blocks are dealt to XCDs round-robin (block b runs on XCD b % 8): an XCD owns the candidate tiles ct = xcd (mod 8) and
-    // walks the row tiles together, heaviest first
+    // walks the row pieces together, heaviest first
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int n_local = (CT + 7) >> 3;
-    const int rt = trigemm_row_tile(slot / n_local, T, alpha_row);
     const int ct = xcd + 8 * (slot % n_local);
-    if (ct >= CT || rt < 0) return;
-    trigemm_job<KS>(rt, ct, W, ldw, KsT, ldk, T, alpha_row, q_part, ldq, mu_raw, r_off, VT, ldv, fz, smem, (int)threadIdx.x);
-}
-
-// Persistent form: 512 workgroups (two per CU) PULL jobs.  Each XCD has its own list (the candidate tiles ct = xcd (mod 8),
-// row tiles heaviest first -- the W row-tile stream stays shared through that XCD's L2) behind an atomic cursor; a workgroup
-// whose list has run dry steals from the next XCD's.  Against one workgroup per job this removes the per-job dispatch and the
-// fixed eighth of the work per XCD (the XCDs finish up to 2.5 % apart).  jobq: 8 cursors + 1 exit counter, all left at zero.
-__global__ __launch_bounds__(2 * GEMM_THREADS, 4) void k_trigemm_sq_pull(const double* __restrict__ W, int64_t ldw,
-                                                                const double* __restrict__ KsT, int64_t ldk,
-                                                                int T, int CT, int64_t alpha_row,
-                                                                double* __restrict__ q_part, int64_t ldq,
-                                                                double* __restrict__ mu_raw, int64_t r_off,
-                                                                double* __restrict__ VT, int64_t ldv, FuseParams fz,
-                                                                unsigned* __restrict__ jobq) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ int s_job, s_probe;
-    const int xcd = blockIdx.x & 7;
-    const int n_local = (CT + 7) >> 3, per = n_local * T;
-    int probe = 0;   // lists found empty so far, starting from the own one
-    for (;;) {
-        if (threadIdx.x == 0) {
-            int j = -1, p = probe;
-            for (; p < 8; ++p) {
-                const int x = (xcd + p) & 7;
-                const unsigned sq = atomicAdd(jobq + x, 1u);
-                if (sq < (unsigned)per) { j = x * per + (int)sq; break; }
-            }
-            s_job = j; s_probe = p;
-        }
-        __syncthreads();
-        const int j = __builtin_amdgcn_readfirstlane(s_job);
-        probe = __builtin_amdgcn_readfirstlane(s_probe);
-        __syncthreads();
-        if (j < 0) break;
-        const int x = j / per, sq = j - x * per;
-        const int rt = trigemm_row_tile(sq / n_local, T, alpha_row);
-        const int ct = x + 8 * (sq % n_local);
-        if (ct >= CT) continue;
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));   // opaque per job: nothing lane-dependent is hoisted out of this loop (it cost 86 spilled VGPRs)
-        trigemm_job<2>(rt, ct, W, ldw, KsT, ldk, T, alpha_row, q_part, ldq, mu_raw, r_off, VT, ldv, fz, smem, tid);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && atomicAdd(jobq + 8, 1u) == gridDim.x - 1) {   // last one out resets the cursors
-#pragma unroll
-        for (int x = 0; x < 9; ++x) __hip_atomic_store(jobq + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ct >= CT) return;
+    const int piece = __builtin_amdgcn_readfirstlane(pieces[slot / n_local]);   // (uniform: a scalar load)
+    // timing runs (bohip_gp_enable_timing): every 33rd workgroup reports how many core-clock cycles and 100 MHz ticks it lived --
+    // their ratio is the clock the chip sustained UNDER THIS KERNEL (MI355X clocks to its power budget: ~2.0 of 2.4 GHz here)
+    __shared__ unsigned long long s_clk[2];
+    if (fz.clk != nullptr && blockIdx.x % 33 == 0 && threadIdx.x == 0) { s_clk[0] = clock64(); s_clk[1] = wall_clock64(); }
+    trigemm_job<KS>(piece & 0xffff, piece >> 16, ct, W, ldw, KsT, ldk, NP, alpha_row, q_part, ldq, mu_raw, r_off, VT, ldv, fz, smem,
+                    (int)threadIdx.x);
+    if (fz.clk != nullptr && blockIdx.x % 33 == 0 && threadIdx.x == 0) {
+        atomicAdd(fz.clk, (unsigned long long)clock64() - s_clk[0]);
+        atomicAdd(fz.clk + 1, (unsigned long long)wall_clock64() - s_clk[1]);
     }
 }
 
@@ -386,7 +365,9 @@ __device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, co
     long long idx = -1;
     if (r < fz.R_total) {
         double q = 0.0;
-        for (int t = 0; t < T; ++t) q += __hip_atomic_load(q_part + (int64_t)t * ldq + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int t = 0; t < T; ++t)   // (upper half + lower half) tile by tile: what a whole-tile job used to store as ONE number
+            q += __hip_atomic_load(q_part + (int64_t)(2 * t) * ldq + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+                 __hip_atomic_load(q_part + (int64_t)(2 * t + 1) * ldq + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double s2 = fz.sigma2 - q;
         if (s2 < 0.0) s2 = 0.0;  // predict_f: max(sigma2, 0)
         const double mu = fz.beta + __hip_atomic_load(mu_raw + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -432,6 +413,8 @@ __device__ void trigemm_fused_finish(const FuseParams& fz, int tile_g, int T, co
     }
 }
 
+// T > 0: T row tiles with TWO partial sums each ([2 t], [2 t + 1]: k_trigemm_sq's layout); T = 0: q_part[r] is the finished sum
+// (row-wise and split-K paths)
 __global__ __launch_bounds__(256) void k_score(const double* __restrict__ q_part, int64_t ldq, int T,
                                                const double* __restrict__ mu_raw, int64_t R, double sigma2,
                                                double beta, AcqParams ap, double* __restrict__ mu_out,
@@ -444,7 +427,8 @@ __global__ __launch_bounds__(256) void k_score(const double* __restrict__ q_part
     long long idx = -1;
     if (r < R) {
         double q = 0.0;
-        for (int t = 0; t < T; ++t) q += q_part[(int64_t)t * ldq + r];
+        for (int t = 0; t < T; ++t) q += q_part[(int64_t)(2 * t) * ldq + r] + q_part[(int64_t)(2 * t + 1) * ldq + r];
+        if (T == 0) q = q_part[r];
         double s2 = sigma2 - q;
         if (s2 < 0.0) s2 = 0.0;  // predict_f: max(sigma2, 0)
         const double mu = beta + mu_raw[r];

@@ -258,6 +258,7 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
     # one launch covers one K*' chunk; the library says how many chunks the shard's call is cut into (equal-sized multiples of 512
     # candidates, BOHIP_INFO_SCORE_LAUNCHES) -- `launches` arrives in `extra` from the caller that holds the handle
     launches = int((extra or {}).pop("_launches", 0)) or max(1, -(-R_GPU // 4096))
+    clock_mhz = int((extra or {}).pop("_clock_mhz", 0))
     flops_per_launch = (R_GPU / launches) * (N_OBS * N_OBS + 2.0 * N_OBS)  # triangular contraction + mu row
     tg_ms = tg_ms / launches
     achieved = flops_per_launch / (tg_ms * 1e-3) / 1e12
@@ -288,7 +289,12 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
                      "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_source": traffic_source,
                      "avg_launch_ms": tg_ms, "flops_per_launch": flops_per_launch, "launches_per_step": launches,
-                     "step_over_kernel": ms_per_step / (tg_ms * launches)},
+                     "step_over_kernel": ms_per_step / (tg_ms * launches),
+                     # MI355X clocks to its power budget (MI355X_MICROARCH.md, DVFS): `peak` is the 2.4 GHz figure; the clock the chip
+                     # actually sustained under this kernel during the timed region is measured inside the kernel (every 33rd workgroup
+                     # counts core-clock cycles against the 100 MHz wall clock)
+                     **({"sustained_clock_mhz": clock_mhz, "peak_at_sustained_clock": FP64_PEAK_TFLOPS * clock_mhz / 2400.0,
+                         "frac_of_peak_at_sustained_clock": achieved / (FP64_PEAK_TFLOPS * clock_mhz / 2400.0)} if clock_mhz > 0 else {})},
         "stage_ms": {**{k: v for k, v in info_ms.items() if k != "trigemm_sq"}, **stage_ms},
         "model_update_ms": fit_ms.get("model_update_ms", fit_ms),
         "cholesky": ({"N": N_OBS, "gflops": fit_ms["cholesky_alone_tflops"] * 1e3,
@@ -400,6 +406,7 @@ def main_single_process(args):
         stage_sum = {}
         for name, ms in model.timing(4096):
             stage_sum[name] = stage_sum.get(name, 0.0) + ms
+        clock_mhz = model.info(_lib.INFO_KERNEL_CLOCK_MHZ)   # core clock under k_trigemm_sq over the timed region (sampled workgroups)
         # UNTIMED: one more second of the same step, so that a coarse GPU-activity sampler around this process sees the device busy
         # (the timed region is ~20 ms of a run whose remainder is the CPU baseline)
         model.enable_timing(0)
@@ -408,7 +415,7 @@ def main_single_process(args):
             step()
         n_launch = C.c_int64(0)
         _lib.check(lib.bohip_gp_info(model._h, _lib.INFO_SCORE_LAUNCHES, C.byref(n_launch)))
-        extra = {"_launches": int(n_launch.value), "value_host_buffers": R_total * args.steps / el_h, "ms_per_step_host_buffers": el_h / args.steps * 1e3,
+        extra = {"_launches": int(n_launch.value), "_clock_mhz": clock_mhz, "value_host_buffers": R_total * args.steps / el_h, "ms_per_step_host_buffers": el_h / args.steps * 1e3,
                  "host_buffers_note": "same workload through bohip_gp_score: host X* in (pageable, 256 KB H2D inside the "
                                       "call), 16-byte record out; `value` is the HBM-resident rate",
                  "host_buffers_same_winner": bool(hv == val and hi == idx)}

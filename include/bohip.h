@@ -177,6 +177,8 @@ int bohip_gp_get_alpha(bohip_gp *gp, double *alpha);
 #define BOHIP_INFO_JITTER_STEPS 7 /* jitter tries the last refit needed (0: none; see bohip_gp_set_jitter) */
 #define BOHIP_INFO_SCORE_LAUNCHES 8 /* K*' chunks (= k_trigemm_sq launches) of the last whole-K scoring pass */
 #define BOHIP_INFO_SCORE_CHUNK 9  /* candidates per K*' chunk of the last scoring call (equal-sized multiples of 512) */
+#define BOHIP_INFO_KERNEL_CLOCK_MHZ 10 /* core clock the chip sustained under k_trigemm_sq since the previous read (timing enabled:
+                                        * a sample of its workgroups counts core-clock cycles against the 100 MHz wall clock), else 0 */
 int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
 /* Benchmarks only (bench.py, tools/): the executor form of the factorisation grows W = L^-1 behind the pivot chain in
  * pieces of `blocks` 128-blocks (default 8).  0 switches those queues off -- the factorisation then runs alone and can

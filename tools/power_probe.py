@@ -37,8 +37,10 @@ def run(name, xs, reps=60):
         ts.append(dict(m.timing()).get("trigemm_sq", float("nan")))
     ts = np.array(ts)
     med = float(np.median(ts))
+    mhz = m.info(_lib.INFO_KERNEL_CLOCK_MHZ)     # core clock under the kernel (sampled workgroups: clock64 / wall_clock64)
     print(f"{name:34s} trigemm_sq median {med * 1e3:7.1f} us  (min {ts.min() * 1e3:7.1f}, max {ts.max() * 1e3:7.1f})  "
-          f"{flops / (med * 1e-3) / 1e12:5.1f} TF/s = {flops / (med * 1e-3) / 1e12 / 78.6:.3f} of 78.6", flush=True)
+          f"{flops / (med * 1e-3) / 1e12:5.1f} TF/s = {flops / (med * 1e-3) / 1e12 / 78.6:.3f} of 78.6;  core clock {mhz} MHz -> "
+          f"{med * mhz:7.1f} kcycles per launch, {flops / (med * 1e-3) / 1e12 / (78.6 * mhz / 2400.0):.3f} of the peak at that clock", flush=True)
     return med
 
 

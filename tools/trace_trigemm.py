@@ -22,7 +22,10 @@ try:
         m.score("EI", [float(y.max())], Xs.T)
     T = (N_OBS + 1 + 127) // 128
     CT = (R + 63) // 64
-    nb = 8 * ((CT + 7) // 8) * T
+    pcs = (C.c_int * 4096)()
+    NP = lib.bohip_debug_trigemm_pieces(T, C.c_int64(N_OBS), pcs, 4096)
+    pieces = np.array(pcs[:NP])
+    nb = 8 * ((CT + 7) // 8) * NP
     buf = (C.c_ulonglong * (6 * nb))()
     lib.bohip_debug_trace_read.restype = C.c_int
     assert lib.bohip_debug_trace_read(buf, C.c_int64(6 * nb)) == 0
@@ -45,13 +48,13 @@ try:
     print(f"blocks {nb} (with work {ok.sum()}), span {span} ticks, distinct CUs {len(set(key[ok]))}")
     slot = np.arange(nb) >> 3
     n_local = (CT + 7) // 8
-    rt = T - 1 - slot // n_local
-    if (N_OBS + 1) - (T - 1) * 128 <= 64 and T > 2:   # half-mode last tile is issued where a job of its length belongs
-        sq = slot // n_local; nbf = T - 1 - T // 2
-        rt = np.where(sq < nbf, T - 2 - sq, np.where(sq == nbf, T - 1, T - 1 - sq))
-    for r in sorted(set(rt[ok])):
-        sel = ok & (rt == r)
-        print(f"  rt={r:2d} jobs {sel.sum():4d} dur mean {np.mean((t1 - t0)[sel]):8.1f} ticks  per-unit {np.mean((t1 - t0)[sel]) / (r + 1):6.1f}  start mean {np.mean(t0[sel] - start):9.1f}  end mean {np.mean(t1[sel]):9.1f}")
+    pc = pieces[slot // n_local]
+    rt, mode = pc & 0xffff, pc >> 16
+    units = np.where(mode == 0, rt + 1.0, np.where(mode == 2, (rt + 1.0) / 2, (rt + 0.5) / 2))   # job length in 128 x 64 x 128 units
+    for key_ in sorted(set(zip(rt[ok].tolist(), mode[ok].tolist()))):
+        sel = ok & (rt == key_[0]) & (mode == key_[1])
+        name = f"{key_[0]:2d}{['  ', 'a ', 'b ', 'a*'][key_[1]]}"
+        print(f"  rt={name} jobs {sel.sum():4d} dur mean {np.mean((t1 - t0)[sel]):8.1f} ticks  per-unit {np.mean((t1 - t0)[sel]) / units[sel][0]:6.1f}  start mean {np.mean(t0[sel] - start):9.1f}  end mean {np.mean(t1[sel]):9.1f}")
     ends = {}
     busy = {}
     for k_, a, b in zip(key[ok], t0[ok], t1[ok]):
@@ -84,7 +87,7 @@ try:
     assert lib.bohip_debug_phase_read(pb, C.c_int64(nb * 8 * 4)) == 0
     ph = np.frombuffer(pb, dtype=np.uint64).reshape(nb, 8, 4).astype(np.float64)
     it = ph[:, :, 3]
-    for name, sel in [("first-wave older (rt 20-23)", (rt >= 20)), ("first-wave younger (rt 16-19)", (rt >= 16) & (rt < 20)), ("all", rt >= 0)]:
+    for name, sel in [("first-wave older (rt 20-23)", (rt >= 20)), ("first-wave younger (rt 16-19)", (rt >= 16) & (rt < 20)), ("half jobs", mode > 0), ("all", rt >= 0)]:
         p = ph[sel]
         n = p[:, :, 3].sum()
         a, b, c = p[:, :, 0].sum() / n, p[:, :, 1].sum() / n, p[:, :, 2].sum() / n
