@@ -248,9 +248,10 @@ static int alloc_model(bohip_gp* g, int64_t cap) {
     HIPCHK(hipMalloc(&g->dW, mat));
     HIPCHK(hipMalloc(&g->dWT, mat));
     HIPCHK(hipMalloc(&g->dS, mat));
-    HIPCHK(hipMalloc(&g->dalpha, g->ld * 8));
-    HIPCHK(hipMalloc(&g->dr, g->ld * 8));
-    HIPCHK(hipMalloc(&g->dt, g->ld * 8));
+    // (+256: k_trimv_stream reads its right-hand sides in whole chunks of 256, masked by index)
+    HIPCHK(hipMalloc(&g->dalpha, (g->ld + 256) * 8));
+    HIPCHK(hipMalloc(&g->dr, (g->ld + 256) * 8));
+    HIPCHK(hipMalloc(&g->dt, (g->ld + 256) * 8));
     HIPCHK(hipMalloc(&g->dApp, (size_t)APP_ROWS * g->ld * 8));
     {
         const size_t Tm = (size_t)(g->ld / TILE) + 1;
@@ -324,6 +325,7 @@ static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hip
     return 0;
 }
 
+static int device_cus();
 static int one_time_kernel_setup() {
     // the >64 KB dynamic-LDS opt-in is a per-device function attribute
     static bool done_dev[64] = {false};
@@ -341,6 +343,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_hi, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_quad, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_chol_exec, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_trimv_stream<TRIMV_D>, hipFuncAttributeMaxDynamicSharedMemorySize, trimv_lds_bytes(TRIMV_D)));
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_MIN")) g_chol_df2_min = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_HI")) g_chol_df2_hi = atoi(e);
@@ -1291,15 +1294,11 @@ static int refit_once(bohip_gp* g, double jitter) {
 // out[r][j] = (W rows[r])[j] for r < P <= 32: one launch, workgroups of 8 rows of W x 8 right-hand sides
 static int launch_rows_trimv(bohip_gp* g, const double* W, int64_t N0, const double* rows, int P, double* out, int upper) {
     if (N0 <= 0 || P <= 0) return 0;
-    const int64_t tiles = (N0 + RT_ROWS - 1) / RT_ROWS;
-    if (P == 1) {
-        hipLaunchKernelGGL(k_rows_trimv<1>, dim3((unsigned)(8 * ((tiles + 7) / 8))), dim3(RT_THREADS), 0, g->stream, W, g->ld, N0,
-                           rows, g->ld, P, out, g->ld, upper);
-    } else {
-        const int64_t G = (P + APPEND_CHUNK - 1) / APPEND_CHUNK;
-        hipLaunchKernelGGL(k_rows_trimv<8>, dim3((unsigned)(8 * ((tiles + 7) / 8) * G)), dim3(RT_THREADS), 0, g->stream, W, g->ld,
-                           N0, rows, g->ld, P, out, g->ld, upper);
-    }
+    // one workgroup per CU walks its share of the 8-row blocks of W (k_trimv_stream, kernels_linalg.hip); 16 right-hand sides per pass
+    const int64_t nblk = (N0 + 7) / 8;
+    const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::max(device_cus(), 1), nblk));
+    hipLaunchKernelGGL(k_trimv_stream<TRIMV_D>, dim3(wgs, (unsigned)((P + 15) / 16)), dim3(TRIMV_THREADS), trimv_lds_bytes(TRIMV_D), g->stream,
+                       W, g->ld, N0, rows, g->ld, P, out, g->ld, upper);
     HIPCHK(hipGetLastError());
     return 0;
 }

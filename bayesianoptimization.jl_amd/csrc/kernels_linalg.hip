@@ -863,87 +863,186 @@ __global__ __launch_bounds__(256) void k_cov_rows(const double* __restrict__ X, 
     }
 }
 
-// out[r][j] = sum_{k<=j} W[j][k] * rows[r][k]   for j < N0, r < P  (P <= APPEND_PMAX = SMALL_R).
-// One workgroup: 8 rows of W against 8 right-hand sides: 256 threads stride k (coalesced), 8 x 8
-// running sums each, so a W element is loaded once per 8 right-hand sides and a right-hand-side element once per 8
-// rows (one workgroup per row re-read every right-hand side N times: L2-bound at ~1.5 TB/s of W).  Reduction in a
-// fixed order -- lane-strided partial sums, recursive halving over the wave (63 shuffles for the 64 sums; lane l ends
-// up with sum number l), then the four waves in index order -- so a result is bit-identical whatever else is in the
-// batch (reference property test/acquisitionfunctions.jl:8-11: batch == single).
-// upper != 0: W is an UPPER-triangular K-major matrix (rows of W'), the sum runs over k in [j, N0) instead:
-//     out[r][j] = sum_{k>=j} W'[j][k] * rows[r][k]  ( = (rows W)[r][j] for the lower-triangular W ).
-constexpr int RT_ROWS = 8;
-constexpr int RT_THREADS = 256;   // 512 measured slower (31 -> 39 us at N=3000, R=10)
-template <int PV>   // right-hand sides per workgroup: 8, or 1 (single right-hand side: alpha, mean_var(model, x::Vector),
-                    // one-point appends): 8 running sums instead of 64 leave room to keep four k-steps of loads in flight.
-                    // Both forms add a (row, right-hand side) pair in exactly the same order -> bit-identical results.
-__global__ __launch_bounds__(RT_THREADS) void k_rows_trimv(const double* __restrict__ W, int64_t ld, int64_t N0,
-                                                    const double* __restrict__ rows, int64_t ldr, int P_total,
-                                                    double* __restrict__ out, int64_t ldo, int upper) {
-    __shared__ double red[RT_THREADS / 64][RT_ROWS * PV];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // block b runs on XCD b % 8; the G = ceil(P_total / PV) workgroups that share a row tile of W are consecutive on
-    // ONE XCD, so W comes from HBM once and the other G - 1 reads hit that XCD's L2
-    const int G = (P_total + PV - 1) / PV;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    // longest rows first: the row of W that needs k in [0, j] (lower) or [j, N0) (upper) costs its length
-    const int64_t tiles = (N0 + RT_ROWS - 1) / RT_ROWS;
-    const int64_t tsel = (int64_t)(idx / G) * 8 + xcd;
-    const int64_t j0 = (upper ? tsel : tiles - 1 - tsel) * RT_ROWS;
-    const int r0 = (idx % G) * PV;
-    const int P = min(PV, P_total - r0);
-    if (j0 < 0 || j0 >= N0 || P <= 0) return;
-    rows += (int64_t)r0 * ldr;
-    out += (int64_t)r0 * ldo;
-    double a[RT_ROWS * PV];   // a[PV i + r]: row j0 + i, right-hand side r
-#pragma unroll
-    for (int t = 0; t < RT_ROWS * PV; ++t) a[t] = 0.0;
-    const int64_t k_lo = upper ? j0 : 0, k_hi = upper ? N0 : min(N0, j0 + RT_ROWS);
-    constexpr int UNROLL_K = PV == 1 ? 4 : 2;
-#pragma unroll UNROLL_K
-    for (int64_t k = k_lo + threadIdx.x; k < k_hi; k += RT_THREADS) {
-        double w[RT_ROWS], v[PV];
-#pragma unroll
-        for (int i = 0; i < RT_ROWS; ++i) {
-            const int64_t j = j0 + i;
-            const bool valid = j < N0 && (upper ? k >= j : k <= j);
-            w[i] = valid ? W[j * ld + k] : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < PV; ++r) v[r] = r < P ? rows[r * ldr + k] : 0.0;
-#pragma unroll
-        for (int i = 0; i < RT_ROWS; ++i)
-#pragma unroll
-            for (int r = 0; r < PV; ++r) a[PV * i + r] += w[i] * v[r];
+// out[r][j] = sum_{k<=j} W[j][k] * rows[r][k]   for j < N0, r < P        (upper != 0: W is an UPPER-triangular K-major matrix, rows of
+// W', and the sum runs over k in [j, N0):  out[r][j] = sum_{k>=j} W'[j][k] * rows[r][k] = (rows W)[r][j] for the lower-triangular W).
+// The row-wise triangular product of the small-batch path (the reference's default: 10 L-BFGS restarts per acquire_max, V' = K*' W'
+// and U' = V' W per evaluation), of alpha = W'(W(y - beta)) and of the incremental append.  STREAMING form (round 4): the product
+// is one pass over 8 N^2 / 2 bytes of W and nothing else, yet the round-3 kernel (one workgroup per 8 rows x 8 right-hand sides,
+// k-strided loads into 64 running sums per thread, 205 VGPRs) took 24 us for 36 MB at N = 3000 with ten right-hand sides: two
+// groups of right-hand sides = two passes, and every workgroup a chain of dependent load -> use round trips
+// (tools/ubench_trimv.hip; a plain read of the same 36 MB takes 5.5 us, tools/ubench_readbw.hip).  Here:
+//   * ONE workgroup per CU (512 threads = 8 waves = 2 contraction halves x 4 groups of 4 right-hand sides) walks a list of 8-row
+//     blocks of W, the blocks dealt out in a snake over the cost-sorted list so that every workgroup streams about the same bytes;
+//   * a block is consumed in chunks of 256 contraction indices; a chunk's 8 x 256 tile of W and 16 x 256 tile of right-hand sides
+//     arrive by LDS-DMA into a ring of D + 1 slots, D steps ahead of their use: every step is exactly six 1-KiB pieces per wave
+//     (two for a wave whose right-hand sides do not exist), so the counted s_waitcnt vmcnt(6 (D - 1)) is exact, nothing asynchronous
+//     lands in a register, and the fragment reads are inline asm (hipcc would answer them with vmcnt(0), see gemm_core.h);
+//   * up to 16 right-hand sides ride on ONE pass over W (blockIdx.y: further groups of 16).
+// Measured (N = 3000, lower / upper): 10 right-hand sides 15.6 / 16.7 us against 24.1 / 22.9; 8: 13.0 / 14.4 against 17.4 / 16.7;
+// 1: 12.0 / 13.4 against 13.0 / 12.7; N = 10^4, 10 right-hand sides: 104 / 111 against 142 / 137 (profiles/r04_ubench_trimv.txt).
+// Summation order of one (row, right-hand side) pair: lane l of contraction half h adds its two products of every chunk in chunk
+// order; the 64 lanes are combined by recursive halving (lane bit 5 first), then half 0 + half 1 -- fixed whatever else is in the
+// batch and whichever workgroup gets the block (reference property test/acquisitionfunctions.jl:8-11: batch == single, bit for bit).
+// Needs: ld even, W / rows 16-byte aligned, and readable memory up to the next multiple of 256 columns behind N0 in every row read
+// (the buffers are sized for it: a row's overshoot is the start of the next row; the values are masked by index, not by zeroes).
+constexpr int TRIMV_THREADS = 512, TRIMV_D = 2;
+constexpr int trimv_lds_bytes(int D) { return ((D + 1) * 24 * 256 + 8 * 32) * 8; }
+struct TrimvWalker {   // the (row block, chunk) steps of one workgroup, in order (all fields wave-uniform)
+    int q, c, c_first, c_last, G, w, upper, nblk, N0, j0, RB;
+    bool valid;
+    __device__ __forceinline__ void load() {
+        const int pos = q * G + ((q & 1) ? G - 1 - w : w);
+        valid = pos < nblk;
+        if (!valid) return;
+        const int b = upper ? pos : nblk - 1 - pos;
+        j0 = b * RB;
+        if (upper) { c_first = j0 >> 8; c_last = (N0 - 1) >> 8; }
+        else { c_first = 0; c_last = min(N0 - 1, j0 + RB - 1) >> 8; }
+        c = c_first;
     }
-    if constexpr (PV == 8) {
-        // recursive halving: after the step with offset o the lane keeps the half of its sums selected by bit o of its id
+    __device__ __forceinline__ void init(int G_, int w_, int upper_, int N0_, int RB_) {
+        G = G_; w = w_; upper = upper_; N0 = N0_; RB = RB_; nblk = (N0_ + RB_ - 1) / RB_; q = 0; load();
+    }
+    __device__ __forceinline__ void advance() { if (!valid) return; if (++c > c_last) { ++q; load(); } }
+};
+// Workgroup = 512 threads = 8 waves = 2 contraction halves (kh) x 4 right-hand-side groups (rg) of 4; row blocks of 8 rows,
+// chunks of 256 contraction indices.  One ring slot = the 8 x 256 tile of W (16 KiB) + the 16 x 256 tile of the right-hand sides
+// (32 KiB), all of it brought by LDS-DMA: every step is exactly SIX 1-KiB pieces per wave (2 of W, 4 of its own right-hand
+// sides), issued D steps ahead, so s_waitcnt vmcnt(6 (D - 1)) is exact and nothing async ever lands in a register.
+template <int D>
+__global__ __launch_bounds__(TRIMV_THREADS) void k_trimv_stream(const double* __restrict__ W, int64_t ld, int64_t N0_,
+                                                   const double* __restrict__ rows, int64_t ldr, int P,
+                                                   double* __restrict__ out, int64_t ldo, int upper) {
+    constexpr int NS = D + 1, WT = 8 * 256, SLOT = 24 * 256, VM = 6;   // doubles per W tile / per ring slot; VMEM instructions per step and wave
+    extern __shared__ __attribute__((aligned(16))) double ring[];   // [NS][8 + 16][256] + red[8][32]
+    double* red = ring + NS * SLOT;
+    const int N0 = (int)N0_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave & 1, rg = wave >> 1;
+    const int r_base = blockIdx.y * 16 + rg * 4;                                        // this wave's four right-hand sides
+    const bool live = r_base < P;            // a wave whose right-hand sides do not exist brings W only (2 pieces per step, not 6)
+    TrimvWalker pw, cw;
+    pw.init(gridDim.x, blockIdx.x, upper, N0, 8);
+    cw.init(gridDim.x, blockIdx.x, upper, N0, 8);
+    const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)ring;
+    const double* rsrc[4];
 #pragma unroll
-        for (int o = 32, n = 64; o >= 1; o >>= 1, n >>= 1) {
-            const bool up = (lane & o) != 0;
+    for (int r = 0; r < 4; ++r) rsrc[r] = rows + (int64_t)min(r_base + r, max(P - 1, 0)) * ldr + kh * 128 + lane * 2;
+    auto issue = [&](const TrimvWalker& x, int slot) {
+        const int row = min(x.j0 + wave, N0 - 1);                   // W: wave w brings row w of the tile (two 1-KiB halves)
+        const double* src = W + (int64_t)row * ld + (x.c << 8) + lane * 2;
+        double* dst = ring + slot * SLOT + wave * 256;
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + 128), (lds_void_ptr)(dst + 128), 16, 0, 0);
+        if (live) {
+            double* rdst = ring + slot * SLOT + WT + (rg * 4) * 256 + kh * 128;   // its own four right-hand sides, its own contraction half
 #pragma unroll
-            for (int t = 0; t < n / 2; ++t) {
-                const double send = up ? a[t] : a[t + n / 2];
-                const double keep = up ? a[t + n / 2] : a[t];
-                a[t] = keep + __shfl_xor(send, o);
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rsrc[r] + (x.c << 8)), (lds_void_ptr)(rdst + r * 256), 16, 0, 0);
+        }
+    };
+    int issued = 0;          // steps issued and not yet consumed
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        if (pw.valid) { issue(pw, u); ++issued; }
+        pw.advance();
+    }
+    double acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.0;
+    int slot = 0;            // ring slot of the consumer's step
+    while (cw.valid) {
+        // step s has landed when only the steps issued after it are outstanding: VM instructions each
+        const int later = issued - 1;
+        if (live) {
+            if (later >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM * (D - 1)) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM * 2) : "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM * 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (later >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+            else if (later == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();          // every wave's pieces of step s are in; every wave is done with step s - 1
+        const uint32_t a = ring_addr + (uint32_t)(slot * SLOT + kh * 128 + lane * 2) * 8u;
+        const uint32_t ar = a + (uint32_t)(WT + rg * 4 * 256) * 8u;
+        d2 wr[8], rcur[4];
+        if (live) { rcur[0] = ds_read128<0>(ar); rcur[1] = ds_read128<2048>(ar); rcur[2] = ds_read128<4096>(ar); rcur[3] = ds_read128<6144>(ar); }
+        else { rcur[0] = rcur[1] = rcur[2] = rcur[3] = d2{0.0, 0.0}; }
+        wr[0] = ds_read128<0>(a); wr[1] = ds_read128<2048>(a); wr[2] = ds_read128<4096>(a); wr[3] = ds_read128<6144>(a);
+        wr[4] = ds_read128<8192>(a); wr[5] = ds_read128<10240>(a); wr[6] = ds_read128<12288>(a); wr[7] = ds_read128<14336>(a);
+        const int cj0 = cw.j0, cc = cw.c, c_first = cw.c_first, c_last = cw.c_last;
+        // the slot of step s - 1 is free now (everybody passed the barrier): issue step s + D into it
+        --issued;
+        if (pw.valid) { issue(pw, slot == 0 ? NS - 1 : slot - 1); ++issued; }
+        pw.advance();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(wr[4]), "+v"(wr[5]), "+v"(wr[6]), "+v"(wr[7]),
+                                              "+v"(rcur[0]), "+v"(rcur[1]), "+v"(rcur[2]), "+v"(rcur[3]));
+        const int k = (cc << 8) + kh * 128 + lane * 2;
+        const bool edge = upper ? (cc == c_first || cc == c_last) : cc == c_last;   // wave-uniform: chunks that need the triangle / N0 mask
+        if (edge && live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k >= N0) rcur[r].x = 0.0;
+                if (k + 1 >= N0) rcur[r].y = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int j = cj0 + i;
+                const bool okx = k < N0 && (upper ? k >= j : k <= j), oky = k + 1 < N0 && (upper ? k + 1 >= j : k + 1 <= j);
+                if (!okx) wr[i].x = 0.0;
+                if (!oky) wr[i].y = 0.0;
             }
         }
-        red[wave][lane] = a[0];
-    } else {
-        // the same pairing tree as the halving above, as a plain butterfly on the 8 sums
+        if (live) {
 #pragma unroll
-        for (int t = 0; t < RT_ROWS; ++t) {
-            double x = a[t];
-            for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
-            if (lane == 0) red[wave][t] = x;
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[i][r] += wr[i].x * rcur[r].x;
+                acc[i][r] += wr[i].y * rcur[r].y;
+            }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < RT_ROWS * PV) {
-        const int i = threadIdx.x / PV, r = threadIdx.x % PV;
-        const int t = threadIdx.x;
-        const double sum = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-        if (r < P && j0 + i < N0) out[(int64_t)r * ldo + j0 + i] = sum;
+        slot = slot == NS - 1 ? 0 : slot + 1;
+        const bool block_ends = cc == c_last;
+        cw.advance();
+        if (block_ends) {
+            // 32 sums per lane -> after five halving levels every lane pair holds one; sum id = lane bits 5..1
+            double a32[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) a32[t] = acc[t >> 2][t & 3];
+#pragma unroll
+            for (int o = 32, n = 32; o >= 2; o >>= 1, n >>= 1) {
+                const bool up = (lane & o) != 0;
+#pragma unroll
+                for (int t = 0; t < n / 2; ++t) {
+                    const double send = up ? a32[t] : a32[t + n / 2];
+                    const double keep = up ? a32[t + n / 2] : a32[t];
+                    a32[t] = keep + __shfl_xor(send, o);
+                }
+            }
+            double v = a32[0];
+            v += __shfl_xor(v, 1);
+            const int id = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+            if ((lane & 1) == 0) red[(kh * 4 + rg) * 32 + id] = v;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 128) {      // 8 rows x 16 right-hand sides: contraction half 0 + half 1
+                const int g = tid >> 5, id2 = tid & 31, i = id2 >> 2, r = id2 & 3;
+                const int rr = blockIdx.y * 16 + g * 4 + r;
+                const double sum = red[g * 32 + id2] + red[(4 + g) * 32 + id2];
+                if (rr < P && cj0 + i < N0) out[(int64_t)rr * ldo + cj0 + i] = sum;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] = 0.0;
+            // (red is rewritten only at the NEXT block's end, behind at least one step barrier that waves 0-1 reach after their reads)
+        }
     }
 }
 
