@@ -30,6 +30,7 @@
 #include <limits>
 #include <string>
 #include <vector>
+#include <queue>
 
 using namespace bohip;
 
@@ -312,6 +313,7 @@ static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind th
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
 static int g_chol_exec_urgent = 32; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
+static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue in earliest-deadline order from a host-side simulation (round-4 experiment: same total, see exec_task_list)
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
 static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
@@ -365,6 +367,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_INV_G")) g_chol_inv_g = std::min(64, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_BULK_EDF")) g_chol_exec_bulk_edf = atoi(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_HALVE")) {   // "lo,hi": row tiles lo <= rt < hi go as two 64-row halves ("0,0": none)
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= a) { g_halve_lo = a; g_halve_hi = b; }
@@ -873,11 +876,105 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
         early(kp + 6, kp + 6);
         for (int i = kp + 6; i < T; ++i) early(i, kp + 3);
     }
-    for (int m = 0; 4 * m + 8 <= T - 1; ++m)
-        for (int c = 4 * m + 8; c < T; ++c)
-            for (int i = c; i < T; ++i)
-                add(EX_QBULK, Sp(i, 4 * m), Sp(c, 4 * m), Ap(i, c), nullptr, 4 * CPB, 4 * CPB, i == c, 1,
-                    {{sver(i, 4 * m + 3), 16u}, {sver(c, 4 * m + 3), 16u}, {ver(i, c), 16u * (unsigned)m}}, ver(i, c), EX_NONE);
+    auto add_bulk = [&](int m, int c, int i) {
+        add(EX_QBULK, Sp(i, 4 * m), Sp(c, 4 * m), Ap(i, c), nullptr, 4 * CPB, 4 * CPB, i == c, 1,
+            {{sver(i, 4 * m + 3), 16u}, {sver(c, 4 * m + 3), 16u}, {ver(i, c), 16u * (unsigned)m}}, ver(i, c), EX_NONE);
+    };
+    if (!g_chol_exec_bulk_edf) {
+        // round 3: group after group, column-major inside a group
+        for (int m = 0; 4 * m + 8 <= T - 1; ++m)
+            for (int c = 4 * m + 8; c < T; ++c)
+                for (int i = c; i < T; ++i) add_bulk(m, c, i);
+    } else {
+        // Round-4 experiment (BOHIP_CHOL_EXEC_BULK_EDF=1, off by default): the bulk queue in EARLIEST-DEADLINE order.  A workgroup
+        // claims from a queue only when its HEAD is runnable, and group after group the head of group m -- the four columns the pivot
+        // chain reaches within the next blocks -- sits behind the far columns of group m-1, which nobody needs for another 50 blocks;
+        // the round-3 trace at N = 10^4 shows the chain stalling for up to 0.8 ms at group boundaries (gap between pivots: mean 64 us,
+        // median 18).  The deadline of a bulk tile is its COLUMN (the chain needs column c complete when it gets there), its release
+        // the moment its group's panels are solved.  The order here is produced by simulating the factorisation on the host: a chain
+        // that needs `period` per block and waits for its next column, `workers` workgroups that each take the released tile of the
+        // smallest column (rounds on one tile in group order), a group released `lag` behind its fourth pivot.  The counters the
+        // records wait for are the same, so any order is CORRECT (tests/test_exec_tasks.py replays this list too).
+        // MEASURED (profiles/r04_exec_bulk_edf.txt): the chain then advances evenly -- 3.3 blocks per 500 us from start to end, no stall
+        // above 100 us -- and the factorisation takes exactly as long: 9.75-9.83 ms against 9.80-9.86 at N = 10^4, 15.3 against 14.9 at
+        // N = 12000.  The executor is THROUGHPUT-bound, not order-bound: 350 of its 476 workgroups are busy whatever the order (bulk
+        // tasks lose 9 us of look + claim per 61 us of work, the row steps 45 us of waiting per 37 us), and an evenly paced chain only
+        // moves the idle time from the group boundaries to every block.
+        const int NG = std::max(0, (T - 1 - 8) / 4 + 1);
+        const double period = 76.0, lag = 90.0, tile_us = 125.0, col_lag = 140.0;   // us: pivot block; pivot -> S rows solved; one tile (two records); last bulk tile of a column -> its pivot can start
+        const int workers = 400;
+        struct Tile { int c, m, i; };
+        auto later = [](const Tile& a, const Tile& b) { return a.c != b.c ? a.c > b.c : (a.m != b.m ? a.m > b.m : a.i > b.i); };
+        std::priority_queue<Tile, std::vector<Tile>, decltype(later)> ready(later);
+        std::vector<int> left_in_col(T, 0);                 // bulk tiles of column c not yet finished
+        std::vector<double> col_done(T, 0.0), pivot_end(T, 0.0);
+        for (int m = 0; m < NG; ++m)
+            for (int c = 4 * m + 8; c < T; ++c) left_in_col[c] += T - c;
+        // (i, c) -> finish time of its last round, next round to run
+        std::vector<int> next_m((size_t)T * T, 0);
+        struct Run { double end; Tile t; };
+        auto run_later = [](const Run& a, const Run& b) { return a.end > b.end; };
+        std::priority_queue<Run, std::vector<Run>, decltype(run_later)> running(run_later);
+        int released = 0, pivots = 0;          // groups released, pivot blocks finished
+        double now = 0.0;
+        size_t emitted = 0, total = 0;
+        for (int c = 8; c < T; ++c) total += (size_t)left_in_col[c];
+        auto pivot_ready_at = [&](int k) {     // when can pivot block k start?  its column must be complete
+            double t = k == 0 ? 0.0 : pivot_end[k - 1];
+            if (k >= 8 && left_in_col[k] > 0) return 1e300;
+            if (k >= 8) t = std::max(t, col_done[k] + col_lag);
+            return t;
+        };
+        std::vector<char> busy((size_t)T * T, 0);   // a round of this tile is running
+        while (emitted < total) {
+            // advance the chain as far as it can go at `now`
+            while (pivots < T) {
+                const double st = pivot_ready_at(pivots);
+                if (st + period > now) break;
+                pivot_end[pivots] = st + period;
+                ++pivots;
+            }
+            // release the groups whose fourth pivot is `lag` old: the tiles whose earlier rounds are all done become ready now, the
+            // others when their running (or still queued) round finishes
+            while (released < NG && 4 * released + 3 < pivots && pivot_end[4 * released + 3] + lag <= now) {
+                const int m = released++;
+                for (int c = 4 * m + 8; c < T; ++c)
+                    for (int i = c; i < T; ++i)
+                        if (next_m[(size_t)i * T + c] == m && !busy[(size_t)i * T + c]) ready.push(Tile{c, m, i});
+            }
+            // start work on free workers, smallest column first
+            while ((int)running.size() < workers && !ready.empty()) {
+                const Tile t = ready.top(); ready.pop();
+                add_bulk(t.m, t.c, t.i);
+                ++emitted;
+                next_m[(size_t)t.i * T + t.c] = t.m + 1;
+                busy[(size_t)t.i * T + t.c] = 1;
+                running.push(Run{now + tile_us, t});
+            }
+            // next event: a tile finishes, a pivot ends, a group is released
+            double nxt = 1e300;
+            if (!running.empty()) nxt = std::min(nxt, running.top().end);
+            if (pivots < T) { const double st = pivot_ready_at(pivots); if (st < 1e299) nxt = std::min(nxt, st + period); }
+            if (released < NG && 4 * released + 3 < pivots) nxt = std::min(nxt, pivot_end[4 * released + 3] + lag);
+            if (nxt >= 1e299) break;       // (cannot happen: something is always in flight until everything is emitted)
+            now = std::max(now, nxt);
+            while (!running.empty() && running.top().end <= now) {
+                const Tile t = running.top().t;
+                const double e = running.top().end;
+                running.pop();
+                busy[(size_t)t.i * T + t.c] = 0;
+                if (--left_in_col[t.c] == 0) col_done[t.c] = e;
+                // the tile's next round, if its group is out already
+                if (t.m + 1 < released && 4 * (t.m + 1) + 8 <= t.c) ready.push(Tile{t.c, t.m + 1, t.i});
+            }
+        }
+        // safety net: whatever the simulation did not emit (it always emits everything; a change of the model must not lose tiles)
+        if (emitted < total)
+            for (int m = 0; m < NG; ++m)
+                for (int c = 4 * m + 8; c < T; ++c)
+                    for (int i = c; i < T; ++i)
+                        if (next_m[(size_t)i * T + c] <= m) { add_bulk(m, c, i); next_m[(size_t)i * T + c] = m + 1; }
+    }
     // Queues 3 (EX_QROWS) and 5 (EX_QWAVE): W = L^-1 behind the chain (inv_g > 0: blocks per piece of the long contraction = chunk size G).
     //   Z(i, j) = -sum_{k=j}^{i-1} L(i, k) W(k, j)   accumulated in place at W(i, j), in k order, from three kinds of pieces:
     //       wave m     chunk m = blocks [G m, G (m+1)), pushed to EVERY row i >= G (m+1) + 1 as soon as the chunk's rows of W are
