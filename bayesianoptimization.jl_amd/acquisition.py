@@ -223,6 +223,88 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
     return best_f, best_X
 
 
+def _batched_direct_l(f_batch, lb, ub, maxeval, stopval=math.inf):
+    """DIviding RECTangles, locally biased (Gablonsky & Kelley 2001) -- the role of NLopt's :GN_DIRECT_L, which the reference uses
+    by default for ThompsonSamplingSimple (src/acquisition.jl:7-9: restarts = 1, maxeval = 2000) -- for MAXIMISATION, with ALL the
+    new points of one iteration evaluated in ONE device call: f_batch(X[d, n]) -> f[n].
+    The rules are those of NLopt's cdirect.c for this algorithm (its `which_alg = 13`): a rectangle's size is its longest side, the
+    potentially optimal set is the upper convex hull of (size, best value of that size) from the incumbent's size up with ONE
+    rectangle per size (Jones' epsilon = 0), a cube is trisected along every side -- best sampled value first, so the best points
+    end up in the largest boxes -- and any other rectangle along its first longest side only.  What is NOT reproduced is NLopt's
+    evaluation ORDER inside an iteration (irrelevant for a deterministic objective, a different random stream for a sampled one).
+    Returns (best value, best point, evaluations)."""
+    lb = np.asarray(lb, float); ub = np.asarray(ub, float)
+    d = lb.size
+    span = ub - lb
+    to_x = lambda U: lb[:, None] + span[:, None] * U              # noqa: E731  unit cube -> box, columns are points
+    C = np.full((d, 1), 0.5)                                      # centres (unit cube)
+    Lv = np.zeros((d, 1), dtype=np.int64)                         # level per side: side length 3^-level
+    F = np.asarray(f_batch(to_x(C)), float).reshape(-1)
+    F = np.where(np.isnan(F), -math.inf, F)
+    evals = 1
+    while evals < maxeval and not (F.max() >= stopval):
+        size = Lv.min(axis=0)                                     # key of the longest side (smaller = larger rectangle)
+        keys = np.unique(size)
+        best_of = {}
+        for k in keys:                                            # one rectangle per size: the best, first on ties
+            idx = np.flatnonzero(size == k)
+            best_of[int(k)] = int(idx[np.argmax(F[idx])])
+        jmax = int(np.argmax(F))
+        # upper hull over (diameter, f) from the incumbent's size towards the larger rectangles
+        cand = sorted((k for k in best_of if k <= size[jmax]), reverse=True)          # increasing diameter
+        hull = []
+        for k in cand:
+            pt = (3.0 ** (-k), F[best_of[k]], best_of[k])
+            while len(hull) >= 2:
+                (x1, y1, _), (x2, y2, _) = hull[-2], hull[-1]
+                if (y2 - y1) * (pt[0] - x1) <= (pt[1] - y1) * (x2 - x1):             # the middle point is not above the chord
+                    hull.pop()
+                else:
+                    break
+            hull.append(pt)
+        chosen = [j for _, _, j in hull]                          # (the first one is the incumbent's own size class)
+        # new points of this iteration (capped by the evaluation budget)
+        plan, cols = [], []
+        for j in chosen:
+            lv = Lv[:, j]
+            kmin = lv.min()
+            longest = np.flatnonzero(lv == kmin)
+            dims = longest if longest.size == d else longest[:1]   # a cube: every side; otherwise the first longest side
+            if evals + len(cols) + 2 * len(dims) > maxeval:
+                dims = dims[: max(0, (maxeval - evals - len(cols)) // 2)]
+            if len(dims) == 0:
+                continue
+            delta = 3.0 ** (-(kmin + 1))
+            start = len(cols)
+            for i in dims:
+                for sgn in (+1.0, -1.0):
+                    c = C[:, j].copy(); c[i] += sgn * delta
+                    cols.append(c)
+            plan.append((j, dims, start))
+        if not cols:
+            break
+        Unew = np.array(cols).T
+        Fnew = np.asarray(f_batch(to_x(Unew)), float).reshape(-1)
+        Fnew = np.where(np.isnan(Fnew), -math.inf, Fnew)
+        evals += Fnew.size
+        newL = np.empty((d, Fnew.size), dtype=np.int64)
+        for j, dims, start in plan:
+            w = np.array([max(Fnew[start + 2 * t], Fnew[start + 2 * t + 1]) for t in range(len(dims))])
+            order = np.argsort(-w, kind="stable")                 # best sampled value first
+            lv = Lv[:, j].copy()
+            for t in order:
+                i = dims[t]
+                lv[i] += 1                                        # the parent shrinks along i; the two children inherit the levels so far
+                newL[:, start + 2 * t] = lv
+                newL[:, start + 2 * t + 1] = lv
+            Lv[:, j] = lv
+        C = np.concatenate([C, Unew], axis=1)
+        Lv = np.concatenate([Lv, newL], axis=1)
+        F = np.concatenate([F, Fnew])
+    jb = int(np.argmax(F))
+    return float(F[jb]), to_x(C[:, jb:jb + 1])[:, 0], evals
+
+
 # NLopt.Opt properties the reference forwards with setproperty! (src/acquisition.jl:24-27).  The device ascent
 # implements the first group; the second is accepted by NLopt but has no counterpart here (a warning says so);
 # anything else raises, as setproperty! on an NLopt.Opt does.
@@ -261,6 +343,29 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None, setparams
     if model.nobs == 0 or restarts <= 0:
         return maxf, maxx
     derivative = len(method) > 1 and method[1] == "D" and not isinstance(a, ThompsonSamplingSimple)   # :31
+    if "DIRECT" in method.upper() and not derivative:
+        # :GN_DIRECT_L (the reference's default for ThompsonSamplingSimple, src/acquisition.jl:7-9) and its siblings: dividing
+        # rectangles with every iteration's new points in one device call.  DIRECT ignores the start point, so `restarts` runs are
+        # `restarts` repetitions (identical for a deterministic acquisition, fresh draws for a sampled one), as with NLopt.
+        sval = float(opts.get("stopval", math.inf))
+        if isinstance(a, ThompsonSamplingSimple):
+            gen = rng or np.random.default_rng()
+
+            def f_batch(X):                                       # x -> myrand(model, x), one draw per point (src/acquisitionfunctions.jl:108)
+                mu, var = model.predict_f(X)
+                return np.asarray(mu) + np.sqrt(np.maximum(np.asarray(var), 0.0)) * gen.standard_normal(np.size(mu))
+        else:
+            def f_batch(X):
+                return model.score(a.acq_id, a.params(), X)[0]
+        for _ in range(restarts):
+            f, x, _ = _batched_direct_l(f_batch, lb, ub, max(1, maxeval), sval)
+            if f > maxf:                                          # :62 strict '>'
+                maxf, maxx = f, x
+            if not isinstance(a, ThompsonSamplingSimple):
+                break                                             # deterministic objective: every repetition is the same run
+        if not np.isfinite(maxf):
+            warnings.warn("acquisition returned no finite value; keeping the lower bounds as maximiser")
+        return maxf, maxx
     if isinstance(a, ThompsonSamplingSimple):
         # one joint draw of the posterior at `maxeval` candidates per restart, arg-max on the device
         n = max(maxeval, 1)

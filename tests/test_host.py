@@ -185,7 +185,14 @@ def test_acquire_max_gradient_free_and_bounds(orc):
     ei = bohip.ExpectedImprovement()
     f0, x0 = bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="GN_DIRECT_L", restarts=1, maxeval=500), np.random.default_rng(1))
     assert ei.tau == y.max()                                            # setparams! ran (src/acquisition.jl:30)
-    assert m.calls[-1] == ("score", 500)                                # derivative-free: maxeval candidates in ONE batch
+    # :GN_DIRECT_L (the reference's default for ThompsonSamplingSimple, src/acquisition.jl:7-9): dividing rectangles, every iteration's
+    # new points in one batch -- never more than maxeval evaluations in total, the first one the centre of the box
+    n_direct = [c[1] for c in m.calls]
+    assert all(c[0] == "score" for c in m.calls) and n_direct[0] == 1 and 2 < len(n_direct) < 120 and 400 < sum(n_direct) <= 500
+    m.calls.clear()
+    fl, xl = bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="LN_COBYLA", restarts=1, maxeval=500), np.random.default_rng(1))
+    assert m.calls[-1] == ("score", 500)                                # other derivative-free methods: maxeval Latin-hypercube candidates in ONE batch
+    assert f0 >= fl * 0.999                                             # 500 evaluations placed by DIRECT-L beat 500 scattered ones here
     f1, x1 = bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="LD_LBFGS", restarts=16, maxeval=60), np.random.default_rng(1))
     assert f1 >= f0 * 0.999                                             # ascent from 16 starts is at least as good as 500 samples
     assert np.all(x1 >= -1) and np.all(x1 <= 1)
@@ -193,6 +200,49 @@ def test_acquire_max_gradient_free_and_bounds(orc):
     f2, x2 = bohip.acquire_max(bohip.MaxMean(), m, [0.6, 0.6], [1.0, 1.0], dict(method="LD_LBFGS", restarts=4, maxeval=60),
                                np.random.default_rng(2))
     assert x2 == pytest.approx([0.6, 0.6], abs=1e-6)
+
+
+def test_direct_l_finds_the_known_maxima():
+    """The dividing-rectangles search on closed-form objectives: Branin's minimum (the reference's test function, test/branin.jl:1-7)
+    to 1e-6 within the reference's default budget of 2000 evaluations, the box respected, the budget never exceeded, NaN never wins,
+    stopval honoured."""
+    from bohip.acquisition import _batched_direct_l
+
+    def neg_branin(X):
+        x1, x2 = X
+        return -((x2 - 5.1 / (4 * math.pi ** 2) * x1 ** 2 + 5 / math.pi * x1 - 6) ** 2 + 10 * (1 - 1 / (8 * math.pi)) * np.cos(x1) + 10)
+
+    sizes = []
+    f, x, ev = _batched_direct_l(lambda X: (sizes.append(X.shape[1]), neg_branin(X))[1], [-5.0, 0.0], [10.0, 15.0], 2000)
+    assert f == pytest.approx(-0.397887, abs=1e-5) and ev <= 2000 and sum(sizes) == ev and len(sizes) < 150
+    assert min(np.hypot(*(x - m_)) for m_ in ([-math.pi, 12.275], [math.pi, 2.275], [9.42478, 2.475])) < 1e-2
+    for d in (1, 4):
+        f, x, ev = _batched_direct_l(lambda X: -np.sum((X - 0.37) ** 2, axis=0), [-1.0] * d, [2.0] * d, 600)
+        assert f > -1e-4 and np.all(x >= -1) and np.all(x <= 2) and ev <= 600
+    f, x, ev = _batched_direct_l(lambda X: np.where(X[0] > 0.9, np.nan, X[0]), [0.0], [1.0], 100)
+    assert np.isfinite(f) and x[0] <= 0.9
+    f, x, ev = _batched_direct_l(lambda X: -np.sum(X ** 2, axis=0), [-1.0, -1.0], [1.0, 1.0], 2000, stopval=-0.5)
+    assert ev == 1                                                      # the centre already reaches stopval
+    f, x, ev = _batched_direct_l(lambda X: -np.sum(X ** 2, axis=0), [-1.0, -1.0], [1.0, 1.0], 7)
+    assert ev <= 7
+
+
+def test_thompson_default_options_run_direct_l_on_posterior_draws(orc):
+    """ThompsonSamplingSimple with the reference's defaultoptions (:GN_DIRECT_L, restarts = 1, maxeval = 2000): x -> myrand(model, x)
+    is a fresh posterior draw per evaluation (src/acquisitionfunctions.jl:108, src/models/gp.jl:6); the search never asks for more than
+    maxeval of them and lands near the posterior's high region."""
+    rng = np.random.default_rng(4)
+    X = rng.random((40, 2)) * 2 - 1
+    y = -((X - 0.3) ** 2).sum(1)
+    m = OracleModel(orc, X, y, [-0.5, -0.5], 0.0, -3.0, float(y.mean()))
+    asked = []
+    pf = m.predict_f
+    m.predict_f = lambda xs: (asked.append(np.asarray(xs).reshape(2, -1).shape[1]), pf(xs))[1]
+    opts = bohip.defaultoptions(bohip.ElasticGPE, bohip.ThompsonSamplingSimple)
+    f, x = bohip.acquire_max(bohip.ThompsonSamplingSimple(), m, [-1, -1], [1, 1], opts, np.random.default_rng(3))
+    assert sum(asked) <= 2000 and len(asked) > 3 and np.all(np.abs(x) <= 1)
+    mu_x, _ = pf(x.reshape(2, 1))
+    assert mu_x[0] > np.quantile(y, 0.75)                               # a draw-maximiser sits where the posterior mean is high
 
 
 def test_acquire_max_empty_model_returns_reference_initial_state():
