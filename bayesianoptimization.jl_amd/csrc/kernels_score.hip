@@ -647,11 +647,17 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
             if (lane == 0) { red[wave][2 * k] = a; red[wave][2 * k + 1] = b; }
         }
     __syncthreads();
+    // q = sum_j V'[r][j]^2 in k_small_finish's exact order: ONE workgroup adds it -- the only one, or split 0, which does so BEFORE it
+    // counts itself in (round 3 left it to the last arriver: a pass over the row + a tree BEHIND the counter, ~4 us of the critical path)
+    double q_all = 0.0;
+    __shared__ double redq[256];
+    if (vq && (S == 1 || sp == 0)) q_all = sumsq_like_small_finish(vq, N, redq);
     if (S > 1) {
         double* mine = parts + ((int64_t)blockIdx.x * S + sp) * PS;
         if (threadIdx.x < 2 * d)
             __hip_atomic_store(mine + threadIdx.x, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (vq && sp == 0 && threadIdx.x == 0) __hip_atomic_store(mine + 2 * DT, q_all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (agent-scope stores + this wait, not __threadfence(): see k_small_finish)
         __syncthreads();
@@ -659,11 +665,7 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
         __syncthreads();
         if (!is_last) return;
         if (threadIdx.x == 0) counters[blockIdx.x] = 0u;
-    }
-    double q_all = 0.0;
-    if (vq) {
-        __shared__ double redq[256];
-        q_all = sumsq_like_small_finish(vq, N, redq);
+        if (vq) q_all = __hip_atomic_load(parts + (int64_t)blockIdx.x * S * PS + 2 * DT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x < d) {
         const int k = threadIdx.x;
