@@ -1827,9 +1827,9 @@ static int launch_grad_any(bohip_gp* g, const double* dXs, int64_t r0, int64_t r
                            double* d_grad, const double* UT, const GradQ& gq = GradQ{}) {
     // small batches: split the observations over S workgroups per candidate (see k_grad_finish)
     int S = 1;
-    // one 256-observation stride per workgroup where 16 splits allow it (N <= 4096): the partial sums are then ONE load -> use round trip
-    // (round 3: N / 768 splits, 4 strides each at N = 3000; 15 -> ~9 us per pass of ten starts)
-    if (r1 - r0 <= SMALL_MAX) S = (int)std::min<int64_t>(16, std::max<int64_t>(1, (g->n + 255) / 256));
+    // (one 256-observation stride per workgroup -- (n + 255) / 256 splits -- was measured in round 4: 2 us of a 58 us pass, and the changed
+    // summation order moved the ascent's end points enough to graze the SciPy check's KKT bound at N = 600: not kept)
+    if (r1 - r0 <= SMALL_MAX) S = (int)std::min<int64_t>(16, std::max<int64_t>(1, g->n / 768));
     if (S > 1) CHK(ensure_small_counters(g));
     if (g->d <= 2) launch_grad<2>(g, dXs, r0, r1, hp, ap, d_grad, UT, S, gq);
     else if (g->d <= 4) launch_grad<4>(g, dXs, r0, r1, hp, ap, d_grad, UT, S, gq);
