@@ -286,7 +286,50 @@ __device__ __forceinline__ void factor16_step(double (&v)[4], int r, int q, doub
     if (q == QJ) v[EJ] = lr;                       // column J is final: L[r][J] for r > J (rows <= J: dead entries)
     if (lane == J + 16 * QJ) { dl[P + J] = ajj * inv; idl[P + J] = inv; }
 }
+#ifndef BOHIP_FACTOR16_SWIZZLE
+#define BOHIP_FACTOR16_SWIZZLE 1   // 1 (default): the 64-lane form above; 0: the 16-lane DPP form below (round-4 experiment, same speed)
+#endif
+// Round 4: the same factorisation with ONE ROW PER LANE on 16 lanes and every broadcast a DPP move (row_newbcast: "lane J of my row of
+// 16 to the whole row", a VALU instruction, gfx90a+) instead of a trip through the LDS crossbar.  The 64-lane form above needs, per pivot,
+// a[r][J] from another 16-lane row (ds_bpermute) and row J's entries in the lane's columns (ds_swizzle): ~120 cycles of LDS-pipe
+// latency on the chain  update -> broadcast -> scale -> update, 16 times per block: 3.3 us per 16 x 16 block, a third of every panel of
+// the pivot chain (profiles/r03_chol_form1_chain_trace_N3000.txt).  With a whole row in the lane, l_r = a[r][J] / L_JJ needs nothing
+// from anybody, and the 15 - J multipliers l_k reach the lanes by DPP (two 32-bit moves each, issued back to back, the one the next
+// pivot needs first).  Same operands, same operations, same order per entry: the factor is bit-identical to the 64-lane form's
+// (tools/chol_ab.py: identical factor and alpha at N = 500 ... 10^4).  MEASURED: no faster -- 3.24 us per 16 x 16 block in the chain's
+// trace either way, refit 1.667 against 1.693 ms at N = 3000 (profiles/r04_factor16_dpp_ab.txt).  The broadcasts were never the chain:
+// a pivot step is readlane/DPP -> v_rsq_f64 -> two Newton steps (eight dependent FP64 operations at ~16 cycles each beside the trailing
+// update's waves on the same SIMDs) -> scale -> update, ~440 cycles whichever way the multipliers travel.  Kept as the alternative form.
+template <int J>
+__device__ __forceinline__ double row_bcast_dpp(double v) {   // value of lane J of this lane's row of 16 (DPP row_newbcast)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int J>
+__device__ __forceinline__ void factor16_row_step(double (&v)[16], int r, double* dl, double* idl, int P, int* info, int row0) {
+    double ajj = row_bcast_dpp<J>(v[J]);                 // the pivot: lane J's diagonal entry
+    if (!(ajj > 0.0)) {
+        if (r == 0) atomicCAS(info, 0, row0 + P + J + 1);
+        ajj = 1.0;
+    }
+    const double inv = fast_rsqrt(ajj);
+    const double lr = v[J] * inv;                          // L[r][J] (rows r > J; row J itself: L_JJ)
+    // the multipliers of the columns right of J, nearest first (the next pivot needs column J + 1 only)
+#define BOHIP_F16_COL(K)                                                     \
+    if constexpr (K > J) {                                                   \
+        const double lk_ = row_bcast_dpp<K>(lr);                             \
+        v[K] -= lr * lk_;                                                    \
+    }
+    BOHIP_F16_COL(1) BOHIP_F16_COL(2) BOHIP_F16_COL(3) BOHIP_F16_COL(4) BOHIP_F16_COL(5) BOHIP_F16_COL(6) BOHIP_F16_COL(7) BOHIP_F16_COL(8)
+    BOHIP_F16_COL(9) BOHIP_F16_COL(10) BOHIP_F16_COL(11) BOHIP_F16_COL(12) BOHIP_F16_COL(13) BOHIP_F16_COL(14) BOHIP_F16_COL(15)
+#undef BOHIP_F16_COL
+    v[J] = lr;                                             // column J is final
+    if (r == J) { dl[P + J] = ajj * inv; idl[P + J] = inv; }
+}
 __device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int P, int lane, int* info, int row0) {
+#if BOHIP_FACTOR16_SWIZZLE
     const int r = lane & 15, q = lane >> 4;
     double v[4];
 #pragma unroll
@@ -307,6 +350,24 @@ __device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int
         const int k = 4 * q + e;
         if (k < r) a[(P + k) * PF_LD + P + r] = v[e];   // mirror
     }
+#else
+    if (lane >= 16) return;                                // (the caller's wave continues after the call: no barrier inside)
+    const int r = lane;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (k <= r) ? a[(P + r) * PF_LD + P + k] : 0.0;   // row r of the lower triangle
+    factor16_row_step<0>(v, r, dl, idl, P, info, row0);   factor16_row_step<1>(v, r, dl, idl, P, info, row0);
+    factor16_row_step<2>(v, r, dl, idl, P, info, row0);   factor16_row_step<3>(v, r, dl, idl, P, info, row0);
+    factor16_row_step<4>(v, r, dl, idl, P, info, row0);   factor16_row_step<5>(v, r, dl, idl, P, info, row0);
+    factor16_row_step<6>(v, r, dl, idl, P, info, row0);   factor16_row_step<7>(v, r, dl, idl, P, info, row0);
+    factor16_row_step<8>(v, r, dl, idl, P, info, row0);   factor16_row_step<9>(v, r, dl, idl, P, info, row0);
+    factor16_row_step<10>(v, r, dl, idl, P, info, row0);  factor16_row_step<11>(v, r, dl, idl, P, info, row0);
+    factor16_row_step<12>(v, r, dl, idl, P, info, row0);  factor16_row_step<13>(v, r, dl, idl, P, info, row0);
+    factor16_row_step<14>(v, r, dl, idl, P, info, row0);  factor16_row_step<15>(v, r, dl, idl, P, info, row0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < r) a[(P + k) * PF_LD + P + r] = v[k];     // finished columns to the mirror position
+#endif
 }
 
 // B0 + B1 of the header above on an image whose strict upper triangle (mirror) holds L and whose idl[] holds 1 / L_ii:
