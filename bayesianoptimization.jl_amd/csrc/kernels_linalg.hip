@@ -179,12 +179,27 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 }
 // 1/sqrt(x) to ~1 ulp: hardware v_rsq_f64 seed + two Newton steps (the libm sqrt + divide pair is a
 // ~150-cycle dependent chain, and this sits on the critical path of every column).
+#ifndef BOHIP_RSQRT_NEWTON2
+#define BOHIP_RSQRT_NEWTON2 1   // 1 (default): two Newton steps; 0: one Halley step (round-4 experiment: same speed, different last bits)
+#endif
 __device__ __forceinline__ double fast_rsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);
+#if BOHIP_RSQRT_NEWTON2
     double h = 0.5 * x;
     y = y * (1.5 - h * y * y);
     y = y * (1.5 - h * y * y);
     return y;
+#else
+    // ONE third-order (Halley) step instead of two Newton steps: v_rsq_f64 is good to ~2^-24, its residual e = 1 - x y^2 cubed is below
+    // 2^-70, and the chain  x y -> e -> (t, y e) -> y + y e t  is four dependent operations instead of eight.  This function sits on the
+    // pivot chain of every 16 x 16 block (factor16_step: 16 times per block, nothing overlaps it).  MEASURED: refit 1.648 against 1.665 ms
+    // at N = 3000, 9.80 against 9.93 at N = 10^4 (profiles/r04_rsqrt_halley_ab.txt): inside the noise -- the depth of this chain is not
+    // what a pivot step waits for either.  Not the default (the factor's last bits would change for nothing).
+    const double xy = x * y;
+    const double e = __builtin_fma(-xy, y, 1.0);
+    const double t = __builtin_fma(0.375, e, 0.5);
+    return __builtin_fma(y * e, t, y);
+#endif
 }
 
 // A3 for a trailing size of NB 16-blocks: cyclic NB x NB register tile per thread (lower half only), FP64 VALU.
