@@ -166,19 +166,26 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
     active = np.isfinite(f)
     best_f, best_X = f.copy(), X.copy()
     while evals < maxeval and active.any():
-        # two-loop recursion, vectorised over columns
-        q = G.copy()
+        # two-loop recursion, vectorised over columns, in the FREE SUBSPACE of every column: a coordinate on a bound with the gradient
+        # pushing outward takes no part (kernels_ascent.hip asc_direction_one: 22-35 passes instead of 228-309 on the headline model,
+        # where UCB peaks in the corners of the box; with no bound active the arithmetic is unchanged)
+        free = ~(((X <= lbc) & (G < 0)) | ((X >= ubc) & (G > 0)))
+        q = np.where(free, G, 0.0)
         al = []
         for s_, y_ in zip(reversed(S), reversed(Y)):
-            rho = 1.0 / np.maximum(np.einsum("dr,dr->r", y_, s_), 1e-300)
+            s_, y_ = np.where(free, s_, 0.0), np.where(free, y_, 0.0)
+            sy = np.einsum("dr,dr->r", y_, s_)
+            rho = np.where(sy > 1e-14, 1.0 / np.where(sy > 1e-14, sy, 1.0), 0.0)     # a pair without curvature in the free subspace is skipped
             a_ = rho * np.einsum("dr,dr->r", s_, q)
             q -= a_ * y_
             al.append((a_, rho))
         if S:
-            sy = np.einsum("dr,dr->r", S[-1], Y[-1])
-            yy = np.maximum(np.einsum("dr,dr->r", Y[-1], Y[-1]), 1e-300)
-            q *= np.where(sy > 0, sy / yy, 1.0)
+            s_, y_ = np.where(free, S[-1], 0.0), np.where(free, Y[-1], 0.0)
+            sy = np.einsum("dr,dr->r", s_, y_)
+            yy = np.maximum(np.einsum("dr,dr->r", y_, y_), 1e-300)
+            q *= np.where(sy > 1e-14, sy / yy, 1.0)
         for (a_, rho), s_, y_ in zip(reversed(al), S, Y):
+            s_, y_ = np.where(free, s_, 0.0), np.where(free, y_, 0.0)
             b_ = rho * np.einsum("dr,dr->r", y_, q)
             q += (a_ - b_) * s_
         D = q                                                     # ascent direction (maximisation: H * grad)
