@@ -2411,10 +2411,24 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     double* dub = dlb + DMAX;
     double* dbx = dub + DMAX;
     const bool use_wg = g_asc_wg_nmax > 0 && g->n <= std::min<int64_t>(g_asc_wg_nmax, AWG_NMAX - 1) && d <= 16 && !g_asc_lockstep;
-    if (!use_wg) {
-        HIPCHK(hipMemcpyAsync(dlb, lb, (size_t)d * 8, hipMemcpyHostToDevice, g->stream));
-        HIPCHK(hipMemcpyAsync(dub, ub, (size_t)d * 8, hipMemcpyHostToDevice, g->stream));
-        HIPCHK(hipMemcpyAsync(g->dXs, starts, (size_t)R * d * 8, hipMemcpyHostToDevice, g->stream));
+    // one pinned block in ([lb | ub | starts]), one pinned block out (k_asc_final's packed result): seven pageable copies were ~0.1 ms
+    // of a call that is 1.3 ms at N = 3000 since the search needs 17 passes instead of 228
+    const size_t n_in = (size_t)(2 + R) * d, n_out = (size_t)2 + d + R + (size_t)R * d + R, n_io = std::max(n_in, n_out);
+    if (n_io > g->asc_io_cap) {
+        if (g->asc_hio) HIPCHK(hipHostFree(g->asc_hio));
+        if (g->asc_dio) HIPCHK(hipFree(g->asc_dio));
+        g->asc_hio = nullptr; g->asc_dio = nullptr; g->asc_io_cap = 0;
+        HIPCHK(hipHostMalloc((void**)&g->asc_hio, n_io * 2 * 8, hipHostMallocDefault));
+        HIPCHK(hipMalloc(&g->asc_dio, n_io * 2 * 8));
+        g->asc_io_cap = n_io * 2;
+    }
+    std::memcpy(g->asc_hio, lb, (size_t)d * 8);
+    std::memcpy(g->asc_hio + d, ub, (size_t)d * 8);
+    std::memcpy(g->asc_hio + 2 * d, starts, (size_t)R * d * 8);
+    HIPCHK(hipMemcpyAsync(g->asc_dio, g->asc_hio, n_in * 8, hipMemcpyHostToDevice, g->stream));
+    if (!use_wg) {   // (the batched kernels read the bounds and the starts where the block landed)
+        dlb = g->asc_dio;
+        dub = g->asc_dio + d;
     }
     double span = INFINITY;
     for (int k = 0; k < d; ++k) span = std::min(span, ub[k] - lb[k] + 1e-300);
@@ -2434,20 +2448,6 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
             if (acq_id != BOHIP_ACQ_MAXMEAN) pw.ap.p0 = acq_params[0];
             if (acq_id == BOHIP_ACQ_MI) pw.ap.p1 = acq_params[1];
         }
-        // one pinned block in ([lb | ub | starts]), one pinned block out (k_asc_final's packed result)
-        const size_t n_in = (size_t)(2 + R) * d, n_out = (size_t)2 + d + R + (size_t)R * d + R, n_io = std::max(n_in, n_out);
-        if (n_io > g->asc_io_cap) {
-            if (g->asc_hio) HIPCHK(hipHostFree(g->asc_hio));
-            if (g->asc_dio) HIPCHK(hipFree(g->asc_dio));
-            g->asc_hio = nullptr; g->asc_dio = nullptr; g->asc_io_cap = 0;
-            HIPCHK(hipHostMalloc((void**)&g->asc_hio, n_io * 2 * 8, hipHostMallocDefault));
-            HIPCHK(hipMalloc(&g->asc_dio, n_io * 2 * 8));
-            g->asc_io_cap = n_io * 2;
-        }
-        std::memcpy(g->asc_hio, lb, (size_t)d * 8);
-        std::memcpy(g->asc_hio + d, ub, (size_t)d * 8);
-        std::memcpy(g->asc_hio + 2 * d, starts, (size_t)R * d * 8);
-        HIPCHK(hipMemcpyAsync(g->asc_dio, g->asc_hio, n_in * 8, hipMemcpyHostToDevice, g->stream));
         pw.beta = g->beta; pw.st = st; pw.starts = g->asc_dio + 2 * d; pw.lb = g->asc_dio; pw.ub = g->asc_dio + d; pw.R = (int)R;
         pw.maxeval = (int)std::min<int64_t>(maxeval, 1 << 30); pw.ftol_rel = ftol_rel; pw.xtol_abs = xtol_abs; pw.first_step_scale = 0.1 * span;
         pw.max_ticks = g->asc_maxtime > 0.0 ? (unsigned long long)(g->asc_maxtime * 1e8) : 0ull;
@@ -2477,7 +2477,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         t_collect(g);
         return 0;
     }
-    hipLaunchKernelGGL(k_asc_start, dim3(nR), dim3(64), 0, g->stream, st, d, g->dXs, dlb, dub);
+    hipLaunchKernelGGL(k_asc_start, dim3(nR), dim3(64), 0, g->stream, st, d, g->asc_dio + 2 * d, dlb, dub);
     CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
     hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d);
     HIPCHK(hipGetLastError());
@@ -2493,7 +2493,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         // FREE-RUNNING form (k_asc_step): pass after pass is enqueued without waiting; the number of start points still active
         // after pass e is read LAG passes later from pinned memory (by then it has long been written: no stall), so at most
         // LAG passes run beyond convergence.  Same per-start-point trajectories as the lock-step form below.
-        const int LAG = 2;
+        const int LAG = 1;   // (2 until round 4: with 17 passes per call instead of 228 a wasted pass is 5 % of it; one queued pass keeps the device fed)
         if (any_active) {
             HIPCHK(hipMemsetAsync(st.it, 0, (size_t)2 * g->asc_cap * sizeof(int), g->stream));   // it, bt
             HIPCHK(hipMemsetAsync(st.nact, 0, (size_t)2 * ASC_RING * sizeof(unsigned), g->stream));
@@ -2547,15 +2547,18 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         ++it;
     }
     }
-    hipLaunchKernelGGL(k_asc_final, dim3(1), dim3(256), 0, g->stream, st, d, (int)R, g->asc_best, dbx);
-    HIPCHK(hipGetLastError());
-    if (f_out) HIPCHK(hipMemcpyAsync(f_out, st.best_f, (size_t)R * 8, hipMemcpyDeviceToHost, g->stream));
-    if (x_out) HIPCHK(hipMemcpyAsync(x_out, st.best_X, (size_t)R * d * 8, hipMemcpyDeviceToHost, g->stream));
-    if (best) HIPCHK(hipMemcpyAsync(best, g->asc_best, sizeof(Best), hipMemcpyDeviceToHost, g->stream));
-    if (best_x) HIPCHK(hipMemcpyAsync(best_x, dbx, (size_t)d * 8, hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
-    if (best && best_x && best->idx < 0)
-        for (int k = 0; k < d; ++k) best_x[k] = lb[k];   // :56  maxx = lowerbounds when nothing beat -Inf
+    {
+        double* dout = g->asc_dio + n_io;   // (second half of the device block: the kernels above read the first)
+        hipLaunchKernelGGL(k_asc_final, dim3(1), dim3(256), 0, g->stream, st, d, (int)R, g->asc_best, dbx, dout, (const int*)nullptr);
+        HIPCHK(hipGetLastError());
+        double* hout = g->asc_hio + n_io;
+        HIPCHK(hipMemcpyAsync(hout, dout, (n_out - R) * 8, hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        if (best) { best->val = hout[0]; best->idx = (long long)hout[1]; }
+        if (best_x) for (int k = 0; k < d; ++k) best_x[k] = hout[1] >= 0.0 ? hout[2 + k] : lb[k];   // :56  maxx = lowerbounds when nothing beat -Inf
+        if (f_out) std::memcpy(f_out, hout + 2 + d, (size_t)R * 8);
+        if (x_out) std::memcpy(x_out, hout + 2 + d + R, (size_t)R * d * 8);
+    }
     if (evals_out) *evals_out = evals;
     t_collect(g);
     return 0;
