@@ -1637,7 +1637,9 @@ static int64_t small_limit(const bohip_gp* g) {
     if (g_small_r >= 0) return g_small_r;
     // measured break-even with the MFMA path: whole-K jobs (N=500: > 256, N=3000: ~190, N=10000: ~110); where the split-K
     // form applies it wins earlier (N=1500: ~150, N=3000: ~95, N=10000: ~55)
-    if (split_applicable(g)) return std::min<int64_t>(SMALL_MAX, 45 + 150000 / std::max<int64_t>(g->n, 1));
+    // (round 4, k_trimv_stream: the row-wise products take 16 right-hand sides per pass over W, so the break-even moves in steps of 16:
+    // N = 1000: ~240, N = 3000: 80, N = 10^4: 32 -- tools/small_limit_sweep.py, profiles/r04_small_limit_sweep.txt)
+    if (split_applicable(g)) return std::min<int64_t>(SMALL_MAX, std::max<int64_t>(16, (20 + 220000 / std::max<int64_t>(g->n, 1)) / 16 * 16));
     return std::min<int64_t>(SMALL_MAX, 90 + 300000 / std::max<int64_t>(g->n, 1));
 }
 // the batch size the path decision is based on (see bohip_gp_set_batch_hint)
