@@ -317,6 +317,7 @@ static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
 static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
+static int64_t g_chunk_rows_forced = 0;   // BOHIP_CHUNK_ROWS: candidates per K*' chunk (tools: chunk-size sweeps), 0 = the rule in chunk_rows
 static int g_halve_lo = -1, g_halve_hi = -1;   // BOHIP_TRIGEMM_HALVE (see trigemm_pieces)
 static int g_ks8 = 1;  // 8-wave k_trigemm_sq (contraction index split inside the workgroup); BOHIP_KS8=0 selects the 4-wave loop
 static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hipStream_t st = nullptr, bool hi = false) {
@@ -368,6 +369,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_BULK_EDF")) g_chol_exec_bulk_edf = atoi(e);
+    if (const char* e = getenv("BOHIP_CHUNK_ROWS")) g_chunk_rows_forced = atoll(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_HALVE")) {   // "lo,hi": row tiles lo <= rt < hi go as two 64-row halves ("0,0": none)
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= a) { g_halve_lo = a; g_halve_hi = b; }
@@ -1445,16 +1447,21 @@ static int ensure_fresh(bohip_gp* g) {
 
 // ---- scoring --------------------------------------------------------------------------------------
 static int64_t chunk_cap(const bohip_gp* g) {
-    // keep the K*' chunk around 128 MB so it stays in the 256 MB Infinity Cache next to W; a multiple of 512 candidates
-    // (8 XCDs x one 64-wide candidate tile: k_trigemm_sq deals candidate tiles to XCDs round-robin)
-    int64_t rows = (int64_t)(128.0 * 1024 * 1024 / (8.0 * g->ld));
-    rows = std::max<int64_t>(1024, std::min<int64_t>(8192, rows / 512 * 512));
+    // A K*' chunk of about the size of the 256 MB Infinity Cache, in multiples of 512 candidates (8 XCDs x one 64-wide candidate
+    // tile: k_trigemm_sq deals candidate tiles to XCDs round-robin).  Rounds 1-3 kept the chunk at 128 MB "so that it stays in the
+    // cache next to W"; the sweep of round 4 (tools/chunk_sweep.py, profiles/r04_chunk_sweep.txt) says larger is better up to
+    // ~200-330 MB -- fewer launches, each with more jobs per slot and a smaller share of ragged end -- and worse beyond:
+    // N = 3000, R = 32768: 4096 per chunk 5.15 ms, 8192: 4.96, 16384: 5.09;  N = 10^4, R = 4096: 1024: 7.28, 2048: 6.49, 4096: 6.43;
+    // N = 6000, R = 16384: 4096: 9.32, 8192: 9.42, 16384: 10.1;  N = 1000, R = 65536: 8192: 1.71, 32768: 1.57, 65536: 1.62.
+    int64_t rows = (int64_t)(256.0 * 1024 * 1024 / (8.0 * g->ld));
+    rows = std::max<int64_t>(1024, std::min<int64_t>(65536, rows / 512 * 512));
     return rows;
 }
 // Chunks of ONE batch are equal-sized multiples of 512 candidates: R = 32768 at N = 3000 is 8 x 4096, not 6 x 5376 + 512
 // (a ragged last chunk is a launch with a few candidate tiles per XCD -- all tail; measured 5.39 against 5.08 ms).  Among the
 // chunk counts that fit the cap the one that leaves the least padding wins, fewer chunks on a tie.
 static int64_t chunk_rows(const bohip_gp* g, int64_t R) {
+    if (g_chunk_rows_forced > 0) return std::min<int64_t>(round_up(std::max<int64_t>(R, 1), TILE), round_up(g_chunk_rows_forced, TILE));
     const int64_t cap = chunk_cap(g), R512 = round_up(std::max<int64_t>(R, 1), 512);
     if (R512 <= cap) return round_up(std::max<int64_t>(R, 1), TILE);   // one chunk (its buffer keeps the 128-row granularity)
     const int64_t nmin = (R512 + cap - 1) / cap;

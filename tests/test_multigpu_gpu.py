@@ -163,7 +163,7 @@ def test_bench_launches_the_way_the_driver_does(bohip):
     assert "bohip_gp_score_sharded_dev" in tr["config"]["parallelism"] and tr["best"] == one["best"]
     strong = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--strong",
                          "--no-cpu-baseline", "--no-c4"])
-    assert strong["scaling"] == "strong" and strong["config"]["R_total"] == 32768 and strong["roofline"]["launches_per_step"] == 8   # 8 x 4096: equal chunks, counted by the library
+    assert strong["scaling"] == "strong" and strong["config"]["R_total"] == 32768 and strong["roofline"]["launches_per_step"] == 4   # 4 x 8192: equal chunks of about 256 MB, counted by the library
     assert "cholesky_c4" in one and one["cholesky_c4"]["N"] == 10000
     X, y = bench.synth(0)
     ll = np.full(bench.DIM, np.log(0.5))

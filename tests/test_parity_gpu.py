@@ -503,9 +503,9 @@ def test_split_k_path_vs_oracle_and_whole_k(bohip, orc, N, d, R):
 
 
 def test_candidate_chunking_is_invisible(bohip, orc):
-    """R larger than one K*' chunk (8192 rows at this N): chunk boundaries, 64-wide tile padding and the per-chunk
-    gradient buffers must not show in the results."""
-    X, y, Xs = synth(200, 3, 20011, seed=17)
+    """R larger than one K*' chunk (65536 rows at this N; two equal chunks of 35328 here): chunk boundaries, 64-wide
+    tile padding and the per-chunk gradient buffers must not show in the results."""
+    X, y, Xs = synth(200, 3, 70001, seed=17)
     ll = np.array([-0.4, -0.9, -0.1])
     L, alpha = orc.fit(X, y, ll, 0.0, -2.0, 0.1)
     m = make_model(bohip, X, y, ll, 0.0, -2.0, 0.1)
@@ -514,15 +514,18 @@ def test_candidate_chunking_is_invisible(bohip, orc):
     sc, bv, bi = m.score("EI", [tau], Xs.T)
     check_scores(sc, sc_o, mu_floor(alpha, 1.0) + 1e-13)
     assert bi == bi_o and sc[bi] == bv
-    for lo, hi in [(0, 8192), (8000, 8400), (16384, 20011)]:                  # any sub-batch on the same (MFMA) path reproduces its slice bit-for-bit
+    from bohip import _lib
+    ch = m.info(_lib.INFO_SCORE_CHUNK)
+    assert 0 < ch < 70001 and m.info(_lib.INFO_SCORE_LAUNCHES) == 2           # the batch really was cut
+    for lo, hi in [(0, ch), (ch - 192, ch + 208), (ch, 70001)]:               # any sub-batch on the same (MFMA) path reproduces its slice bit-for-bit
         np.testing.assert_array_equal(m.score("EI", [tau], Xs[lo:hi].T)[0], sc[lo:hi])
     sg, g = m.score_grad("EI", [tau], Xs.T)
     np.testing.assert_array_equal(sg, sc)
-    _, g_o = orc.score_grad(X, ll, 0.0, 0.1, L, alpha, "EI", [tau], Xs[8000:8400])
-    np.testing.assert_allclose(g[:, 8000:8400].T, g_o, rtol=1e-6, atol=1e-9 * np.abs(g_o).max())
+    lo, hi = ch - 192, ch + 208
+    _, g_o = orc.score_grad(X, ll, 0.0, 0.1, L, alpha, "EI", [tau], Xs[lo:hi])
+    np.testing.assert_allclose(g[:, lo:hi].T, g_o, rtol=1e-6, atol=1e-9 * np.abs(g_o).max())
     bvs, bis = m.thompson(Xs.T, 4, seed=3)
     mu, var = m.predict_f(Xs.T)
-    from bohip import _lib
     lib = _lib.load()
     for s_ in range(4):
         f = mu[bis[s_]] + math.sqrt(var[bis[s_]]) * lib.bohip_thompson_normal(3, s_, int(bis[s_]))
