@@ -2756,6 +2756,72 @@ int bohip_debug_set_chol_inv_g(int g_new) {
     g_chol_inv_g = std::min(64, std::max(0, g_new));
     return old;
 }
+// tools only (tools/exec_throughput.py): how fast does the executor kernel get through its task list when NOTHING has to be waited for?
+// The records of the queues in `qmask` run with their counters removed (every task runnable at once, no chain kernel beside them), on
+// whatever the matrices hold: the time is the floor under any schedule of the same records.  hot = 1: every operand address of the bulk
+// and wave records points at the first panel of the scratch matrix (L2-resident) -- the same instruction stream without its fabric-side
+// traffic.  The model's factor and inverse are garbage afterwards (the handle is marked stale: the next use refits).
+int bohip_debug_exec_throughput(bohip_gp* g, unsigned qmask, int hot, int wgs, double* ms_out, double* gflop_out) {
+    if (!g || !ms_out || g->n == 0) return BOHIP_E_ARG;
+    hipSetDevice(g->device);
+    CHK(one_time_kernel_setup());
+    const int T = (int)(round_up(g->n + 1, TILE) / TILE);
+    if (T <= 3) return BOHIP_E_UNSUPPORTED;
+    std::vector<ExTask> all, run;
+    int qb[EX_NQ + 1], qb2[EX_NQ + 1];
+    exec_task_list(g->dL, g->dS, g->dW, g->dWT, g->dchol_flags, g->ld, T, g_chol_nsf, g_chol_inv_g, all, qb);
+    double fl = 0.0;
+    qb2[0] = 0;
+    for (int qi = 0; qi < EX_NQ; ++qi) {
+        if ((qmask >> qi) & 1u)
+            for (int i = qb[qi]; i < qb[qi + 1]; ++i) {
+                ExTask t = all[i];
+                for (int d = 0; d < EX_NDEP; ++d) { t.dep_idx[d] = EX_NONE; t.dep_want[d] = 0; }
+                t.sig_idx[0] = t.sig_idx[1] = EX_NONE;
+                t.kc_split = 0; t.dep2_idx[0] = t.dep2_idx[1] = EX_NONE;
+                if (hot && (qi == EX_QBULK || qi == EX_QWAVE)) { t.A = g->dS; t.B = g->dS + (int64_t)TILE * g->ld; }
+                fl += 2.0 * TILE * CTILE * KC * t.kc;
+                run.push_back(t);
+            }
+        qb2[qi + 1] = (int)run.size();
+    }
+    if (run.empty()) return BOHIP_E_ARG;
+    ExTask* dt = nullptr;
+    HIPCHK(hipMalloc(&dt, run.size() * sizeof(ExTask)));
+    HIPCHK(hipMemcpy(dt, run.data(), run.size() * sizeof(ExTask), hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(g->dchol_flags, 0, chol_flag_words(T) * sizeof(unsigned), g->stream));
+    ExQueues q{};
+    q.tasks = dt;
+    for (int i = 0; i <= EX_NQ; ++i) q.qbeg[i] = qb2[i];
+    q.flags = g->dchol_flags;
+    q.abort = g->dchol_flags + chol_abort_word(T);
+    q.heads = q.abort + 1;
+    q.ld = g->ld;
+    q.spin_ticks = g_chol_spin_ticks;
+    q.fill = g_chol_exec_fill;
+    const int exec_wgs = wgs > 0 ? wgs : std::max(2, std::min(g_chol_exec_wgs, 2 * std::max(1, device_cus() - (9 + g_chol_nsf + 6))));
+    q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));
+    q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
+    q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
+    q.fill_inv = g_chol_exec_fill_inv;
+    q.patience_ticks = (unsigned)g_chol_exec_patience_us * 100u;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, g->stream));
+    hipLaunchKernelGGL(k_chol_exec, dim3(exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->stream, q);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, g->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(dt);
+    *ms_out = ms;
+    if (gflop_out) *gflop_out = fl * 1e-9;
+    g->stale = true;
+    g->w_done = false;
+    return 0;
+}
 #if BOHIP_CHOL_TRACE
 int bohip_debug_chol_trace_read(unsigned long long* out, int64_t n_words) {   // tools only
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(bohip::g_chol_trace), (size_t)n_words * 8) == hipSuccess ? 0 : -3;
