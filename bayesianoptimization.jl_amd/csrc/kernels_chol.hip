@@ -104,6 +104,15 @@ __device__ unsigned long long g_chol_trace[8 * 1024];   // [4096, 4352): inverse
 #endif
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte agent-scope (sc1, write-through) store: ONE fabric write where two 8-byte atomic stores are two at 2.7x the time per byte
+// (MI355X_MICROARCH.md, "stores of each flavour"); a panel hand-over was 2048 of the small ones.  Inline asm (the atomic builtin stops
+// at 8 bytes); the s_nop is the wait state a > 64-bit VMEM store needs before its data registers are rewritten.
+// (`volatile` 16-byte accesses were tried first: the compiler emits them sc0 sc1 = system scope, and a pivot panel then took 9.5 us
+// instead of 7.)
+__device__ __forceinline__ void st_agent2(double* p, double x, double y) {
+    d2 v; v.x = x; v.y = y;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
 // 16-byte agent-scope loads (the atomic builtin stops at 8 bytes): issue, then ONE wait that also ties the results in
 __device__ __forceinline__ void ld_agent_x2_issue(const double* p, d2& out) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(out) : "v"(p) : "memory");
@@ -166,6 +175,7 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
     bool have = false;
     for (int p = 0; p < CH_PANELS; ++p) {
         if (t == 0) {
+            if (WITH_D1 && k_blk == 1) CH_MARK(5912 + p);   // starts waiting (or finds the panel staged ahead)
             if (!have) flag_wait_ge(fl.panel + k_blk * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
             if (WITH_D1) CH_MARK(1024 + k_blk * CH_PANELS + p);
             *nready = (p + 1 < CH_PANELS && __hip_atomic_load(fl.panel + k_blk * CH_PANELS + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= fl.panel_want) ? 1 : 0;
@@ -178,18 +188,29 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
                 double v0 = pv0, v1 = pv1, v2 = pv2, v3 = pv3;
                 if (!have) {
                     const double* src = Lkk + (int64_t)i * ld + 16 * p + 4 * mq;
-                    v0 = ld_agent(src); v1 = ld_agent(src + 1); v2 = ld_agent(src + 2); v3 = ld_agent(src + 3);
+                    d2 u0, u1;
+                    ld_agent_x2_issue(src, u0);
+                    ld_agent_x2_issue(src + 2, u1);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(u0), "+v"(u1) : : "memory");
+                    v0 = u0.x; v1 = u0.y; v2 = u1.x; v3 = u1.y;
                 }
                 double* dst = LPt + (4 * mq) * WK_LS + i;
                 dst[0] = v0; dst[WK_LS] = v1; dst[2 * WK_LS] = v2; dst[3 * WK_LS] = v3;
             }
-            if (t < 256) W16s[t] = have ? pw : ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p) * 256 + t);
+            if (have) {
+                if (t < 256) W16s[t] = pw;
+            } else if (t < 128) {
+                d2 u;
+                ld_agent_x2_issue(fl.w16_g + ((size_t)k_blk * CH_PANELS + p) * 256 + 2 * t, u);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(u) : : "memory");
+                *reinterpret_cast<d2*>(W16s + 2 * t) = u;
+            }
         }
         if (nxt) {   // the next panel's staging loads: in flight during this panel's solve and update
             const int i = t >> 2, mq = t & 3;
             if (i >= 16 * (p + 1)) {
                 const double* src = Lkk + (int64_t)i * ld + 16 * (p + 1) + 4 * mq;
-                pv0 = ld_agent(src); pv1 = ld_agent(src + 1); pv2 = ld_agent(src + 2); pv3 = ld_agent(src + 3);
+                pv0 = ld_agent(src); pv1 = ld_agent(src + 1); pv2 = ld_agent(src + 2); pv3 = ld_agent(src + 3);   // (in flight across the panel's phases: loads the compiler tracks)
             }
             if (t < 256) pw = ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p + 1) * 256 + t);
         }
@@ -218,10 +239,9 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
             }
             double* Srow = S + ((int64_t)i_tile * TILE + row) * ld + (int64_t)k_blk * TILE + 16 * p + 4 * part;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                XS[row * WK_XS + 4 * part + cc] = x4[cc];
-                st_agent(Srow + cc, x4[cc]);
-            }
+            for (int cc = 0; cc < 4; ++cc) XS[row * WK_XS + 4 * part + cc] = x4[cc];
+            st_agent2(Srow, x4[0], x4[1]);
+            st_agent2(Srow + 2, x4[2], x4[3]);
         }
         __syncthreads();
         if (w > p) {   // wave-uniform: this wave's columns lie beyond the panel
@@ -283,13 +303,16 @@ __device__ __forceinline__ void publish_panel(double* __restrict__ Lblk, int64_t
     const int i = tid & 127, h = tid >> 7;
     if (i >= P) {
         double* dst = Lblk + (int64_t)i * ld + P + 8 * h;
+        double v[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int c0 = P + 8 * h + c;
-            st_agent(dst + c, (i > c0) ? a[c0 * PF_LD + i] : (i == c0 ? dl[i] : 0.0));
+            v[c] = (i > c0) ? a[c0 * PF_LD + i] : (i == c0 ? dl[i] : 0.0);
         }
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) st_agent2(dst + c, v[c], v[c + 1]);
     }
-    st_agent(w16_out + tid, w16s[tid]);   // 256 publishing threads, 256 entries
+    if (tid < 128) st_agent2(w16_out + 2 * tid, w16s[2 * tid], w16s[2 * tid + 1]);   // 256 entries, 16 bytes per store
 }
 
 __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, double* __restrict__ Lblk, int64_t ld,
@@ -357,8 +380,14 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
         __syncthreads();
         if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 1);
         if (tid >= 320) {
+            if (lane == 0 && wave == 5 && k_blk == 1) CH_MARK(5904 + jb);   // wave 5 starts waiting for its stores
             release_wg();   // s_waitcnt vmcnt(0): this wave's part of the panel has left the CU
-            if (lane == 0) { atomicAdd(pflag + jb, 1u); if (wave == 5) CH_MARK(k_blk * CH_PANELS + jb); }
+            if (lane == 0) {
+                atomicAdd(pflag + jb, 1u);
+                if (wave == 5) CH_MARK(k_blk * CH_PANELS + jb);
+                if (wave == 6 && k_blk == 1) CH_MARK(5888 + jb);
+                if (wave == 7 && k_blk == 1) CH_MARK(5896 + jb);
+            }
         }
         if (m == 0) break;
         if (wave == 0) {
@@ -563,19 +592,28 @@ __device__ __forceinline__ void gated_tile(const double* __restrict__ A, const d
         __syncthreads();   // (also: the previous chunk's fragments have been read)
         if (act) {
             // LDS[row][slot] holds the 16-B segment slot ^ (row & 7) of the row's 128-B chunk (the swizzle of gemm_core.h)
+            // (six 16-byte agent-scope loads per thread, one wait: as 8-byte atomic loads they were twelve fabric reads)
+            d2 va[4], vb[2];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7, seg = slot ^ (row & 7);
-                const double* src = A + (int64_t)row * ld + c * KC + 2 * seg;
-                As[row * GL_ROW + 2 * slot] = ld_agent(src);
-                As[row * GL_ROW + 2 * slot + 1] = ld_agent(src + 1);
+                ld_agent_x2_issue(A + (int64_t)row * ld + c * KC + 2 * seg, va[u]);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7, seg = slot ^ (row & 7);
-                const double* src = B + (int64_t)row * ld + c * KC + 2 * seg;
-                Bs[row * GL_ROW + 2 * slot] = ld_agent(src);
-                Bs[row * GL_ROW + 2 * slot + 1] = ld_agent(src + 1);
+                ld_agent_x2_issue(B + (int64_t)row * ld + c * KC + 2 * seg, vb[u]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(vb[0]), "+v"(vb[1]) : : "memory");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7;
+                *reinterpret_cast<d2*>(As + row * GL_ROW + 2 * slot) = va[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int sidx = tid + 256 * u, row = sidx >> 3, slot = sidx & 7;
+                *reinterpret_cast<d2*>(Bs + row * GL_ROW + 2 * slot) = vb[u];
             }
         }
         __syncthreads();
@@ -585,11 +623,19 @@ __device__ __forceinline__ void gated_tile(const double* __restrict__ A, const d
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int r = acc_row(lane, wr, mi);
+            // Neighbouring lanes hold neighbouring columns: the even lane of a pair takes both lanes' values of column group nj, the odd
+            // lane both of group nj + 1 -- 16 stores of 16 bytes per thread instead of 32 of 8 (each one a fabric write of its own,
+            // all of them drained before the tile's counter goes up: the hand-over to the next pivot block waits for exactly that)
+            const bool odd = (lane & 1) != 0;
 #pragma unroll
-            for (int nj = 0; nj < 4; ++nj) {
-                const int cc = acc_col<4>(lane, wc, nj);
+            for (int nj = 0; nj < 4; nj += 2) {
+                const double a0 = -acc[mi][nj], a1 = -acc[mi][nj + 1];
+                const double got = __shfl_xor(odd ? a0 : a1, 1);
+                const int cc = odd ? acc_col<4>(lane, wc, nj + 1) - 1 : acc_col<4>(lane, wc, nj);   // first column of this lane's piece
+                const double x = odd ? got : a0, y = odd ? a1 : got;
                 if (col0 + cc > row0 + r) continue;   // the strict upper triangle stays zero
-                st_agent(C + (int64_t)r * ld + cc, -acc[mi][nj]);
+                if (col0 + cc + 1 > row0 + r) st_agent(C + (int64_t)r * ld + cc, x);
+                else st_agent2(C + (int64_t)r * ld + cc, x, y);
             }
         }
         release_wg();

@@ -15,9 +15,9 @@ m.append_(X.T, y)
 for _ in range(3):
     m.set_params_(logNoise=-2.0); m.fit_()
 lib = _lib.load()
-buf = (C.c_ulonglong * 4096)()
+buf = (C.c_ulonglong * 8192)()
 lib.bohip_debug_chol_trace_read.argtypes = [C.c_void_p, C.c_int64]
-assert lib.bohip_debug_chol_trace_read(buf, 4096) == 0
+assert lib.bohip_debug_chol_trace_read(buf, 8192) == 0
 t = np.array(buf, dtype=np.int64)
 T = (N + 1 + 127) // 128
 pub, saw, fin, blk = t[:1024], t[1024:2048], t[2048:3072], t[3072:]
@@ -52,3 +52,9 @@ for p_ in range(8):
 print("block 1, per panel (us since the block's pivot start): W16 done (wave 4) | row solve done (thread 0, before the barrier) | barrier passed")
 for jb in range(8):
     print("  panel", jb, [None if ph[jb][c] == 0 else round((ph[jb][c] - t[3072 + 2]) / 100.0, 2) for c in (5, 6, 0)])
+
+print("block 1, the panel flag's way (us since the block's pivot start): wave 5 starts draining its stores | flag +1 by wave 6 | wave 7 | wave 5 | "
+      "owner of row 2 starts waiting | sees the flag")
+for jb in range(8):
+    r = lambda v: None if v == 0 else round((v - t[3072 + 2]) / 100.0, 2)
+    print("  panel", jb, [r(t[5904 + jb]), r(t[5888 + jb]), r(t[5896 + jb]), r(t[8 + jb]), r(t[5912 + jb]), r(t[1024 + 8 + jb])])
