@@ -154,6 +154,8 @@ constexpr int WK_LS = TILE + 2;   // row stride of LPt (even: 16-B aligned rows;
 // of a 10 us panel).
 // Thread t of a follower: wave w = t >> 6 owns columns 16w..16w+15 of tile (i, k); lane (r16 = lane & 15, cg = lane >> 4)
 // holds rows r16 + 16 i (i < 8) x columns 16w + 4cg + e (e < 4):  a[4 i + e].
+template <int H>
+__device__ __forceinline__ void d1_rank16(const double* XB, double (&d)[18]);
 template <bool WITH_D1, int H>
 __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ S,
                                              int i_tile, int k_blk, const CholFlags& fl, double* wk, double (&a)[32],
@@ -360,14 +362,12 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
         }
         __syncthreads();
         if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 0);
-        // Panel jb is final.  Waves that take no part in the factorisation publish it -- their stores and the wait for
-        // them to land stay off the pivot chain: they are issued here, awaited behind the next barrier, and each wave then
-        // adds 1 to the panel's flag (followers wait for 4).
-        if (tid >= 320) {   // waves 5-7 publish (192 threads walk the 256 publishing slots)
-            for (int s_ = tid - 320; s_ < PF_THREADS; s_ += 192)
-                publish_panel(Lblk, ld, a, dl, w16s, fl.w16_g + ((size_t)k_blk * CH_PANELS + jb) * 256, P, s_);
-        }
-        if (m > 0 && act) {   // rank-16 update of the next pivot block
+        // Panel jb is final.  Two phases follow.  First the rank-16 update of the NEXT pivot block alone, on 256 threads (16 products per
+        // thread) -- until round 4 the publishing waves issued their stores in this phase too and everybody waited at its barrier for them:
+        // 1.4 us of every 7 us panel.  (The update on wave 0 alone, four elements per lane and no barrier, was measured as well: 2.0 us.)
+        // Then: waves 4, 6, 7 publish the panel (stores, the wait for them to land, +1 each on the panel's flag: followers wait for 3), wave 0
+        // factors the next pivot block, waves 1, 2, 3, 5 update the rest of the trailing matrix.
+        if (m > 0 && act) {
             const int ty = tid >> 4, tx = tid & 15;
             double acc = 0.0;
 #pragma unroll
@@ -377,14 +377,21 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
             }
             if (tx <= ty) a[(base + ty) * PF_LD + base + tx] -= acc;
         }
-        __syncthreads();
+        if (m > 0) __syncthreads();
         if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 1);
-        if (tid >= 320) {
-            if (lane == 0 && wave == 5 && k_blk == 1) CH_MARK(5904 + jb);   // wave 5 starts waiting for its stores
+        // Who does what follows from where the waves sit: wave w runs on SIMD w % 4, so wave 4 shares its SIMD with wave 0.  The pivot
+        // chain (wave 0) gets the lightest neighbour: waves 4, 6, 7 publish (a few LDS reads and stores each), waves 1, 2, 3, 5 carry the
+        // trailing update.  (With the trailing update on waves 1-4, factor16 took 7.3 us instead of 2.9 beside the first, widest update
+        // of a block -- the "slow first panel" of rounds 2-3.)
+        if (wave == 4 || wave >= 6) {   // 192 threads walk the 256 publishing slots
+            const int pw = wave == 4 ? 0 : wave - 5;
+            for (int s_ = 64 * pw + lane; s_ < PF_THREADS; s_ += 192)
+                publish_panel(Lblk, ld, a, dl, w16s, fl.w16_g + ((size_t)k_blk * CH_PANELS + jb) * 256, P, s_);
+            if (lane == 0 && wave == 4 && k_blk == 1) CH_MARK(5904 + jb);   // wave 4 starts waiting for its stores
             release_wg();   // s_waitcnt vmcnt(0): this wave's part of the panel has left the CU
             if (lane == 0) {
                 atomicAdd(pflag + jb, 1u);
-                if (wave == 5) CH_MARK(k_blk * CH_PANELS + jb);
+                if (wave == 4) CH_MARK(k_blk * CH_PANELS + jb);
                 if (wave == 6 && k_blk == 1) CH_MARK(5888 + jb);
                 if (wave == 7 && k_blk == 1) CH_MARK(5896 + jb);
             }
@@ -393,11 +400,10 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
         if (wave == 0) {
             factor16(a, dl, idl, base, lane, info, row0);
             if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 3);
-        } else if (wave <= 4) {
-            // waves 1-4: one (ty, tx) position of every live 16 x 16 sub-block per thread.  (k_potf2_inv has three waves for this
-            // and splits the fourth wave's rows three ways: four code variants per size, 28 in all, ~30 KB, each run once per
-            // block from a cold instruction cache -- the first panel's update took 14 us for ~2 us of work.)
-            const int u = tid - 64;
+        } else if (wave <= 3 || wave == 5) {
+            // waves 1, 2, 3, 5: one (ty, tx) position of every live 16 x 16 sub-block per thread.  (k_potf2_inv has three waves for this
+            // and splits the fourth wave's rows three ways: four code variants per size, 28 in all, ~30 KB.)
+            const int u = 64 * (wave == 5 ? 3 : wave - 1) + lane;
             trailing_dispatch<true, -1>(a, P, m >> 4, u >> 4, u & 15);
             if (tid == 64 && k_blk == 1) CH_MARK(3584 + 8 * jb + 4);
         }
@@ -482,6 +488,9 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             }
             d1_load<H>(Lmat, ld, r, d);
             if (tid == 0) CH_MARK(3500 + r);
+            // (The owner following block r-1 ITSELF -- tile (r, r-1) in its registers beside the diagonal tile, follow_block<true, H>, no
+            // hop through S and a second workgroup -- was built and measured in round 4: its panel then takes longer than the pivot's
+            // and it falls behind, 1.85 against 1.57 ms at N = 3000.  The split stays: the follower solves, this workgroup only adds.)
             const unsigned* xf = xp_at(fl, r - 1, r);
             const double* Sx = S + ((int64_t)r * TILE + (tid >> 2)) * ld + (int64_t)(r - 1) * TILE + 4 * (tid & 3);
             for (int p = 0; p < CH_PANELS; ++p) {
@@ -707,11 +716,24 @@ __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, i
             const int R0 = 16 * p, R1 = R0 + 16;
             if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
             __syncthreads();
-            if (tid < 256) W16s[tid] = ld_agent(fl.w16_g + ((size_t)k * CH_PANELS + p) * 256 + tid);
-            if (p + 1 < CH_PANELS) {   // rows 16(p+1) .. of L_kk, columns < 16(p+1): thread (r = tid >> 5, mm = tid & 31)
-                const int r = tid >> 5, mm = tid & 31;
+            {   // ONE round trip of 16-byte agent-scope loads (as 8-byte atomic loads: up to 4 + 1 fabric reads per thread and panel)
+                d2 uw, ul[2];
+                uw.x = uw.y = 0.0; ul[0] = uw; ul[1] = uw;
+                const int r = tid >> 5, mm = tid & 31;   // rows 16(p+1) .. of L_kk, columns < 16(p+1): 16-byte pieces 2 mm + 64 i
                 const double* src = Lblk + (int64_t)(R1 + r) * ld;
-                for (int col = mm; col < R1; col += 32) Lrow[r * INV_WROWS + col] = ld_agent(src + col);
+                if (tid < 128) ld_agent_x2_issue(fl.w16_g + ((size_t)k * CH_PANELS + p) * 256 + 2 * tid, uw);
+                if (p + 1 < CH_PANELS) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        if (2 * mm + 64 * i < R1) ld_agent_x2_issue(src + 2 * mm + 64 * i, ul[i]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(uw), "+v"(ul[0]), "+v"(ul[1]) : : "memory");
+                if (tid < 128) *reinterpret_cast<d2*>(W16s + 2 * tid) = uw;
+                if (p + 1 < CH_PANELS) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        if (2 * mm + 64 * i < R1) *reinterpret_cast<d2*>(Lrow + r * INV_WROWS + 2 * mm + 64 * i) = ul[i];
+                }
             }
             if (p > 0 && c < R0) {
 #pragma unroll
@@ -778,9 +800,18 @@ __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, i
                 }
             } else {
                 // the last row panel goes out straight from the registers (rows 112 + 4 rq .. + 3, column c) and from W16
+                {   // rows of W: the even lane of a pair stores rows j = 0, 1 of both lanes' columns, the odd lane rows 2, 3 (16 bytes each)
+                    const bool odd = (c & 1) != 0;
+                    const double g0 = __shfl_xor(odd ? wn[0] : wn[2], 1), g1 = __shfl_xor(odd ? wn[1] : wn[3], 1);
+                    if (c < R0) {   // (R0 = 112 is even: both lanes of a pair are inside or outside)
+                        const int j0 = odd ? 2 : 0, cc = c & ~1;
+                        const double x0 = odd ? g0 : wn[0], y0 = odd ? wn[2] : g0;   // row j0:     columns cc, cc + 1
+                        const double x1 = odd ? g1 : wn[1], y1 = odd ? wn[3] : g1;   // row j0 + 1
+                        st_agent2(Wb + (int64_t)(R0 + 4 * rq + j0) * ldw + cc, x0, y0);
+                        st_agent2(Wb + (int64_t)(R0 + 4 * rq + j0 + 1) * ldw + cc, x1, y1);
+                    }
+                }
                 if (c < R0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) st_agent(Wb + (int64_t)(R0 + 4 * rq + j) * ldw + c, wn[j]);
                     d2 v0, v1;
                     v0.x = wn[0]; v0.y = wn[1]; v1.x = wn[2]; v1.y = wn[3];
                     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq), "v"(v0) : "memory");

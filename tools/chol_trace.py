@@ -58,3 +58,6 @@ print("block 1, the panel flag's way (us since the block's pivot start): wave 5 
 for jb in range(8):
     r = lambda v: None if v == 0 else round((v - t[3072 + 2]) / 100.0, 2)
     print("  panel", jb, [r(t[5904 + jb]), r(t[5888 + jb]), r(t[5896 + jb]), r(t[8 + jb]), r(t[5912 + jb]), r(t[1024 + 8 + jb])])
+
+print("inverse of the diagonal block published (us after the pivot block's end), blocks 0..7:",
+      [round((t[4096 + k] - blk[2 * k + 1]) / 100.0, 1) for k in range(min(T, 8))])
