@@ -1243,8 +1243,17 @@ static int refit_once(bohip_gp* g, double jitter) {
             // the process (BOHIP_CHOL_DF_STRICT=1: report it instead, for tests and tools).
             g->chol_fallbacks++;
             g->chol_abort_T = T;
-            fprintf(stderr, "libbohip: dataflow factorisation (form %d, %d row tiles) timed out on a dependency; using the launch-chained form for a while\n",
-                    g->chol_form_last, T);
+            {
+                // the chain kernel's waits leave the word address of the flag that never arrived (bit 31 set); the executor's tasks and the
+                // flagged launches of the older forms leave 1
+                char which[96] = "counters of an executor task or a flagged launch";
+                if (aborted & 0x80000000u) {
+                    const unsigned base_w = (unsigned)(reinterpret_cast<uintptr_t>(g->dchol_flags) >> 2) | 0x80000000u;
+                    snprintf(which, sizeof which, "flag word %u of %zu", (aborted - base_w) & 0x7fffffffu, chol_flag_words(T));
+                }
+                fprintf(stderr, "libbohip: dataflow factorisation (form %d, %d row tiles) timed out on a dependency (%s); using the launch-chained form for a while\n",
+                        g->chol_form_last, T, which);
+            }
             if (getenv("BOHIP_CHOL_DF_STRICT")) return fail(BOHIP_E_HIP, "dataflow factorisation timed out on a dependency (BOHIP_CHOL_DF_STRICT)");
             {
                 const int bo = std::min(1024, 2 * g_chol_df_backoff.load(std::memory_order_relaxed) + 8);

@@ -87,7 +87,8 @@ __device__ __forceinline__ void flag_wait_ge(const unsigned* flag, unsigned want
         if (__hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
         __builtin_amdgcn_s_sleep(4);
         if (wall_clock64() - t0 > spin_ticks) {   // something upstream never arrived
-            __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (the first one to give up leaves the flag's word address behind: the host names it in its message)
+            atomicCAS(abort, 0u, (unsigned)(reinterpret_cast<uintptr_t>(flag) >> 2) | 0x80000000u);
             return;
         }
     }
@@ -491,6 +492,10 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             // (The owner following block r-1 ITSELF -- tile (r, r-1) in its registers beside the diagonal tile, follow_block<true, H>, no
             // hop through S and a second workgroup -- was built and measured in round 4: its panel then takes longer than the pivot's
             // and it falls behind, 1.85 against 1.57 ms at N = 3000.  The split stays: the follower solves, this workgroup only adds.)
+            // (Round 4 also tried: the follower publishes the LAST panel's right-hand side one panel early and the owner solves that panel
+            // itself from the pivot's flag -- bit-identical, no faster: the owner's own panel 6 ends only ~3 us before the follower's panel 7
+            // would have arrived, and its panel 7 then costs 5.4 us instead of 4.  What bounds the hand-over is follower 4-5 us + owner 4 us
+            // per panel in a pipeline that runs at the pivot's pace, not the last hop.)
             const unsigned* xf = xp_at(fl, r - 1, r);
             const double* Sx = S + ((int64_t)r * TILE + (tid >> 2)) * ld + (int64_t)(r - 1) * TILE + 4 * (tid & 3);
             for (int p = 0; p < CH_PANELS; ++p) {

@@ -149,3 +149,23 @@ if qb[4] > qb[3]:
                     e = et[qb[3] + ix]
                     jj = ((off[ix] % ld) // 128, ((off[ix] % ld) % 128) // 64)
                     print(f"   {nm:8s} j={jj[0]:2d} h={jj[1]} | {us(e[0]) - pe:8.1f} {us(e[1]) - pe:8.1f} {us(e[2]) - pe:8.1f} | wg {int(e[3]):3d} | {ix}")
+
+# the inverse's row chain against the pivots: row i's products W(i, j) = W_ii Z(i, j) (queue 3 records whose A operand is a diagonal tile of W)
+if qb[4] > qb[3]:
+    A_addr = recs.view(np.uint64)[:, 0].astype(np.int64)
+    baseW = 3 << 44
+    in_q3 = np.arange(qb[3], qb[4])
+    offA = (A_addr[in_q3] - baseW) // 8
+    isW = (A_addr[in_q3] >= baseW) & (A_addr[in_q3] < (4 << 44))
+    rt, ctile = offA // (128 * ld), (offA % ld) // 128
+    prod = isW & (rt == ctile)
+    print("inverse rows: row i -- last product of the row ends (us after pivot i's end) | since the previous row's")
+    prev = None
+    for i in range(1, T):
+        sel = in_q3[prod & (rt == i)]
+        if len(sel) == 0: continue
+        e = us(et[sel, 2]).max()
+        pe = us(ct[3072 + 2 * i + 1])
+        if i < 8 or i % 4 == 0 or i >= T - 3:
+            print(f"  row {i:3d}: {e - pe:8.1f} | {'' if prev is None else f'{e - prev:7.1f}'}")
+        prev = e
