@@ -44,8 +44,8 @@ namespace bohip {
 constexpr int CH_THREADS = 512;
 constexpr int CH_PANELS = TILE / 16;          // 8 panels of 16 columns per 128-block
 constexpr int WK_LPS = 16;                    // worker LDS: published panel LP[128][16]
-constexpr int WK_XS = 17;                     //             solved rows   XB[128][17]
-constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + 2 * TILE * WK_XS + 256 + 2;   // LPt[16][130] | XB[128][17] | XS[128][17] | W16[16][16] | next-panel-ready word
+constexpr int WK_XS = 18;                     //             solved rows   XB[128][18]: rows 16-byte aligned (two entries per ds_read_b128), 16 consecutive rows on 16 different bank quads
+constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + 2 * TILE * WK_XS + 256 + 2;   // LPt[16][130] | XB[128][18] | XS[128][18] | W16[16][16] | next-panel-ready word
 constexpr int INV_LDS_DOUBLES = (TILE - 16) * TILE + 16 * (TILE - 16) + 16 * TILE + 256;   // the inverter workgroup's image (inverter_role)
 constexpr int CH_LDS_BYTES = (INV_LDS_DOUBLES > TILE * PF_LD + 2 * TILE + 256 ? INV_LDS_DOUBLES : TILE * PF_LD + 2 * TILE + 256) * 8;   // the potf2 image + dl + idl + W16 scratch (the worker arrays alias its start), or the inverter's
 static_assert(WK_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "worker arrays must fit inside the diagonal-block image");
@@ -166,8 +166,8 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
     // them chunk by chunk while the block is still being factored
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), r16 = lane & 15, cg = lane >> 4;
     double* LPt = wk;                        // [16][WK_LS]
-    double* XB = wk + 16 * WK_LS;            // [128][17]  panel entries before the solve
-    double* XS = XB + TILE * WK_XS;          // [128][17]  x = the 16 new columns of L(i, k)
+    double* XB = wk + 16 * WK_LS;            // [128][18]  panel entries before the solve
+    double* XS = XB + TILE * WK_XS;          // [128][18]  x = the 16 new columns of L(i, k)
     double* W16s = XS + TILE * WK_XS;        // [16][16]
     const double* Lkk = Lmat + (int64_t)k_blk * TILE * (ld + 1);
     const int ty = (t & 255) >> 4, tx = t & 15;
@@ -230,7 +230,10 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
             const int row = t & 127, part = t >> 7;
             double r[16], x4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < 16; ++c) r[c] = XB[row * WK_XS + c];
+            for (int c = 0; c < 16; c += 2) {
+                const d2 rv = *reinterpret_cast<const d2*>(XB + row * WK_XS + c);
+                r[c] = rv.x; r[c + 1] = rv.y;
+            }
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 const d2* wrow = reinterpret_cast<const d2*>(W16s + (4 * part + cc) * 16);
@@ -250,18 +253,22 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
         __syncthreads();
         if (w > p) {   // wave-uniform: this wave's columns lie beyond the panel
             const double* lp = LPt + 16 * w + 4 * cg;
-#pragma unroll 4
-            for (int m = 0; m < 16; ++m) {
-                const d2 l01 = *reinterpret_cast<const d2*>(lp + m * WK_LS), l23 = *reinterpret_cast<const d2*>(lp + m * WK_LS + 2);
-                double xv[8];
+#pragma unroll 2
+            for (int m = 0; m < 16; m += 2) {   // two contraction indices per round of LDS reads (x as 16-byte pieces); per entry still m = 0, 1, 2, ...
+                d2 xv[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) xv[i] = XS[(r16 + 16 * i) * WK_XS + m];
+                for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const d2*>(XS + (r16 + 16 * i) * WK_XS + m);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    a[4 * i + 0] -= xv[i] * l01.x;
-                    a[4 * i + 1] -= xv[i] * l01.y;
-                    a[4 * i + 2] -= xv[i] * l23.x;
-                    a[4 * i + 3] -= xv[i] * l23.y;
+                for (int h = 0; h < 2; ++h) {
+                    const d2 l01 = *reinterpret_cast<const d2*>(lp + (m + h) * WK_LS), l23 = *reinterpret_cast<const d2*>(lp + (m + h) * WK_LS + 2);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const double x = h == 0 ? xv[i].x : xv[i].y;
+                        a[4 * i + 0] -= x * l01.x;
+                        a[4 * i + 1] -= x * l01.y;
+                        a[4 * i + 2] -= x * l23.x;
+                        a[4 * i + 3] -= x * l23.y;
+                    }
                 }
             }
         }
@@ -501,16 +508,18 @@ __device__ __forceinline__ void d1_rank16(const double* XB, double (&d)[18]) {
     double acc[18];
 #pragma unroll
     for (int s = 0; s < 18; ++s) acc[s] = 0.0;
-#pragma unroll 4
-    for (int m = 0; m < 16; ++m) {
-        double li[8], lk[8];
+#pragma unroll 2
+    for (int m = 0; m < 16; m += 2) {   // two contraction indices per round of LDS reads (16-byte pieces): 128 reads per thread instead of 256
+        d2 li[8], lk[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            li[u] = XB[(16 * u + ty) * WK_XS + m];
-            lk[u] = XB[(16 * u + tx) * WK_XS + m];
+            li[u] = *reinterpret_cast<const d2*>(XB + (16 * u + ty) * WK_XS + m);
+            lk[u] = *reinterpret_cast<const d2*>(XB + (16 * u + tx) * WK_XS + m);
         }
 #pragma unroll
-        for (int s = 0; s < 18; ++s) acc[s] += li[blk_bi(2 * s + H)] * lk[blk_bj(2 * s + H)];
+        for (int s = 0; s < 18; ++s) acc[s] += li[blk_bi(2 * s + H)].x * lk[blk_bj(2 * s + H)].x;
+#pragma unroll
+        for (int s = 0; s < 18; ++s) acc[s] += li[blk_bi(2 * s + H)].y * lk[blk_bj(2 * s + H)].y;
     }
 #pragma unroll
     for (int s = 0; s < 18; ++s) d[s] -= acc[s];
@@ -525,7 +534,7 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
     double* a = sm;
     double* dl = sm + TILE * PF_LD;
     double* idl = dl + TILE;
-    double* XB = sm;   // [128][17] while the image is not in use
+    double* XB = sm;   // [128][18] while the image is not in use
     const int tid = threadIdx.x;
     double d[18];
     for (int r = w; r < T; r += 2) {
@@ -561,7 +570,8 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
                     ld_agent_x2_issue(Sx + 16 * p + 2, v1);
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1) : : "memory");
                     double* dst = XB + (tid >> 2) * WK_XS + 4 * (tid & 3);
-                    dst[0] = v0.x; dst[1] = v0.y; dst[2] = v1.x; dst[3] = v1.y;
+                    *reinterpret_cast<d2*>(dst) = v0;
+                    *reinterpret_cast<d2*>(dst + 2) = v1;
                 }
                 __syncthreads();
                 d1_rank16<H>(XB, d);
