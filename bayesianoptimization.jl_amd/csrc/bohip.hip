@@ -313,6 +313,7 @@ static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind th
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
 static int g_chol_exec_urgent = 32; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
+static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: 112 up to 48 row tiles, none above)
 static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue in earliest-deadline order from a host-side simulation (round-4 experiment: same total, see exec_task_list)
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
 static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
@@ -369,6 +370,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_BULK_EDF")) g_chol_exec_bulk_edf = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_FAST")) g_chol_exec_fast = atoi(e);
     if (const char* e = getenv("BOHIP_CHUNK_ROWS")) g_chunk_rows_forced = atoll(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_HALVE")) {   // "lo,hi": row tiles lo <= rt < hi go as two 64-row halves ("0,0": none)
         int a = 0, b = 0;
@@ -1128,6 +1130,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
         const int cus_free = std::max(1, device_cus() - (9 + g_chol_nsf + 6));
         const int exec_wgs = std::max(2, std::min(g_chol_exec_wgs, 2 * cus_free));
         q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));   // queue 0 is served by these only: never zero
+        q.nfast = std::max(0, std::min(exec_wgs / 4, g_chol_exec_fast >= 0 ? g_chol_exec_fast : (T <= 48 ? 112 : 0)));
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
         q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
         q.fill_inv = g_chol_exec_fill_inv;

@@ -89,6 +89,9 @@ struct ExQueues {
     int64_t ld;
     unsigned long long spin_ticks;   // a workgroup that finds no runnable task for this long gives up (see flag_wait_ge)
     int nurgent;                // workgroups 0 .. nurgent-1 serve the urgent queue (and nothing else until it is exhausted)
+    int nfast;                  // the next nfast workgroups never take bulk or wave tasks: whatever the chain will need soon (queues 1-3) finds
+                                // one of them free.  Chain-paced sizes only: with every general workgroup inside a 60-100 us bulk / wave task
+                                // right after a group's release, the row steps waited that long and the pivot chain with them
     int fill_inv;               // ... and inverse-wave work (1), see k_chol_exec
     unsigned patience_ticks;    // ... but only once the held record has been waited for this long (wall-clock ticks of 10 ns)
     int fill;                   // a workgroup that holds a claimed task whose counters are not in yet takes bulk work meanwhile:
@@ -377,6 +380,8 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                                // workgroup holding one goes on claiming everywhere else
     __shared__ unsigned s_tp, s_tp3;   // when the records in `pend` / `pend3` were claimed (low word of the wall clock)
     __shared__ int s_urgent;
+    const unsigned lane_mask = ((int)blockIdx.x >= q.nurgent && (int)blockIdx.x < q.nurgent + q.nfast)
+                                   ? ~((1u << EX_QBULK) | (1u << EX_QWAVE)) : ~0u;   // queues this workgroup may ever claim from
     if (threadIdx.x == 0) { s_look = -1; s_pend = -1; s_pend2 = -1; s_pend2n = 0; s_pend3 = -1; s_tp = 0u; s_tp3 = 0u; s_urgent = (int)blockIdx.x < q.nurgent; }
     __syncthreads();
     // The urgent queue (~10 tasks per block: what the chain kernel reads next) has its own workgroups: each takes the next urgent
@@ -444,6 +449,7 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                     if (pend2 < 0 && (q.fill >= 2 || (q.fill == 1 && queue_of(pend) == 2))) qmask |= 1u << EX_QBULK;
                     if (pend3 < 0 && q.fill_inv) qmask |= 1u << EX_QWAVE;
                 }
+                qmask &= lane_mask;
                 const bool nothing_held = pend < 0 && pend2 < 0 && pend3 < 0;
                 if (qmask != 0u) {
                     if (look >= 0 && ((qmask >> (look >> 24)) & 1u)) { tk = ex_claim(q, look >> 24, (unsigned)(look & 0xffffff), pl, rdy); if (tk == -2) tk = -3; }

@@ -61,3 +61,5 @@ for jb in range(8):
 
 print("inverse of the diagonal block published (us after the pivot block's end), blocks 0..7:",
       [round((t[4096 + k] - blk[2 * k + 1]) / 100.0, 1) for k in range(min(T, 8))])
+print("gap pivot end -> next pivot start, every block (us):", [round(float(g_), 1) for g_ in gap])
+print("pivot block duration, every block (us):", [round(float(d_), 1) for d_ in dur])

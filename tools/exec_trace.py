@@ -89,7 +89,7 @@ pdur = [(us(ct[3072 + 2 * k + 1]) - us(ct[3072 + 2 * k])) for k in range(T)]
 gaps = [(us(ct[3072 + 2 * (k + 1)]) - us(ct[3072 + 2 * k + 1])) for k in range(T - 1)]
 print(f"pivot duration mean {np.mean(pdur):.1f} us (min {np.min(pdur):.1f} max {np.max(pdur):.1f}); gap to the next pivot mean {np.mean(gaps):.1f} us (median {np.median(gaps):.1f}, max {np.max(gaps):.1f})")
 print("block k: [rel. to pivot k-1 end] owner waits for crit[k-2] from .. to | follower of row k saw crit[k-2] | owner saw last panel of L(k,k-1) | pivot k start || first-row Late(k-1) tasks: start / stage-2 in / loop done / end")
-for k in list(range(2, 8)) + list(range(8, T - 3, 6)):
+for k in (list(range(2, T - 3)) if T <= 32 else list(range(2, 8)) + list(range(8, T - 3, 6))):
     pe = us(ct[3072 + 2 * (k - 1) + 1])
     lt = rows.get(k - 1)
     ls = " ".join(f"[{us(r[1]) - pe:.0f}/{us(r[4]) - pe:.0f}/{us(r[5]) - pe:.0f}/{us(r[2]) - pe:.0f}]" for r in lt) if lt is not None else ""
