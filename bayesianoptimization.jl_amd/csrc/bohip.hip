@@ -1115,7 +1115,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
     fl.nsf = g_chol_nsf;
     hipLaunchKernelGGL(k_chol_chain, dim3(9 + g_chol_nsf + 6), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
     HIPCHK(hipGetLastError());
-    if (T > 3) {
+    if (T > 3 || g->ex_qbeg[EX_NQ] > 0) {   // (T = 2, 3: no factorisation task, but the inverse's rows)
         ExQueues q{};
         q.tasks = g->dex_tasks;
         for (int i = 0; i <= EX_NQ; ++i) q.qbeg[i] = g->ex_qbeg[i];
@@ -1144,7 +1144,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
     hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
     HIPCHK(hipGetLastError());
     g->w_seeded = true;
-    g->w_done = T > 3 && g->ex_qbeg[EX_QROWS + 1] > g->ex_qbeg[EX_QROWS];
+    g->w_done = g->ex_qbeg[EX_QROWS + 1] > g->ex_qbeg[EX_QROWS];
     return 0;
 }
 
@@ -1205,16 +1205,18 @@ static int refit_once(bohip_gp* g, double jitter) {
     // (the chain's fill the LDS): the chain's 8-9 (+ solve followers), form 1's T - 3 row followers and 2 (T - 3) column
     // updaters.  On a device (or partition: CPX mode exposes 32 CUs) that cannot hold them the launch chain is used.
     const int cus = device_cus();
-    const bool df_size = (g_chol_df == 1 && T >= 3 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP);
+    const bool df_size = (g_chol_df == 1 && T >= 2 && T <= g_chol_df_tmax) || (g_chol_df == 2 && T >= 2 && T <= CHOL_DF_TCAP);
     bool paused = false;
     if (df_size)   // the pause after a time-out counts refits that WOULD have used a dataflow form, nothing else
         for (int sk = g_chol_df_skip.load(std::memory_order_relaxed); sk > 0;)
             if (g_chol_df_skip.compare_exchange_weak(sk, sk - 1, std::memory_order_relaxed)) { paused = true; break; }
     const bool want_df = !paused && df_size;
-    const int exec_min = g_chol_exec_min >= 0 ? g_chol_exec_min : (g_chol_inv_g > 0 ? 4 : 32);
-    const bool exec_ok = g_chol_exec && T >= std::max(4, exec_min) && cus >= 9 + g_chol_nsf + 6 + 8;
+    // (from TWO row tiles on with the inverse queues: at T = 2, 3 the executor has no factorisation task at all -- every tile is inside the
+    // chain kernel's window -- but it grows W = L^-1 behind the chain: N = 200 0.15 instead of 0.21 ms, N = 300 0.20 instead of 0.28)
+    const int exec_min = g_chol_exec_min >= 0 ? g_chol_exec_min : (g_chol_inv_g > 0 ? 2 : 32);
+    const bool exec_ok = g_chol_exec && T >= std::max(g_chol_inv_g > 0 ? 2 : 4, exec_min) && cus >= 9 + g_chol_nsf + 6 + 8;
     const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
-    const bool form1_ok = cus >= 8 + 3 * std::max(0, T - 3) + 8;
+    const bool form1_ok = T >= 3 && cus >= 8 + 3 * std::max(0, T - 3) + 8;
     // (stage name: with the executor's inverse queues the factorisation and W = L^-1 are ONE stage)
     t_begin(g, want_df && exec_ok && g_chol_inv_g > 0 ? "cholesky+inverse" : "cholesky");
     if (want_df && (exec_ok || form2_ok || form1_ok)) {

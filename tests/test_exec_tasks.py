@@ -259,7 +259,7 @@ def replay(T, order, seed=0, inv_g=INV_G):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < 1e-12, err
     if inv_g > 0:   # the inverse queue: W = L^-1 in the lower triangle of W, the same entries in the upper triangle of W'
-        assert qbeg[NQ] > qbeg[NQ - 1] and qbeg[4] > qbeg[3]
+        assert qbeg[4] > qbeg[3] and (qbeg[NQ] > qbeg[NQ - 1]) == (T > inv_g + 1)   # (a wave needs a whole chunk of rows above it)
         Wref = np.linalg.inv(ref)
         W = np.tril(mats[BASE_W][:N, :N])
         assert not np.isnan(W).any()
@@ -271,7 +271,7 @@ def replay(T, order, seed=0, inv_g=INV_G):
 
 
 @pytest.mark.parametrize("order", ["tasks_first", "low_priority_first", "chain_first", "random"])
-@pytest.mark.parametrize("T", [4, 5, 9, 14])
+@pytest.mark.parametrize("T", [2, 3, 4, 5, 9, 14])
 def test_executor_records_replay_to_the_cholesky_factor(T, order):
     replay(T, order)
 
