@@ -259,6 +259,7 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
     # candidates, BOHIP_INFO_SCORE_LAUNCHES) -- `launches` arrives in `extra` from the caller that holds the handle
     launches = int((extra or {}).pop("_launches", 0)) or max(1, -(-R_GPU // 4096))
     clock_mhz = int((extra or {}).pop("_clock_mhz", 0))
+    spd = int((extra or {}).pop("_shards_per_device", 1))   # logical shards that share one device run one after the other
     flops_per_launch = (R_GPU / launches) * (N_OBS * N_OBS + 2.0 * N_OBS)  # triangular contraction + mu row
     tg_ms = tg_ms / launches
     achieved = flops_per_launch / (tg_ms * 1e-3) / 1e12
@@ -289,7 +290,7 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
                      "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_source": traffic_source,
                      "avg_launch_ms": tg_ms, "flops_per_launch": flops_per_launch, "launches_per_step": launches,
-                     "step_over_kernel": ms_per_step / (tg_ms * launches),
+                     "step_over_kernel": ms_per_step / (tg_ms * launches * spd),
                      # MI355X clocks to its power budget (MI355X_MICROARCH.md, DVFS): `peak` is the 2.4 GHz figure; the clock the chip
                      # actually sustained under this kernel during the timed region is measured inside the kernel (every 33rd workgroup
                      # counts core-clock cycles against the 100 MHz wall clock)
@@ -469,8 +470,8 @@ def main_single_process(args):
     mode = f"one process, {len(devices)} device(s) x {spd} shard(s), in-library RCCL {model.info(_lib.MGP_INFO_RCCL_VERSION)}"
     n_launch = C.c_int64(0)
     lib.bohip_gp_info(g0, _lib.INFO_SCORE_LAUNCHES, C.byref(n_launch))
-    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, {"_launches": int(n_launch.value)},
-           n_devices=len(devices))
+    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode,
+           {"_launches": int(n_launch.value), "_shards_per_device": spd}, n_devices=len(devices))
 
 
 def default_usage(model, tau):
