@@ -7,6 +7,10 @@
 // Reference call sites replaced: update!/append!/fit! in src/models/gp.jl:11-18 (GaussianProcesses.jl
 // update_cK! + ElasticPDMats Cholesky behind them).
 #include "gemm_core.h"
+#include <utility>
+#ifndef BOHIP_FACTOR16_ROWDPP
+#define BOHIP_FACTOR16_ROWDPP 1   // factor16: row J's entries reach the lanes of a 16-row by DPP row_newbcast (1) or ds_swizzle (0)
+#endif
 
 namespace bohip {
 
@@ -272,6 +276,13 @@ __device__ __forceinline__ double row_bcast16(double v) {   // value of lane J o
     hi = __builtin_amdgcn_ds_swizzle(hi, (J << 5) | 0x10);
     return __hiloint2double(hi, lo);
 }
+template <int J>
+__device__ __forceinline__ double row_bcast16_dpp(double v) {   // the same value by DPP row_newbcast: a VALU move, no trip through the LDS crossbar
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double lane_fetch(double v, int byte_addr) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_ds_bpermute(byte_addr, lo);
@@ -301,6 +312,39 @@ __device__ __forceinline__ void factor16_step(double (&v)[4], int r, int q, doub
     if (q == QJ) v[EJ] = lr;                       // column J is final: L[r][J] for r > J (rows <= J: dead entries)
     if (lane == J + 16 * QJ) { dl[P + J] = ajj * inv; idl[P + J] = inv; }
 }
+// The same step with nothing but arithmetic and lane exchanges in it: the diagonal and its reciprocal (lane-uniform) stay in registers
+// until the block is done, a non-positive pivot is remembered and reported once at the end -- no divergent branch (two per step before:
+// `if (lane == ...)` around two LDS writes, `if (!(ajj > 0))` around the atomic) between a pivot and the next.
+template <int J>
+__device__ __forceinline__ void factor16_step_nb(double (&v)[4], int r, int q, double (&dj)[16], double (&ij)[16], int& bad) {
+    constexpr int QJ = J >> 2, EJ = J & 3;
+    double ajj = readlane_f64(v[EJ], J + 16 * QJ);
+    const double arj = lane_fetch(v[EJ], 4 * (r + 16 * QJ));
+    double ajk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ajk[e] = BOHIP_FACTOR16_ROWDPP ? row_bcast16_dpp<J>(v[e]) : row_bcast16<J>(v[e]);
+    const bool ok = ajj > 0.0;
+    bad = (!ok && bad == 0) ? J + 1 : bad;
+    ajj = ok ? ajj : 1.0;
+    const double inv = fast_rsqrt(ajj);
+    const double lr = arj * inv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double lk = ajk[e] * inv;
+        if (4 * q + e > J) v[e] -= lr * lk;   // (forced into a select -- every lane computes, the lanes right of column J keep -- it was slower: 6500 against 5500 cycles per block)
+    }
+    if (q == QJ) v[EJ] = lr;
+    dj[J] = ajj * inv;
+    ij[J] = inv;
+}
+template <int... Js>
+__device__ __forceinline__ void factor16_steps_nb(double (&v)[4], int r, int q, double (&dj)[16], double (&ij)[16], int& bad,
+                                                  std::integer_sequence<int, Js...>) {
+    (factor16_step_nb<Js>(v, r, q, dj, ij, bad), ...);
+}
+#ifndef BOHIP_FACTOR16_NOBRANCH
+#define BOHIP_FACTOR16_NOBRANCH 1
+#endif
 #ifndef BOHIP_FACTOR16_SWIZZLE
 #define BOHIP_FACTOR16_SWIZZLE 1   // 1 (default): the 64-lane form above; 0: the 16-lane DPP form below (round-4 experiment, same speed)
 #endif
@@ -352,6 +396,21 @@ __device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int
         const int k = 4 * q + e;
         v[e] = (k <= r) ? a[(P + r) * PF_LD + P + k] : a[(P + k) * PF_LD + P + r];   // lower triangle, mirrored into the upper
     }
+#if BOHIP_FACTOR16_NOBRANCH
+    {
+        double dj[16], ij[16];
+        int bad = 0;
+        factor16_steps_nb(v, r, q, dj, ij, bad, std::make_integer_sequence<int, 16>{});
+        double dmine = 0.0, imine = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            dmine = lane == j ? dj[j] : dmine;
+            imine = lane == j ? ij[j] : imine;
+        }
+        if (lane < 16) { dl[P + lane] = dmine; idl[P + lane] = imine; }
+        if (bad != 0 && lane == 0) atomicCAS(info, 0, row0 + P + bad);
+    }
+#else
     factor16_step<0>(v, r, q, dl, idl, P, lane, info, row0);   factor16_step<1>(v, r, q, dl, idl, P, lane, info, row0);
     factor16_step<2>(v, r, q, dl, idl, P, lane, info, row0);   factor16_step<3>(v, r, q, dl, idl, P, lane, info, row0);
     factor16_step<4>(v, r, q, dl, idl, P, lane, info, row0);   factor16_step<5>(v, r, q, dl, idl, P, lane, info, row0);
@@ -360,6 +419,7 @@ __device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int
     factor16_step<10>(v, r, q, dl, idl, P, lane, info, row0);  factor16_step<11>(v, r, q, dl, idl, P, lane, info, row0);
     factor16_step<12>(v, r, q, dl, idl, P, lane, info, row0);  factor16_step<13>(v, r, q, dl, idl, P, lane, info, row0);
     factor16_step<14>(v, r, q, dl, idl, P, lane, info, row0);  factor16_step<15>(v, r, q, dl, idl, P, lane, info, row0);
+#endif
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int k = 4 * q + e;
