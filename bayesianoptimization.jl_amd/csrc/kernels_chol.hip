@@ -326,76 +326,88 @@ __device__ __forceinline__ void publish_panel(double* __restrict__ Lblk, int64_t
     if (tid < 128) st_agent2(w16_out + 2 * tid, w16s[2 * tid], w16s[2 * tid + 1]);   // 256 entries, 16 bytes per store
 }
 
-// ---- forward substitution against a 16 x 16 pivot block on the lanes of a QUAD (used by pivot_block) ----------------------
+// ---- forward substitution against a 16 x 16 pivot block on LPR lanes per row (used by pivot_block) ----------------------------------
+// Lane p of a group of LPR (= 2 or 4) neighbouring lanes holds the entries k = p + LPR j of its row.  The owner of entry C finishes it, a DPP
+// quad_perm move hands it to the group, everybody updates the entries it holds.
+#ifndef BOHIP_FSUB_LPR
+#define BOHIP_FSUB_LPR 4   // measured: 2 lanes per row (four waves, 150 registers of pivot-block entries per lane) 1.36 ms at N = 3000, 4 lanes (seven waves) 1.33-1.35
+#endif
+constexpr int FSUB_LPR = BOHIP_FSUB_LPR, FSUB_NJ = 16 / FSUB_LPR;
 template <int S>
-__device__ __forceinline__ double quad_bcast(double v) {   // the value lane S of this lane's quad holds (DPP quad_perm: a VALU move, no LDS)
-    constexpr int ctrl = S | (S << 2) | (S << 4) | (S << 6);
+__device__ __forceinline__ double group_bcast(double v) {   // the value lane S of this lane's group holds (DPP quad_perm: a VALU move, no LDS)
+    constexpr int ctrl = FSUB_LPR == 4 ? (S | (S << 2) | (S << 4) | (S << 6)) : (S | (S << 2) | ((2 + S) << 4) | ((2 + S) << 6));
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
     hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-// The pivot block's entries a lane needs -- L16[q + 4 j][C] for the steps C that still reach slot j, and 1 / diag -- are ALL fetched before
-// the first step (one round of LDS reads, ~50 registers): inside the steps nothing but the product, the quad broadcast and the updates is
-// left on the dependent chain (fetched where they were used, every step waited for its own LDS round trip: 2.0 us instead of 2.4, not 1).
-struct QuadL16 {
-    double l[16][4], id[16];
+// The pivot block's entries a lane needs -- L16[p + LPR j][C] for the steps C that still reach slot j, and 1 / diag -- are ALL fetched before
+// the first step (one round of LDS reads): inside the steps nothing but the product, the group broadcast and the updates is left on the
+// dependent chain (fetched where they were used, every step waited for its own LDS round trip).
+struct GroupL16 {
+    double l[16][FSUB_NJ], id[16];
 };
-__device__ __forceinline__ void quad_l16_load(const double* a, const double* idl, int P, int q, QuadL16& L) {
+__device__ __forceinline__ void group_l16_load(const double* a, const double* idl, int P, int p, GroupL16& L) {
 #pragma unroll
     for (int C = 0; C < 16; ++C) {
         L.id[C] = idl[P + C];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) L.l[C][j] = (4 * j + 3 <= C) ? 0.0 : a[(P + C) * PF_LD + P + q + 4 * j];
+        for (int j = 0; j < FSUB_NJ; ++j) L.l[C][j] = (FSUB_LPR * j + FSUB_LPR - 1 <= C) ? 0.0 : a[(P + C) * PF_LD + P + p + FSUB_LPR * j];
     }
 }
-// one row below the pivot block:  x L16' = a[i][P .. P+15].  Lane q of the quad holds the row's entries k = q + 4 j in rw[j].
-// Step C: x_C = rw_C / L_CC (owner: lane C & 3), written to the image as column P + C; then rw_k -= x_C L16[k][C] for every k > C.
+// one row below the pivot block:  x L16' = a[i][P .. P+15].
+// Step C: x_C = rw_C / L_CC (owner: lane C % LPR), written to the image as column P + C; then rw_k -= x_C L16[k][C] for every k > C.
 template <int C>
-__device__ __forceinline__ void quad_fsub_row_step(double* a, int P, int i, bool on, int q, double (&rw)[4], const QuadL16& L) {
-    const double x = quad_bcast<(C & 3)>(rw[C >> 2] * L.id[C]);
-    if (on && q == (C & 3)) a[(P + C) * PF_LD + i] = x;
+__device__ __forceinline__ void group_fsub_row_step(double* a, int P, int i, bool on, int p, double (&rw)[FSUB_NJ], const GroupL16& L) {
+    const double x = group_bcast<(C % FSUB_LPR)>(rw[C / FSUB_LPR] * L.id[C]);
+    if (on && p == (C % FSUB_LPR)) a[(P + C) * PF_LD + i] = x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (4 * j + 3 <= C) continue;   // no lane holds an entry k > C in this slot
-        if (4 * j > C || q + 4 * j > C) rw[j] -= x * L.l[C][j];
+    for (int j = 0; j < FSUB_NJ; ++j) {
+        if (FSUB_LPR * j + FSUB_LPR - 1 <= C) continue;   // no lane holds an entry k > C in this slot
+        if (FSUB_LPR * j > C || p + FSUB_LPR * j > C) rw[j] -= x * L.l[C][j];
     }
+    // (keep the steps apart: left to itself the scheduler sinks every update next to its consumer to save registers, and entry C then waits
+    // for a chain of C dependent FMAs -- the left-looking form's latency with the right-looking form's code)
+    __builtin_amdgcn_sched_barrier(0);
 }
 template <int... Cs>
-__device__ __forceinline__ void quad_fsub_row_steps(double* a, int P, int i, bool on, int q, double (&rw)[4], const QuadL16& L,
-                                                    std::integer_sequence<int, Cs...>) {
-    (quad_fsub_row_step<Cs>(a, P, i, on, q, rw, L), ...);
+__device__ __forceinline__ void group_fsub_row_steps(double* a, int P, int i, bool on, int p, double (&rw)[FSUB_NJ], const GroupL16& L,
+                                                     std::integer_sequence<int, Cs...>) {
+    (group_fsub_row_step<Cs>(a, P, i, on, p, rw, L), ...);
 }
-__device__ __forceinline__ void quad_fsub_rows(double* a, const double* idl, int P, int i, bool on, int q) {
-    double rw[4];
+__device__ __forceinline__ void group_fsub_rows(double* a, const double* idl, int P, int i, bool on, int p) {
+    double rw[FSUB_NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rw[j] = on ? a[i * PF_LD + P + q + 4 * j] : 0.0;
-    QuadL16 L;
-    quad_l16_load(a, idl, P, q, L);
-    quad_fsub_row_steps(a, P, i, on, q, rw, L, std::make_integer_sequence<int, 16>{});
+    for (int j = 0; j < FSUB_NJ; ++j) rw[j] = on ? a[i * PF_LD + P + p + FSUB_LPR * j] : 0.0;
+    GroupL16 L;
+    group_l16_load(a, idl, P, p, L);
+    group_fsub_row_steps(a, P, i, on, p, rw, L, std::make_integer_sequence<int, 16>{});
 }
-// column cc of W16 = L16^-1 (right-looking: w_k is final, every later partial sum takes its term at once).  Lane q holds the partial
-// sums of the rows i = q + 4 j.
+// column cc of W16 = L16^-1 (right-looking: w_k is final, every later partial sum takes its term at once).  Lane p holds the partial
+// sums of the rows i = p + LPR j.
 template <int K>
-__device__ __forceinline__ void quad_fsub_w16_step(double* w16s, int cc, int q, double (&sacc)[4], const QuadL16& L) {
-    const double w_own = (K < cc) ? 0.0 : (K == cc ? L.id[K] : -sacc[K >> 2] * L.id[K]);   // (meaningful in the owner lane K & 3)
-    const double wk = quad_bcast<(K & 3)>(w_own);
-    if (q == (K & 3)) w16s[K * 16 + cc] = wk;
+__device__ __forceinline__ void group_fsub_w16_step(double* w16s, int cc, int p, double (&sacc)[FSUB_NJ], const GroupL16& L) {
+    const double w_own = (K < cc) ? 0.0 : (K == cc ? L.id[K] : -sacc[K / FSUB_LPR] * L.id[K]);   // (meaningful in the owner lane K % LPR)
+    const double wk = group_bcast<(K % FSUB_LPR)>(w_own);
+    if (p == (K % FSUB_LPR)) w16s[K * 16 + cc] = wk;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (4 * j + 3 <= K) continue;
-        if (4 * j > K || q + 4 * j > K) sacc[j] += L.l[K][j] * wk;
+    for (int j = 0; j < FSUB_NJ; ++j) {
+        if (FSUB_LPR * j + FSUB_LPR - 1 <= K) continue;
+        if (FSUB_LPR * j > K || p + FSUB_LPR * j > K) sacc[j] += L.l[K][j] * wk;
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 template <int... Ks>
-__device__ __forceinline__ void quad_fsub_w16_steps(double* w16s, int cc, int q, double (&sacc)[4], const QuadL16& L, std::integer_sequence<int, Ks...>) {
-    (quad_fsub_w16_step<Ks>(w16s, cc, q, sacc, L), ...);
+__device__ __forceinline__ void group_fsub_w16_steps(double* w16s, int cc, int p, double (&sacc)[FSUB_NJ], const GroupL16& L, std::integer_sequence<int, Ks...>) {
+    (group_fsub_w16_step<Ks>(w16s, cc, p, sacc, L), ...);
 }
-__device__ __forceinline__ void quad_fsub_w16(const double* a, const double* idl, double* w16s, int P, int cc, int q) {
-    double sacc[4] = {0.0, 0.0, 0.0, 0.0};
-    QuadL16 L;
-    quad_l16_load(a, idl, P, q, L);
-    quad_fsub_w16_steps(w16s, cc, q, sacc, L, std::make_integer_sequence<int, 16>{});
+__device__ __forceinline__ void group_fsub_w16(const double* a, const double* idl, double* w16s, int P, int cc, int p) {
+    double sacc[FSUB_NJ];
+#pragma unroll
+    for (int j = 0; j < FSUB_NJ; ++j) sacc[j] = 0.0;
+    GroupL16 L;
+    group_l16_load(a, idl, P, p, L);
+    group_fsub_w16_steps(w16s, cc, p, sacc, L, std::make_integer_sequence<int, 16>{});
 }
 
 __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, double* __restrict__ Lblk, int64_t ld,
@@ -410,16 +422,17 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
         const int P = 16 * jb;
         const int base = P + 16, m = TILE - base;
         // Phase A: W16 = inverse of the pivot block (for the followers) on wave 4 beside the row solves below the pivot block on the other
-        // seven waves -- FOUR LANES per column of W16 / per row (quad_fsub_*: lane q of a quad holds the entries q, q + 4, q + 8, q + 12; the
-        // owner of entry c finishes it, a DPP quad broadcast hands it to the other three, everybody updates the entries it holds).  Until
+        // waves -- LPR = 4 LANES per column of W16 / per row (group_fsub_*: lane p of a group holds the entries p, p + 4, ...; the
+        // owner of entry c finishes it, a DPP quad_perm move hands it to the group, everybody updates the entries it holds; two lanes per row
+        // were measured too: the same 1.9 us -- a step is ~22 wave instructions either way and issue-bound).  Until
         // round 4 one thread per row / column walked all 16 steps with 136 broadcast LDS reads in its dependent chain: 2.4 us of a 6.15 us
         // panel for a few hundred flops per thread.  Same operations in the same order per entry: the factor does not change by a bit.
         if (wave == 4) {
-            quad_fsub_w16(a, idl, w16s, P, lane >> 2, lane & 3);
+            if (lane < 16 * FSUB_LPR) group_fsub_w16(a, idl, w16s, P, lane / FSUB_LPR, lane % FSUB_LPR);
             if (tid == PF_THREADS && k_blk == 1) CH_MARK(3584 + 8 * jb + 5);
         } else {
-            const int t4 = wave < 4 ? tid : tid - 64, ri = t4 >> 2;
-            quad_fsub_rows(a, idl, P, base + ri, ri < m, t4 & 3);
+            const int t4 = wave < 4 ? tid : tid - 64, ri = t4 / FSUB_LPR;
+            if (t4 < FSUB_LPR * (TILE - 16)) group_fsub_rows(a, idl, P, base + ri, ri < m, t4 % FSUB_LPR);   // (whole waves in or out)
             if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 6);
         }
         __syncthreads();
