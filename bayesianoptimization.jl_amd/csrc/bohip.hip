@@ -313,6 +313,7 @@ static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind th
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
 static int g_chol_exec_urgent = 32; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
+static int g_chol_exec_nbu = 2;      // BOHIP_CHOL_EXEC_NBU: rows behind the solve followers whose row step (Solve, Late) sits in the urgent queue
 static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: 112 up to 48 row tiles, none above)
 static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue in earliest-deadline order from a host-side simulation (round-4 experiment: same total, see exec_task_list)
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
@@ -371,6 +372,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_BULK_EDF")) g_chol_exec_bulk_edf = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_FAST")) g_chol_exec_fast = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_NBU")) g_chol_exec_nbu = std::max(0, std::min(16, atoi(e)));
     if (const char* e = getenv("BOHIP_CHUNK_ROWS")) g_chunk_rows_forced = atoll(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_HALVE")) {   // "lo,hi": row tiles lo <= rt < hi go as two 64-row halves ("0,0": none)
         int a = 0, b = 0;
@@ -829,7 +831,7 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
         // queue: what paces the whole factorisation is the latency pivot k -> inverse -> Solve -> Late of the row that enters the
         // follower window next (chain period ~ 69 us + that latency - ~29 us), and in the ordinary queue that row's two steps wait
         // for a free workgroup twice and run beside bulk work.  Everything further out is queue 1.
-        const int NBU = 2, rb = k + 3 + CH_NSF;   // first row solved by the executor
+        const int NBU = g_chol_exec_nbu, rb = k + 3 + CH_NSF;   // first row solved by the executor
         auto solve_row = [&](int qi, int i) {
             add(qi, Ap(i, k), Wkk, Sp(i, k), nullptr, CPB / 2, CPB, false, 0,
                 {{widx(fl.solved + k), 1u}, {k >= 1 ? ver(i, k) : EX_NONE, 16u * (unsigned)(nb(k) + 1)}}, sver(i, k), EX_NONE);
