@@ -330,15 +330,17 @@ __device__ __forceinline__ void publish_panel(double* __restrict__ Lblk, int64_t
 // Lane p of a group of LPR (= 2 or 4) neighbouring lanes holds the entries k = p + LPR j of its row.  The owner of entry C finishes it, a DPP
 // quad_perm move hands it to the group, everybody updates the entries it holds.
 #ifndef BOHIP_FSUB_LPR
-#define BOHIP_FSUB_LPR 4   // measured: 2 lanes per row (four waves, 150 registers of pivot-block entries per lane) 1.36 ms at N = 3000, 4 lanes (seven waves) 1.33-1.35
+#define BOHIP_FSUB_LPR 4   // measured: 2 lanes per row (four waves, 150 registers of pivot-block entries per lane) 1.36 ms at N = 3000, 4 lanes (seven waves) 1.33-1.35;
+                          // since the owner keeps x in its slot the 2-lane form no longer fits 256 registers (it spills, and the chain kernel then times out)
 #endif
 constexpr int FSUB_LPR = BOHIP_FSUB_LPR, FSUB_NJ = 16 / FSUB_LPR;
+static_assert(FSUB_LPR == 4, "the two-lane form needs more than 256 registers (see above)");
 template <int S>
 __device__ __forceinline__ double group_bcast(double v) {   // the value lane S of this lane's group holds (DPP quad_perm: a VALU move, no LDS)
     constexpr int ctrl = FSUB_LPR == 4 ? (S | (S << 2) | (S << 4) | (S << 6)) : (S | (S << 2) | ((2 + S) << 4) | ((2 + S) << 6));
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, true);   // (old = the source itself: no zero to materialise; every lane has a source lane)
+    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // The pivot block's entries a lane needs -- L16[p + LPR j][C] for the steps C that still reach slot j, and 1 / diag -- are ALL fetched before
@@ -360,7 +362,7 @@ __device__ __forceinline__ void group_l16_load(const double* a, const double* id
 template <int C>
 __device__ __forceinline__ void group_fsub_row_step(double* a, int P, int i, bool on, int p, double (&rw)[FSUB_NJ], const GroupL16& L) {
     const double x = group_bcast<(C % FSUB_LPR)>(rw[C / FSUB_LPR] * L.id[C]);
-    if (on && p == (C % FSUB_LPR)) a[(P + C) * PF_LD + i] = x;
+    rw[C / FSUB_LPR] = (p == (C % FSUB_LPR)) ? x : rw[C / FSUB_LPR];   // the owner keeps x_C in the slot it no longer needs: written out after the last step
 #pragma unroll
     for (int j = 0; j < FSUB_NJ; ++j) {
         if (FSUB_LPR * j + FSUB_LPR - 1 <= C) continue;   // no lane holds an entry k > C in this slot
@@ -382,6 +384,10 @@ __device__ __forceinline__ void group_fsub_rows(double* a, const double* idl, in
     GroupL16 L;
     group_l16_load(a, idl, P, p, L);
     group_fsub_row_steps(a, P, i, on, p, rw, L, std::make_integer_sequence<int, 16>{});
+    if (on) {   // x_k for k = p + LPR j: column P + k of the image, row i
+#pragma unroll
+        for (int j = 0; j < FSUB_NJ; ++j) a[(P + p + FSUB_LPR * j) * PF_LD + i] = rw[j];
+    }
 }
 // column cc of W16 = L16^-1 (right-looking: w_k is final, every later partial sum takes its term at once).  Lane p holds the partial
 // sums of the rows i = p + LPR j.

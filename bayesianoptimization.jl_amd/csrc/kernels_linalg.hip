@@ -279,8 +279,8 @@ __device__ __forceinline__ double row_bcast16(double v) {   // value of lane J o
 template <int J>
 __device__ __forceinline__ double row_bcast16_dpp(double v) {   // the same value by DPP row_newbcast: a VALU move, no trip through the LDS crossbar
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + J, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + J, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_fetch(double v, int byte_addr) {
