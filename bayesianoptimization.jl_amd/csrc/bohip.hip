@@ -314,10 +314,10 @@ static int g_chol_nsf = 3;         // solve-follower workgroups of the chain ker
 static int g_chol_exec_urgent = 32; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
 static int g_chol_exec_nbu = 2;      // BOHIP_CHOL_EXEC_NBU: rows behind the solve followers whose row step (Solve, Late) sits in the urgent queue
-static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: 112 up to 48 row tiles, none above)
+static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: where CUs hold two executor workgroups and the chain paces, 33 ... 48 row tiles: up to 112)
 static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue in earliest-deadline order from a host-side simulation (round-4 experiment: same total, see exec_task_list)
 static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
-static int g_chol_exec_wgs = 512; // executor workgroups (BOHIP_CHOL_EXEC_WGS): two per CU
+static int g_chol_exec_wgs = -1;  // executor workgroups (BOHIP_CHOL_EXEC_WGS); -1: by size -- ONE per free CU up to 32 row tiles, two from 45 on (see cholesky_exec)
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int64_t g_chunk_rows_forced = 0;   // BOHIP_CHUNK_ROWS: candidates per K*' chunk (tools: chunk-size sweeps), 0 = the rule in chunk_rows
 static int g_halve_lo = -1, g_halve_hi = -1;   // BOHIP_TRIGEMM_HALVE (see trigemm_pieces)
@@ -1130,9 +1130,16 @@ static int cholesky_exec(bohip_gp* g, int T) {
         // executor workgroups: two per CU that the chain kernel leaves free (a small partition must not fill its slots with the
         // urgent queue's own workgroups: nobody would serve the other queues until the time-out)
         const int cus_free = std::max(1, device_cus() - (9 + g_chol_nsf + 6));
-        const int exec_wgs = std::max(2, std::min(g_chol_exec_wgs, 2 * cus_free));
+        // How many: two per CU share the CU's matrix pipe -- more throughput (N = 10^4: 14.5 against 15.6 ms for the bare task list), but every
+        // task takes ~1.6x as long beside a busy neighbour, and at chain-paced sizes that is what the pivot chain waits for (the row steps
+        // Solve -> Late of the rows about to enter its window): with ONE workgroup per CU the refit at N = 3000 takes 1.43 instead of 1.61 ms,
+        // N = 4000 2.13 instead of 2.38; from N = 6000 on two per CU win (4.55 against 5.2).  Swept at T = 8 ... 47
+        // (profiles/r04_exec_workgroups_by_size.txt): 1 per CU up to 32 row tiles, 2 from 45 on, linear in between.
+        const double per_cu = T <= 32 ? 1.0 : (T >= 45 ? 2.0 : 1.0 + (T - 32) / 13.0);
+        const int exec_wgs = std::max(2, g_chol_exec_wgs > 0 ? std::min(g_chol_exec_wgs, 2 * cus_free) : (int)(per_cu * cus_free + 0.5));
         q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));   // queue 0 is served by these only: never zero
-        q.nfast = std::max(0, std::min(exec_wgs / 4, g_chol_exec_fast >= 0 ? g_chol_exec_fast : (T <= 48 ? 112 : 0)));
+        // (with one workgroup per CU nobody slows a neighbour down and the reserve buys nothing: 1.43 ms at N = 3000 with 0, 30 or 59 of them)
+        q.nfast = std::max(0, std::min(exec_wgs / 4, g_chol_exec_fast >= 0 ? g_chol_exec_fast : (T <= 48 && per_cu > 1.0 ? (int)(112 * (per_cu - 1.0)) : 0)));
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
         q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
         q.fill_inv = g_chol_exec_fill_inv;
@@ -2815,7 +2822,7 @@ int bohip_debug_exec_throughput(bohip_gp* g, unsigned qmask, int hot, int wgs, d
     q.ld = g->ld;
     q.spin_ticks = g_chol_spin_ticks;
     q.fill = g_chol_exec_fill;
-    const int exec_wgs = wgs > 0 ? wgs : std::max(2, std::min(g_chol_exec_wgs, 2 * std::max(1, device_cus() - (9 + g_chol_nsf + 6))));
+    const int exec_wgs = wgs > 0 ? wgs : std::max(2, std::min(g_chol_exec_wgs > 0 ? g_chol_exec_wgs : 1 << 20, 2 * std::max(1, device_cus() - (9 + g_chol_nsf + 6))));
     q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));
     q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
     q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;

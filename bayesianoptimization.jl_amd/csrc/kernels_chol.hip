@@ -916,6 +916,9 @@ __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, i
         }
         release_wg();
         __syncthreads();
+#ifdef BOHIP_INV_DELAY_TICKS   // (sensitivity experiment: publish the inverse this many 10 ns ticks late)
+        if (tid == 0) { const unsigned long long t0_ = wall_clock64(); while (wall_clock64() - t0_ < BOHIP_INV_DELAY_TICKS) __builtin_amdgcn_s_sleep(1); }
+#endif
         if (tid == 0) { flag_set(fl.solved + k, 1u); CH_MARK(4096 + k); }
     }
 }
