@@ -313,6 +313,8 @@ static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind th
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
 static int g_chol_exec_urgent = 32; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
+static int g_chol_exec_second = 1;   // BOHIP_CHOL_EXEC_SECOND=0: every executor workgroup serves every queue (until round 4).  1: the workgroups beyond one per CU take
+                                     // throughput work only (early sums, bulk, waves) and leave when it is exhausted: N = 6000 4.60 -> 4.38 ms, N = 5000 3.27 -> 3.18
 static int g_chol_exec_nbu = 2;      // BOHIP_CHOL_EXEC_NBU: rows behind the solve followers whose row step (Solve, Late) sits in the urgent queue
 static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: where CUs hold two executor workgroups and the chain paces, 33 ... 48 row tiles: up to 112)
 static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue in earliest-deadline order from a host-side simulation (round-4 experiment: same total, see exec_task_list)
@@ -372,6 +374,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_BULK_EDF")) g_chol_exec_bulk_edf = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_FAST")) g_chol_exec_fast = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_EXEC_SECOND")) g_chol_exec_second = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_NBU")) g_chol_exec_nbu = std::max(0, std::min(16, atoi(e)));
     if (const char* e = getenv("BOHIP_CHUNK_ROWS")) g_chunk_rows_forced = atoll(e);
     if (const char* e = getenv("BOHIP_TRIGEMM_HALVE")) {   // "lo,hi": row tiles lo <= rt < hi go as two 64-row halves ("0,0": none)
@@ -1138,6 +1141,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
         const double per_cu = T <= 32 ? 1.0 : (T >= 45 ? 2.0 : 1.0 + (T - 32) / 13.0);
         const int exec_wgs = std::max(2, g_chol_exec_wgs > 0 ? std::min(g_chol_exec_wgs, 2 * cus_free) : (int)(per_cu * cus_free + 0.5));
         q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));   // queue 0 is served by these only: never zero
+        q.second_from = g_chol_exec_second && exec_wgs > cus_free ? cus_free : 0;
         // (with one workgroup per CU nobody slows a neighbour down and the reserve buys nothing: 1.43 ms at N = 3000 with 0, 30 or 59 of them)
         q.nfast = std::max(0, std::min(exec_wgs / 4, g_chol_exec_fast >= 0 ? g_chol_exec_fast : (T <= 48 && per_cu > 1.0 ? (int)(112 * (per_cu - 1.0)) : 0)));
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);

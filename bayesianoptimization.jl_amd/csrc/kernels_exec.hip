@@ -89,6 +89,7 @@ struct ExQueues {
     int64_t ld;
     unsigned long long spin_ticks;   // a workgroup that finds no runnable task for this long gives up (see flag_wait_ge)
     int nurgent;                // workgroups 0 .. nurgent-1 serve the urgent queue (and nothing else until it is exhausted)
+    int second_from;            // > 0: workgroups from this index on take only early sums, bulk and wave tasks (see k_chol_exec)
     int nfast;                  // the next nfast workgroups never take bulk or wave tasks: whatever the chain will need soon (queues 1-3) finds
                                 // one of them free.  Chain-paced sizes only: with every general workgroup inside a 60-100 us bulk / wave task
                                 // right after a group's release, the row steps waited that long and the pivot chain with them
@@ -380,8 +381,12 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                                // workgroup holding one goes on claiming everywhere else
     __shared__ unsigned s_tp, s_tp3;   // when the records in `pend` / `pend3` were claimed (low word of the wall clock)
     __shared__ int s_urgent;
+    // queues this workgroup may ever claim from.  The workgroups from `second_from` on are (as dispatched) the SECOND ones of their CUs: they
+    // take throughput work only (early sums, bulk, waves) and leave when that is exhausted, so that what remains at the end -- the inverse's
+    // row-to-row chain -- runs one workgroup per CU
     const unsigned lane_mask = ((int)blockIdx.x >= q.nurgent && (int)blockIdx.x < q.nurgent + q.nfast)
-                                   ? ~((1u << EX_QBULK) | (1u << EX_QWAVE)) : ~0u;   // queues this workgroup may ever claim from
+                                   ? ~((1u << EX_QBULK) | (1u << EX_QWAVE))
+                                   : (q.second_from > 0 && (int)blockIdx.x >= q.second_from ? ((1u << 2) | (1u << EX_QBULK) | (1u << EX_QWAVE)) : ~0u);
     if (threadIdx.x == 0) { s_look = -1; s_pend = -1; s_pend2 = -1; s_pend2n = 0; s_pend3 = -1; s_tp = 0u; s_tp3 = 0u; s_urgent = (int)blockIdx.x < q.nurgent; }
     __syncthreads();
     // The urgent queue (~10 tasks per block: what the chain kernel reads next) has its own workgroups: each takes the next urgent
