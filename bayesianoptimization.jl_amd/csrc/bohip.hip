@@ -1142,6 +1142,8 @@ static int cholesky_exec(bohip_gp* g, int T) {
         const int exec_wgs = std::max(2, g_chol_exec_wgs > 0 ? std::min(g_chol_exec_wgs, 2 * cus_free) : (int)(per_cu * cus_free + 0.5));
         q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));   // queue 0 is served by these only: never zero
         q.second_from = g_chol_exec_second && exec_wgs > cus_free ? cus_free : 0;
+        // (idling the 32 second workgroups that are dispatched as the urgent workgroups' CU mates was measured: the lost throughput costs more,
+        // N = 8000 8.85 against 8.60 ms, N = 10^4 alone 9.4 against 9.1)
         // (with one workgroup per CU nobody slows a neighbour down and the reserve buys nothing: 1.43 ms at N = 3000 with 0, 30 or 59 of them)
         q.nfast = std::max(0, std::min(exec_wgs / 4, g_chol_exec_fast >= 0 ? g_chol_exec_fast : (T <= 48 && per_cu > 1.0 ? (int)(112 * (per_cu - 1.0)) : 0)));
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
