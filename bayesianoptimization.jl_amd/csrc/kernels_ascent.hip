@@ -38,12 +38,36 @@ __device__ __forceinline__ double asc_wsum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// The same sum when only the lanes k < d (one coordinate each) hold anything but zero -- every inner product of the ascent's step.
+// __shfl_xor is two ds_bpermute_b32 per level, a trip through the LDS crossbar each: k_asc_step was 384 of them in 192 dependent round
+// trips (32 sums x 6 levels), ~7 us for a few hundred flops.  Here the levels that matter (lane distance < the power of two above d) are
+// DPP moves -- quad_perm for 1 and 2, row_shl / row_shr with complementary bank masks for 4 and 8 (checked lane for lane on the chip) --
+// in the butterfly's own order, largest distance first, and lane 0's total is handed to every lane with one readlane: the value is the
+// butterfly's bit for bit (its upper levels only ever added zeros).  d > 16 (more than one DPP row): the butterfly itself.
+template <int CTRL_A, int BANK_A, int CTRL_B, int BANK_B>
+__device__ __forceinline__ double asc_dpp_pair(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int l2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL_A, 0xf, BANK_A, false), h2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL_A, 0xf, BANK_A, false);
+    if constexpr (CTRL_B != 0) {
+        l2 = __builtin_amdgcn_update_dpp(l2, lo, CTRL_B, 0xf, BANK_B, false);
+        h2 = __builtin_amdgcn_update_dpp(h2, hi, CTRL_B, 0xf, BANK_B, false);
+    }
+    return __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double asc_csum(double v, int d) {
+    if (d > 16) return asc_wsum(v);
+    if (d > 8) v += asc_dpp_pair<0x108, 0x3, 0x118, 0xc>(v);   // lane ^ 8: row_shl:8 into lanes 0-7, row_shr:8 into lanes 8-15
+    if (d > 4) v += asc_dpp_pair<0x104, 0x5, 0x114, 0xa>(v);   // lane ^ 4
+    if (d > 2) v += asc_dpp_pair<(2 | (3 << 2) | (0 << 4) | (1 << 6)), 0xf, 0, 0>(v);   // lane ^ 2: quad_perm [2, 3, 0, 1]
+    if (d > 1) v += asc_dpp_pair<(1 | (0 << 2) | (3 << 4) | (2 << 6)), 0xf, 0, 0>(v);   // lane ^ 1: quad_perm [1, 0, 3, 2]
+    return readlane_f64(v, 0);
+}
 // Does start point r go on after an iteration that moved it by s (this lane's coordinate, new value xn) and changed the value by
 // df to fn?  NLopt's tests for a maximisation: ftol_rel, ftol_abs on the improvement, xtol_abs on the step (its norm, as before),
 // xtol_rel per coordinate (stop when EVERY |dx_k| <= xtol_rel |x_k|), stopval.  Wave-uniform (the sums are butterflies).
-__device__ __forceinline__ bool asc_goes_on(const AscentState& st, bool on, double s, double xn, double df, double fn, double moved,
+__device__ __forceinline__ bool asc_goes_on(const AscentState& st, int d, bool on, double s, double xn, double df, double fn, double moved,
                                             double ftol_rel, double xtol_abs) {
-    const double n_big = asc_wsum((on && fabs(s) > st.xtol_rel * fabs(xn)) ? 1.0 : 0.0);   // coordinates that moved by more than xtol_rel |x|
+    const double n_big = asc_csum((on && fabs(s) > st.xtol_rel * fabs(xn)) ? 1.0 : 0.0, d);   // coordinates that moved by more than xtol_rel |x|
     return df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs && df > st.ftol_abs && (st.xtol_rel <= 0.0 || n_big > 0.0) &&
            !(fn >= st.stopval);
 }
@@ -98,15 +122,15 @@ __device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, 
         const int slot = (newest - i + ASC_M) % ASC_M;
         const int64_t ho = ((int64_t)slot * R + r) * d + k;
         const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
-        const double sy = asc_wsum(y * s);
+        const double sy = asc_csum(y * s, d);
         rho[i] = sy > 1e-14 ? 1.0 / sy : 0.0;     // (a pair without curvature in the free subspace is skipped)
-        al[i] = rho[i] * asc_wsum(s * q);
+        al[i] = rho[i] * asc_csum(s * q, d);
         q -= al[i] * y;
     }
     if (nh > 0) {
         const int64_t ho = ((int64_t)newest * R + r) * d + k;
         const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
-        const double sy = asc_wsum(s * y), yy = fmax(asc_wsum(y * y), 1e-300);
+        const double sy = asc_csum(s * y, d), yy = fmax(asc_csum(y * y, d), 1e-300);
         q *= sy > 1e-14 ? sy / yy : 1.0;
     }
 #pragma unroll
@@ -115,21 +139,21 @@ __device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, 
         const int slot = (newest - i + ASC_M) % ASC_M;
         const int64_t ho = ((int64_t)slot * R + r) * d + k;
         const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
-        const double b = rho[i] * asc_wsum(y * q);
+        const double b = rho[i] * asc_csum(y * q, d);
         q += (al[i] - b) * s;
     }
     // do not push active constraints outward; fall back to the projected gradient if that is no ascent direction
     double D = q;
     if ((x <= lo && D < 0.0) || (x >= hi && D > 0.0)) D = 0.0;
     const double gp = ((x <= lo && g < 0.0) || (x >= hi && g > 0.0)) ? 0.0 : g;
-    double slope = asc_wsum(on ? gp * D : 0.0);
+    double slope = asc_csum(on ? gp * D : 0.0, d);
     if (!(slope > 0.0)) {
         D = gp;
-        slope = asc_wsum(on ? gp * gp : 0.0);
+        slope = asc_csum(on ? gp * gp : 0.0, d);
     }
     const int active = st.active[r];
     double step = 1.0;
-    if (nh == 0) step = 1.0 / fmax(sqrt(asc_wsum(on ? D * D : 0.0)), 1e-12) * first_step_scale;
+    if (nh == 0) step = 1.0 / fmax(sqrt(asc_csum(on ? D * D : 0.0, d)), 1e-12) * first_step_scale;
     if (!(active && slope > 0.0)) step = 0.0;
     if (on) {
         st.D[o] = D;
@@ -159,7 +183,7 @@ __global__ __launch_bounds__(64) void k_asc_linesearch(AscentState st, int d, co
     const bool on = k < d;
     const int64_t o = (int64_t)r * d + k;
     const double x = on ? st.X[o] : 0.0, xt = on ? st.Xt[o] : 0.0, gp = on ? st.Gp[o] : 0.0;
-    const double dot = asc_wsum(on ? gp * (xt - x) : 0.0);
+    const double dot = asc_csum(on ? gp * (xt - x) : 0.0, d);
     const double ft = st.ft[r], f = st.f[r];
     const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
     if (ok) {
@@ -186,10 +210,10 @@ __global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R,
     const double x = on ? st.X[o] : 0.0, xn = on ? st.Xn[o] : 0.0, g = on ? st.G[o] : 0.0, gn = on ? st.Gn[o] : 0.0;
     const double s = xn - x, y = -(gn - g);
     const double f = st.f[r], fn = st.fn[r], df = fn - f, best_before = st.best_f[r];
-    const double moved = sqrt(asc_wsum(s * s));
-    const bool good = asc_wsum(s * y) > 1e-14;
+    const double moved = sqrt(asc_csum(s * s, d));
+    const bool good = asc_csum(s * y, d) > 1e-14;
     int active = st.active[r];
-    active = (active && asc_goes_on(st, on, s, xn, df, fn, moved, ftol_rel, xtol_abs)) ? 1 : 0;
+    active = (active && asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs)) ? 1 : 0;
     if (on) {
         const int64_t ho = ((int64_t)slot * R + r) * d + k;
         st.S[ho] = good ? s : 0.0;
@@ -236,7 +260,7 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
         yv[i] = on ? st.Y[ho] : 0.0;
     }
     if (active) {
-        const double dot = asc_wsum(on ? gpo * (xt - x) : 0.0);
+        const double dot = asc_csum(on ? gpo * (xt - x) : 0.0, d);
         const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
         if (!ok && bt < 11) {
             const double step = step_old * 0.5;
@@ -247,9 +271,9 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
             const double g = g_old;
             const double xn = ok ? xt : x, gn = ok ? g_trial : g, fn = ok ? ft : f;
             const double s = xn - x, y = -(gn - g), df = fn - f;
-            const double moved = sqrt(asc_wsum(s * s));
-            const bool good = asc_wsum(s * y) > 1e-14;
-            active = asc_goes_on(st, on, s, xn, df, fn, moved, ftol_rel, xtol_abs) ? 1 : 0;
+            const double moved = sqrt(asc_csum(s * s, d));
+            const bool good = asc_csum(s * y, d) > 1e-14;
+            active = asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs) ? 1 : 0;
             const int slot = it % ASC_M;
             const double s_new = good ? s : 0.0, y_new = good ? y : 0.0;
             if (on) {
@@ -293,30 +317,30 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
                 for (int i = 0; i < ASC_M; ++i) {   // newest -> oldest
                     if (i >= nh) break;
                     const double ps = fr ? pair_s(i) : 0.0, py = fr ? pair_y(i) : 0.0;
-                    const double sy = asc_wsum(py * ps);
+                    const double sy = asc_csum(py * ps, d);
                     rho[i] = sy > 1e-14 ? 1.0 / sy : 0.0;
-                    al[i] = rho[i] * asc_wsum(ps * q);
+                    al[i] = rho[i] * asc_csum(ps * q, d);
                     q -= al[i] * py;
                 }
                 {
                     const double sf = fr ? s_new : 0.0, yf = fr ? y_new : 0.0;
-                    const double sy = asc_wsum(sf * yf), yy = fmax(asc_wsum(yf * yf), 1e-300);
+                    const double sy = asc_csum(sf * yf, d), yy = fmax(asc_csum(yf * yf, d), 1e-300);
                     q *= sy > 1e-14 ? sy / yy : 1.0;
                 }
 #pragma unroll
                 for (int i = ASC_M - 1; i >= 0; --i) {   // oldest -> newest
                     if (i >= nh) continue;
                     const double ps = fr ? pair_s(i) : 0.0, py = fr ? pair_y(i) : 0.0;
-                    const double b = rho[i] * asc_wsum(py * q);
+                    const double b = rho[i] * asc_csum(py * q, d);
                     q += (al[i] - b) * ps;
                 }
                 double D = q;
                 if ((xn <= lo && D < 0.0) || (xn >= hi && D > 0.0)) D = 0.0;
                 const double gp = ((xn <= lo && gn < 0.0) || (xn >= hi && gn > 0.0)) ? 0.0 : gn;
-                double slope = asc_wsum(on ? gp * D : 0.0);
+                double slope = asc_csum(on ? gp * D : 0.0, d);
                 if (!(slope > 0.0)) {
                     D = gp;
-                    slope = asc_wsum(on ? gp * gp : 0.0);
+                    slope = asc_csum(on ? gp * gp : 0.0, d);
                 }
                 if (slope > 0.0) {
                     if (on) {
