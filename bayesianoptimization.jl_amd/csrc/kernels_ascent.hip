@@ -62,6 +62,16 @@ __device__ __forceinline__ double asc_csum(double v, int d) {
     if (d > 1) v += asc_dpp_pair<(1 | (0 << 2) | (3 << 4) | (2 << 6)), 0xf, 0, 0>(v);   // lane ^ 1: quad_perm [1, 0, 3, 2]
     return readlane_f64(v, 0);
 }
+// A sum over all 64 lanes (k_ascent_wg: a row of W against k*, one partial sum per lane), the same way: four DPP levels inside every row
+// of 16 lanes, then the four row totals from lanes 0, 16, 32, 48.  Wave-uniform result.  (The association differs from the butterfly's --
+// rows first --: the one-workgroup form agrees with the batched kernels to rounding, as it always did, not bit for bit.)
+__device__ __forceinline__ double asc_wsum_dpp(double v) {
+    v += asc_dpp_pair<(1 | (0 << 2) | (3 << 4) | (2 << 6)), 0xf, 0, 0>(v);
+    v += asc_dpp_pair<(2 | (3 << 2) | (0 << 4) | (1 << 6)), 0xf, 0, 0>(v);
+    v += asc_dpp_pair<0x104, 0x5, 0x114, 0xa>(v);
+    v += asc_dpp_pair<0x108, 0x3, 0x118, 0xc>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
 // Does start point r go on after an iteration that moved it by s (this lane's coordinate, new value xn) and changed the value by
 // df to fn?  NLopt's tests for a maximisation: ftol_rel, ftol_abs on the improvement, xtol_abs on the step (its norm, as before),
 // xtol_rel per coordinate (stop when EVERY |dx_k| <= xtol_rel |x_k|), stopval.  Wave-uniform (the sums are butterflies).
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(AWG_THREADS) void k_ascent_wg(AscWgParams p) {
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const double t = asc_wsum(s[u]);
+                const double t = asc_wsum_dpp(s[u]);
                 if (lane == 0 && kend[u] >= 0) V[i0 + (int64_t)u * AWG_WAVES] = t;
             }
         }
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(AWG_THREADS) void k_ascent_wg(AscWgParams p) {
         {   // q = sum_{i < N} V[i]^2 in a fixed order
             double s = 0.0;
             for (int64_t i = tid; i < N; i += AWG_THREADS) s += V[i] * V[i];
-            s = asc_wsum(s);
+            s = asc_wsum_dpp(s);
             if (lane == 0) red[wave][0] = s;
         }
         for (int64_t j0 = wave; j0 < N; j0 += 4 * AWG_WAVES) {     // U[j] = sum_{i >= j} W'[j][i] V[i], four rows of W' at a time
@@ -503,7 +513,7 @@ __global__ __launch_bounds__(AWG_THREADS) void k_ascent_wg(AscWgParams p) {
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const double t = asc_wsum(s[u]);
+                const double t = asc_wsum_dpp(s[u]);
                 const int64_t j = j0 + (int64_t)u * AWG_WAVES;
                 if (lane == 0 && j < N) U[j] = t;
             }
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(AWG_THREADS) void k_ascent_wg(AscWgParams p) {
 #pragma unroll
         for (int k = 0; k < DT; ++k)
             if (k < d) {
-                const double a = asc_wsum(gm[k]), b = asc_wsum(gv[k]);
+                const double a = asc_wsum_dpp(gm[k]), b = asc_wsum_dpp(gv[k]);
                 if (lane == 0) { red[wave][2 * k] = a; red[wave][2 * k + 1] = b; }
             }
         __syncthreads();
