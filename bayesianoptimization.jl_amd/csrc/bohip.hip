@@ -83,7 +83,7 @@ struct bohip_gp {
     bool w_seeded = false;                        // the diagonal blocks of W were produced during the factorisation (k_chol_inverter)
     ExTask* dex_tasks = nullptr;                  // task records of the executor form (kernels_exec.hip), built once per (buffers, T)
     size_t ex_cap = 0;
-    int ex_T = 0, ex_nsf = 0, ex_inv_g = -1, ex_qbeg[EX_NQ + 1] = {0};
+    int ex_T = 0, ex_nsf = 0, ex_inv_g = -1, ex_grp_min = -1, ex_qbeg[EX_NQ + 1] = {0};
     bool w_done = false;       // the last factorisation also produced W = L^-1 (executor form with its inverse queue)
     // scoring scratch
     double* dKsT = nullptr;
@@ -308,6 +308,7 @@ static int g_chol_exec_min = -1;  // BOHIP_CHOL_EXEC_MIN, row tiles.  Default: 4
 static int g_chol_exec_patience_us = 1000;   // BOHIP_CHOL_EXEC_PATIENCE_US: how long a workgroup only polls a held record before it takes other work meanwhile
 static int g_chol_exec_fill_inv = 1;    // a workgroup waiting for the counters of a claimed task runs inverse-wave tasks meanwhile (BOHIP_CHOL_EXEC_FILL_INV)
 static int g_chol_exec_inv_pairs = 0;   // inverse queue claimed one record (0) or one tile = two records (1) at a time (BOHIP_CHOL_EXEC_INV_PAIRS)
+static int g_chol_inv_grp_min = 40;   // row tiles from which the inverse queues take the GROUP form (exec_task_list); BOHIP_CHOL_INV_GRP_MIN
 static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
                                    // of contraction (BOHIP_CHOL_INV_G; 0 = off: the level-by-level inverse runs after the factorisation)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
@@ -370,6 +371,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL_INV")) g_chol_exec_fill_inv = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_INV_PAIRS")) g_chol_exec_inv_pairs = atoi(e) != 0;
     if (const char* e = getenv("BOHIP_CHOL_INV_G")) g_chol_inv_g = std::min(64, std::max(0, atoi(e)));
+    if (const char* e = getenv("BOHIP_CHOL_INV_GRP_MIN")) g_chol_inv_grp_min = std::max(0, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_BULK_EDF")) g_chol_exec_bulk_edf = atoi(e);
@@ -996,7 +998,111 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
     // in ONE queue with the waves every row waited behind a whole wave).  Counters, 4 words per tile behind the queue cursors:
     // [0] zver = rounds on Z (16 each), [1] zt = Z' complete, [2] wfin.  Everything a record waits for is earlier in its queue, in
     // another queue or the chain's; nothing outside these two queues ever waits for them.
-    if (inv_g > 0) {
+    // GROUP FORM of the two inverse queues (T >= g_chol_inv_grp_min).  Above, every row of W waits for the row before it: last(i) needs
+    // W(i-1, j), product(i) needs last(i) -- two dependent K = 128 records per row, ~117 us under load, T - 1 rows one after the other.  At
+    // N = 10^4 that chain IS the second half of the refit: starved behind the bulk until ~7 ms, then 67 rows x 117 us = 7.8 ms during which
+    // the waves fill in but the end is the chain's (profiles/r04_exec_trace_N10000.txt).  Here the rows of a GROUP of G blocks do not wait
+    // for each other.  With g0 = G g the first block of group g and D_g = L_gg^-1 the group's own triangular block of W:
+    //   D_g                      by the row chain above, restricted to the columns j >= g0 (queue 3: at most G - 1 short row steps, right
+    //                            behind the pivots, nothing else waits inside them)
+    //   P(i, j) = -sum_{k=j}^{g0-1} L(i, k) W(k, j),  j < g0      the waves as above, one round per earlier group m (blocks of group m, pushed
+    //                            to every later row as soon as group m's rows of W are final); the round of group g-1 completes P and
+    //                            also stores P' to the mirror tile (j, i)
+    //   W(i, j) = sum_{k=g0}^{i} W(i, k) P(k, j)                  ONE record per tile half, K = 128 (i - g0 + 1): A = row i of D_g (K-major in W),
+    //                            B = the mirror tiles (j, g0 .. i)
+    // so the serial part is one K = 128 G round + one product per GROUP (~250 us per G rows instead of ~117 us per row), and what runs last
+    // is a full-width product, not a row chain.  Queue 5 order: rounds of group m for the rows of group m+1 first, then the first half of the
+    // far rows, then the products of group m+1 (their inputs were claimed a thousand records earlier), then the other half (which separates
+    // the products from the rounds of group m+1 that need them).  Counters: word 3 of tile (g0, j) counts the completed P' tiles of group g
+    // and column j, word 2 of the same tile its finished products, word 3 of the diagonal tile (g0, g0) the finished tiles of D_g.
+    const bool inv_groups = inv_g >= 2 && T >= g_chol_inv_grp_min;   // (a group of one row has no D_g: nothing would mark W as grown)
+    if (inv_groups) {
+        const int G = inv_g, NG = (T + G - 1) / G;
+        const uint32_t ivb = (uint32_t)chol_inv_word(T);
+        auto iw = [&](int i, int j, int w) { return ivb + (uint32_t)(((size_t)i * T + j) * 4 + w); };
+        auto chain_row = [&](int kk, int r) { return Dep{widx(fl.xp + ((size_t)kk * T + r) * CH_PANELS + (CH_PANELS - 1)), 1u}; };
+        auto l_final = [&](int i, int k) { return i <= k + 2 ? chain_row(k, i) : Dep{sver(i, k), 16u}; };
+        auto w_final = [&](int k, int j) { return k > j ? Dep{iw(k, j, 2), 16u} : Dep{widx(fl.solved + j), 1u}; };   // inside a group
+        auto add_inv = [&](int qi, const double* A, const double* B, double* C, double* CTb, int kc, int mode, std::initializer_list<Dep> deps,
+                           uint32_t s0, uint32_t s1) {
+            for (int h = 0; h < 2; ++h) {
+                ExTask t{};
+                t.A = A; t.B = B + (int64_t)h * CTILE * ld; t.C = C + h * CTILE; t.P = CTb ? CTb + (int64_t)h * CTILE * ld : nullptr;
+                int nd = 0;
+                for (int d = 0; d < EX_NDEP; ++d) { t.dep_idx[d] = EX_NONE; t.dep_want[d] = 0; }
+                for (const Dep& d : deps) {
+                    if (d.idx == EX_NONE || d.want == 0) continue;
+                    t.dep_idx[nd] = d.idx; t.dep_want[nd] = d.want; ++nd;
+                }
+                t.sig_idx[0] = s0; t.sig_idx[1] = s1;
+                t.kc = kc; t.diag_h = -1; t.rmw = mode | (CTb ? 4 : 0); t.prio = 0; t.kc_split = 0;
+                t.dep2_idx[0] = t.dep2_idx[1] = EX_NONE;
+                q[qi].push_back(t);
+            }
+        };
+        auto Wp = [&](int i, int j) { return dW + (int64_t)i * TILE * ld + (int64_t)j * TILE; };
+        auto WTp = [&](int j, int i) { return dWT + (int64_t)j * TILE * ld + (int64_t)i * TILE; };
+        auto rows_of = [&](int g) { return std::min(G, T - G * g); };
+        auto tiles_of = [&](int g) { const int r = rows_of(g); return r * (r - 1) / 2; };
+        auto GP = [&](int g, int j) { return iw(G * g, j, 3); };
+        auto GW = [&](int g, int j) { return iw(G * g, j, 2); };
+        auto GD = [&](int g) { return iw(G * g, G * g, 3); };
+        // D_g: row i's tiles j = g0 .. i-1 -- what is below row i-1 in one piece (needs row i-2), then {i-1}, then the product.
+        // Z(i, j) is summed in the scratch matrix's mirror tile (free since Late consumed its Early sum, long before row i was solved), NOT
+        // in place: the products below read the tiles of D_g through LDS-DMA, and a tile that was written THREE times by workgroups on
+        // different XCDs (Z, Z, then W) is served stale from the reader's L2 every now and then -- nothing else in these queues reads a
+        // location that is written more than once (first version: 1 % errors in W at N = 3000 whenever eight refits shared the device).
+        auto Zp = [&](int i, int j) { return const_cast<double*>(Pp(i, j)); };
+        auto d_partial = [&](int i) {
+            if (i >= T) return;
+            const int g0 = G * (i / G);
+            for (int j = g0; j < i - 1; ++j)
+                add_inv(EX_QROWS, Sp(i, j), WTp(j, j), Zp(i, j), nullptr, (i - 1 - j) * CPB, 2, {l_final(i, i - 2), w_final(i - 2, j)}, iw(i, j, 0), EX_NONE);
+        };
+        auto d_last = [&](int i) {
+            const int g0 = G * (i / G);
+            for (int j = g0; j < i; ++j) {
+                const bool hp = j < i - 1;
+                add_inv(EX_QROWS, Sp(i, i - 1), WTp(j, i - 1), Zp(i, j), Wp(j, i), CPB, hp ? 1 : 2,
+                        {l_final(i, i - 1), w_final(i - 1, j), Dep{hp ? iw(i, j, 0) : EX_NONE, 16u}}, iw(i, j, 0), iw(i, j, 1));
+            }
+        };
+        auto d_product = [&](int i) {
+            const int g = i / G, g0 = G * g;
+            for (int j = g0; j < i; ++j)
+                add_inv(EX_QROWS, Wp(i, i), Wp(j, i), Wp(i, j), WTp(j, i), CPB, 0, {Dep{iw(i, j, 1), 16u}, Dep{widx(fl.solved + i), 1u}}, iw(i, j, 2), GD(g));
+        };
+        for (int i = 1; i < T; ++i) {
+            if ((i + 1) / G == i / G) d_partial(i + 1);
+            if (i % G != 0) { d_last(i); d_product(i); }
+        }
+        // one round: the blocks of group m into P(i, j)
+        auto round = [&](int m, int i, int j) {
+            const int g = i / G, m0 = G * m, m1 = G * (m + 1), a = std::max(j, m0), nbf = j >= m0 ? 0 : m - j / G;
+            const bool fin = m == g - 1;
+            const Dep src = j < m0 ? Dep{GW(m, j), 16u * (unsigned)rows_of(m)} : Dep{GD(m), 16u * (unsigned)tiles_of(m)};
+            add_inv(EX_QWAVE, Sp(i, a), WTp(j, a), Wp(i, j), fin ? Wp(j, i) : nullptr, (m1 - a) * CPB, nbf == 0 ? 2 : 1,
+                    {l_final(i, m1 - 1), src, Dep{widx(fl.solved + m1 - 1), 1u}, Dep{nbf ? iw(i, j, 0) : EX_NONE, 16u * (unsigned)nbf}},
+                    iw(i, j, 0), fin ? GP(g, j) : EX_NONE);
+        };
+        auto products = [&](int g) {
+            const int g0 = G * g, r = rows_of(g);
+            for (int i = g0; i < g0 + r; ++i)
+                for (int j = 0; j < g0; ++j)
+                    add_inv(EX_QWAVE, Wp(i, g0), Wp(j, g0), Wp(i, j), WTp(j, i), (i - g0 + 1) * CPB, 0,
+                            {Dep{GP(g, j), 16u * (unsigned)r}, Dep{GD(g), 16u * (unsigned)tiles_of(g)}, Dep{widx(fl.solved + g0 + r - 1), 1u}}, GW(g, j), EX_NONE);
+        };
+        for (int m = 0; m + 1 < NG; ++m) {
+            const int m1 = G * (m + 1), near_end = std::min(T, m1 + G), far_mid = near_end + (T - near_end + 1) / 2;
+            for (int i = m1; i < near_end; ++i)
+                for (int j = 0; j < m1; ++j) round(m, i, j);
+            for (int i = near_end; i < far_mid; ++i)
+                for (int j = 0; j < m1; ++j) round(m, i, j);
+            products(m + 1);
+            for (int i = far_mid; i < T; ++i)
+                for (int j = 0; j < m1; ++j) round(m, i, j);
+        }
+    } else if (inv_g > 0) {
         const int G = inv_g;
         const uint32_t ivb = (uint32_t)chol_inv_word(T);
         auto iw = [&](int i, int j, int w) { return ivb + (uint32_t)(((size_t)i * T + j) * 4 + w); };
@@ -1092,7 +1198,7 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
     }
 }
 static int build_exec_tasks(bohip_gp* g, int T) {
-    if (g->ex_T == T && g->dex_tasks && g->ex_nsf == g_chol_nsf && g->ex_inv_g == g_chol_inv_g) return 0;
+    if (g->ex_T == T && g->dex_tasks && g->ex_nsf == g_chol_nsf && g->ex_inv_g == g_chol_inv_g && g->ex_grp_min == g_chol_inv_grp_min) return 0;
     std::vector<ExTask> all;
     exec_task_list(g->dL, g->dS, g->dW, g->dWT, g->dchol_flags, g->ld, T, g_chol_nsf, g_chol_inv_g, all, g->ex_qbeg);
     if (all.size() > g->ex_cap) {
@@ -1106,6 +1212,7 @@ static int build_exec_tasks(bohip_gp* g, int T) {
     g->ex_T = T;
     g->ex_nsf = g_chol_nsf;
     g->ex_inv_g = g_chol_inv_g;
+    g->ex_grp_min = g_chol_inv_grp_min;
     return 0;
 }
 
@@ -1145,6 +1252,8 @@ static int cholesky_exec(bohip_gp* g, int T) {
         // (idling the 32 second workgroups that are dispatched as the urgent workgroups' CU mates was measured: the lost throughput costs more,
         // N = 8000 8.85 against 8.60 ms, N = 10^4 alone 9.4 against 9.1)
         // (with one workgroup per CU nobody slows a neighbour down and the reserve buys nothing: 1.43 ms at N = 3000 with 0, 30 or 59 of them)
+        // (36 more workgroups than fit beside the chain -- they start on its 18 CUs when it has ended, at N = 10^4 with 6 ms still to go --
+        // were measured: 15.4-15.6 ms either way.  What ran last then was the inverse's row chain, not a lack of workgroups.)
         q.nfast = std::max(0, std::min(exec_wgs / 4, g_chol_exec_fast >= 0 ? g_chol_exec_fast : (T <= 48 && per_cu > 1.0 ? (int)(112 * (per_cu - 1.0)) : 0)));
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
         q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
@@ -2757,8 +2866,11 @@ int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base
     // one-time setup may not have run yet), and the process-wide setting is left alone
     int nsf = g_chol_nsf;
     if (const char* e = getenv("BOHIP_CHOL_NSF")) nsf = std::min(bohip::CH_NSF_MAX, std::max(1, atoi(e)));
+    const int grp_min = g_chol_inv_grp_min;
+    if (const char* e = getenv("BOHIP_CHOL_INV_GRP_MIN")) g_chol_inv_grp_min = std::max(0, atoi(e));
     exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W),
                    reinterpret_cast<double*>(base_WT), fb, ld, T, nsf, inv_g, all, qb);
+    g_chol_inv_grp_min = grp_min;
     for (int i = 0; i <= bohip::EX_NQ; ++i) qbeg[i] = qb[i];
     const bohip::CholFlags fl = chol_flags_layout_at(fb, nullptr, T);
     const unsigned* ptrs[10] = {fl.panel, fl.solved, fl.crit, fl.rest, fl.col, fl.farall, fl.fol, fl.colall, fl.colr, fl.xp};

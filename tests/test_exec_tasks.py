@@ -23,8 +23,13 @@ BASE_L, BASE_S, BASE_W, BASE_WT = 1 << 44, 2 << 44, 3 << 44, 4 << 44
 INV_G = 2   # blocks per piece of the inverse queue's long contractions (small, so that multi-piece tiles occur at test sizes)
 
 
-def get_tasks(T, ld, inv_g=INV_G):
+def get_tasks(T, ld, inv_g=INV_G, groups=False):
+    """groups: the inverse queues in their group form (the library's choice from BOHIP_CHOL_INV_GRP_MIN row tiles on), else row by row"""
+    import os
+
     from bohip import _lib
+
+    os.environ["BOHIP_CHOL_INV_GRP_MIN"] = "0" if groups else "1000000"
 
     lib = C.CDLL(_lib.LIB_PATH)
     f = lib.bohip_debug_exec_tasks
@@ -37,6 +42,7 @@ def get_tasks(T, ld, inv_g=INV_G):
     buf = np.zeros((n, 16), dtype=np.uint64)
     assert f(T, ld, BASE_L, BASE_S, BASE_W, BASE_WT, inv_g, buf.ctypes.data_as(C.c_void_p), n, qbeg, layout) == n
     names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp", "nsf", "inv", "xp3"]
+    del os.environ["BOHIP_CHOL_INV_GRP_MIN"]
     return buf, list(qbeg), dict(zip(names, layout))
 
 
@@ -54,11 +60,11 @@ def decode(rec):
     return t
 
 
-def replay(T, order, seed=0, inv_g=INV_G):
+def replay(T, order, seed=0, inv_g=INV_G, groups=False):
     ld = TILE * T + 16
     N = TILE * T
     rng = np.random.default_rng(seed)
-    recs, qbeg, lay = get_tasks(T, ld, inv_g)
+    recs, qbeg, lay = get_tasks(T, ld, inv_g, groups)
     tasks = [decode(r) for r in recs]
     # a well-conditioned SPD matrix (kernel matrix of random points + noise), lower triangle only -- as k_build_cov leaves it
     X = rng.random((N, 3))
@@ -78,6 +84,13 @@ def replay(T, order, seed=0, inv_g=INV_G):
     # operands of the contraction engine arrive through LDS-DMA, i.e. through caches nothing invalidates while the kernel runs:
     # a location that was read that way must never be written afterwards
     dma_read = {b: np.zeros((ld, ld), dtype=bool) for b in mats}
+    # ... and the other way round: the executor's workgroups sit on eight XCDs whose L2s do not see each other's stores, so a location
+    # that tasks write MORE THAN ONCE (a sum that grows in place) may be served stale to a later LDS-DMA read -- such locations may
+    # only ever be read through the read-modify-write path (agent-scope loads).  (The first group form of the inverse summed Z in place
+    # in W and read the finished tile as an operand: right in every replay, 1 % off on the device now and then.)  Enforced for W and W';
+    # the trailing-matrix tiles of L are the known exception -- the row solves read them after many rounds, the last of them a
+    # read-modify-write long after the others, and thousands of refits have compared bit for bit (tools/chol_stress.py).
+    writes = {b: np.zeros((ld, ld), dtype=np.uint8) for b in mats}
 
     def view(addr, rows, cols):
         base = addr & ~((1 << 44) - 1)
@@ -90,10 +103,13 @@ def replay(T, order, seed=0, inv_g=INV_G):
         base = addr & ~((1 << 44) - 1)
         r, c = divmod((addr - base) // 8, ld)
         region = dma_read[base][r:r + rows, c:c + cols]
+        wr = writes[base][r:r + rows, c:c + cols]
         if reading:
             region[:] = True
+            assert base == BASE_L or wr.max(initial=0) <= 1, f"LDS-DMA read of a location that tasks wrote more than once: {hex(addr)}"
         else:
             assert not region.any(), f"write to a location an earlier task read through LDS-DMA: {hex(addr)}"
+            np.minimum(wr + 1, 200, out=wr, casting="unsafe")
 
     def tile(base, i, j):
         return mats[base][i * TILE:(i + 1) * TILE, j * TILE:(j + 1) * TILE]
@@ -259,7 +275,10 @@ def replay(T, order, seed=0, inv_g=INV_G):
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < 1e-12, err
     if inv_g > 0:   # the inverse queue: W = L^-1 in the lower triangle of W, the same entries in the upper triangle of W'
-        assert qbeg[4] > qbeg[3] and (qbeg[NQ] > qbeg[NQ - 1]) == (T > inv_g + 1)   # (a wave needs a whole chunk of rows above it)
+        if groups and inv_g >= 2:   # (the group form needs groups of at least two rows)
+            assert qbeg[4] > qbeg[3] and (qbeg[NQ] > qbeg[NQ - 1]) == (T > inv_g)   # (rounds and products from the second group on)
+        else:
+            assert qbeg[4] > qbeg[3] and (qbeg[NQ] > qbeg[NQ - 1]) == (T > inv_g + 1)   # (a wave needs a whole chunk of rows above it)
         Wref = np.linalg.inv(ref)
         W = np.tril(mats[BASE_W][:N, :N])
         assert not np.isnan(W).any()
@@ -279,6 +298,12 @@ def test_executor_records_replay_to_the_cholesky_factor(T, order):
 def test_executor_records_random_orders_mid_size():
     for seed in range(3):
         replay(18, "random", seed=seed, inv_g=(2, 3, 8)[seed])
+
+
+@pytest.mark.parametrize("order", ["tasks_first", "low_priority_first", "chain_first", "random"])
+@pytest.mark.parametrize("T,inv_g", [(2, 2), (3, 2), (5, 2), (9, 2), (14, 3), (18, 8), (19, 4)])
+def test_executor_records_replay_with_the_inverse_in_group_form(T, inv_g, order):
+    replay(T, order, inv_g=inv_g, groups=True)
 
 
 def test_executor_records_without_the_inverse_queue():
