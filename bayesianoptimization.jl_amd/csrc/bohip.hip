@@ -312,7 +312,8 @@ static int g_chol_inv_grp_min = 40;   // row tiles from which the inverse queues
 static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
                                    // of contraction (BOHIP_CHOL_INV_G; 0 = off: the level-by-level inverse runs after the factorisation)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
-static int g_chol_exec_urgent = 32; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT)
+static int g_chol_exec_urgent = -1; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT); -1: 32, and 16 from 56 row tiles on
+                                    // (N = 10^4: 14.0-14.2 against 14.3 ms; 8 starve the chain at N = 6000: 4.75 against 3.95; profiles/r04_inverse_group_form.txt)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
 static int g_chol_exec_second = 1;   // BOHIP_CHOL_EXEC_SECOND=0: every executor workgroup serves every queue (until round 4).  1: the workgroups beyond one per CU take
                                      // throughput work only (early sums, bulk, waves) and leave when it is exhausted: N = 6000 4.60 -> 4.38 ms, N = 5000 3.27 -> 3.18
@@ -1247,7 +1248,7 @@ static int cholesky_exec(bohip_gp* g, int T) {
         // (profiles/r04_exec_workgroups_by_size.txt): 1 per CU up to 32 row tiles, 2 from 45 on, linear in between.
         const double per_cu = T <= 32 ? 1.0 : (T >= 45 ? 2.0 : 1.0 + (T - 32) / 13.0);
         const int exec_wgs = std::max(2, g_chol_exec_wgs > 0 ? std::min(g_chol_exec_wgs, 2 * cus_free) : (int)(per_cu * cus_free + 0.5));
-        q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));   // queue 0 is served by these only: never zero
+        q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent > 0 ? g_chol_exec_urgent : (T >= 56 ? 16 : 32)));   // queue 0 is served by these only: never zero
         q.second_from = g_chol_exec_second && exec_wgs > cus_free ? cus_free : 0;
         // (idling the 32 second workgroups that are dispatched as the urgent workgroups' CU mates was measured: the lost throughput costs more,
         // N = 8000 8.85 against 8.60 ms, N = 10^4 alone 9.4 against 9.1)
@@ -2941,7 +2942,7 @@ int bohip_debug_exec_throughput(bohip_gp* g, unsigned qmask, int hot, int wgs, d
     q.spin_ticks = g_chol_spin_ticks;
     q.fill = g_chol_exec_fill;
     const int exec_wgs = wgs > 0 ? wgs : std::max(2, std::min(g_chol_exec_wgs > 0 ? g_chol_exec_wgs : 1 << 20, 2 * std::max(1, device_cus() - (9 + g_chol_nsf + 6))));
-    q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent));
+    q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent > 0 ? g_chol_exec_urgent : (T >= 56 ? 16 : 32)));
     q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
     q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
     q.fill_inv = g_chol_exec_fill_inv;

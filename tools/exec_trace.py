@@ -118,8 +118,35 @@ for k in list(range(2, 6)) + list(range(6, T - 4, 5)):
         parts.append(txt)
     print(f"{k:4d}: " + "  ".join(parts) + f"   | pivot k start {us(ct[3072 + 2 * k]) - pe:.0f}, end {us(ct[3072 + 2 * k + 1]) - pe:.0f}")
 
+GRP = INV_G >= 2 and T >= int(os.environ.get("BOHIP_CHOL_INV_GRP_MIN", "40"))   # the inverse queues in their group form (exec_task_list)
+if GRP and qb[4] > qb[3]:
+    A_addr = recs[:, 0].astype(np.int64); C_addr = recs[:, 2].astype(np.int64)
+    bS, bW = 2 << 44, 3 << 44
+    rmw = recs.view(np.int32)[:, 24]
+    q3 = np.arange(qb[3], qb[4]); q5 = np.arange(qb[5], qb[6])
+    dprod = q3[(C_addr[q3] >= bW)]                                   # D_g: the products of the short row chain (C in W)
+    drow = ((C_addr[dprod] - bW) // 8 // ld) // 128
+    is_prod = (A_addr[q5] >= bW)                                      # queue 5: group products have their A operand in W, rounds in S
+    prow = ((C_addr[q5] - bW) // 8 // ld) // 128
+    fin = (~is_prod) & ((rmw[q5] & 4) != 0)                           # the round that completes P (stores P' too)
+    print("inverse, group form: group g (rows) | pivot of its last row ends (us) | D_g done | last round into its rows: first start, last end | "
+          "products: first start, last end, records, mean run (all relative to that pivot's end)")
+    for g in range(0, (T + INV_G - 1) // INV_G):
+        r0, r1 = INV_G * g, min(T, INV_G * (g + 1))
+        pe = us(ct[3072 + 2 * (r1 - 1) + 1])
+        sd = dprod[(drow >= r0) & (drow < r1)]
+        txt = f"{g:3d} ({r0:2d}..{r1 - 1:2d}) | {pe:8.1f} | " + (f"{us(et[sd, 2]).max() - pe:8.1f}" if len(sd) else "       -")
+        sf = q5[fin & (prow >= r0) & (prow < r1)]
+        sp = q5[is_prod & (prow >= r0) & (prow < r1)]
+        txt += " | " + (f"{us(et[sf, 1]).min() - pe:8.1f} {us(et[sf, 2]).max() - pe:8.1f}" if len(sf) else "       -        -")
+        txt += " | " + (f"{us(et[sp, 1]).min() - pe:8.1f} {us(et[sp, 2]).max() - pe:8.1f} {len(sp):5d} {dur[sp].mean():6.1f}" if len(sp) else "       -")
+        print(txt)
+    rd = q5[~is_prod]
+    print(f"rounds: {len(rd)} records, mean run {dur[rd].mean():.1f} us, look+wait {look[rd].mean():.1f}; products: {int(is_prod.sum())} records, "
+          f"mean run {dur[q5[is_prod]].mean():.1f} us, look+wait {look[q5[is_prod]].mean():.1f}")
+
 # the inverse's row chain: per row i, its partial / last / product records (first start .. last end), relative to the end of pivot i
-if qb[4] > qb[3]:
+if qb[4] > qb[3] and not GRP:
     print("inverse row chain: row i | pivot i end (us) | partial: first start, last end | last piece: first start, last end | product: first start, last end   (rel. to pivot i end)")
     Cc = recs[:, 2]
     rws = recs.view(np.int32)[:, 24]
@@ -151,7 +178,7 @@ if qb[4] > qb[3]:
                     print(f"   {nm:8s} j={jj[0]:2d} h={jj[1]} | {us(e[0]) - pe:8.1f} {us(e[1]) - pe:8.1f} {us(e[2]) - pe:8.1f} | wg {int(e[3]):3d} | {ix}")
 
 # the inverse's row chain against the pivots: row i's products W(i, j) = W_ii Z(i, j) (queue 3 records whose A operand is a diagonal tile of W)
-if qb[4] > qb[3]:
+if qb[4] > qb[3] and not GRP:
     A_addr = recs.view(np.uint64)[:, 0].astype(np.int64)
     baseW = 3 << 44
     in_q3 = np.arange(qb[3], qb[4])
