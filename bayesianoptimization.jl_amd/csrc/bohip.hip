@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <queue>
@@ -1217,6 +1218,7 @@ static int build_exec_tasks(bohip_gp* g, int T) {
     return 0;
 }
 
+static std::mutex g_df_mutex[64];   // per device: see refit_once
 static int device_cus();
 static int cholesky_exec(bohip_gp* g, int T) {
     const int64_t ld = g->ld;
@@ -1261,6 +1263,10 @@ static int cholesky_exec(bohip_gp* g, int T) {
         q.fill_inv = g_chol_exec_fill_inv;
         q.patience_ticks = (unsigned)g_chol_exec_patience_us * 100u;
         HIPCHK(hipStreamWaitEvent(g->col_stream, g->ev_panels, 0));
+        // (Holding this launch back until the chain's workgroups are resident -- hipStreamWaitValue32 on a word they count themselves into:
+        // the kernel then starts ~10 us behind them -- was built against the time-outs of refits that share the device with other host
+        // threads' work: it cost 0.1 ms at N = 10^4 and the time-outs stayed.  What causes those is streams of several handles sharing a
+        // hardware queue, where a kernel waits for the END of the one before it; the per-device lock in refit_once removed most of them.)
         hipLaunchKernelGGL(k_chol_exec, dim3(exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g->ev_inv, g->col_stream));
@@ -1345,6 +1351,11 @@ static int refit_once(bohip_gp* g, double jitter) {
     // (stage name: with the executor's inverse queues the factorisation and W = L^-1 are ONE stage)
     t_begin(g, want_df && exec_ok && g_chol_inv_g > 0 ? "cholesky+inverse" : "cholesky");
     if (want_df && (exec_ok || form2_ok || form1_ok)) {
+        // One dataflow refit per device at a time: its persistent workgroups must be resident together, and two refits from two host threads
+        // (several models on one GPU, the logical shards of bohip_mgp_*) take each other's CUs -- every other one then sat out its 200 ms
+        // time-out and fell back (tools/w_stress.py: 6 time-outs in 64 refits on 8 threads).  The refit is synchronous anyway (the abort word is
+        // read back below), so a host lock from the first launch to that read costs nothing a contended chip would not have cost.
+        std::unique_lock<std::mutex> df_lock(g_df_mutex[g->device & 63]);
         g->w_done = false;
         if (exec_ok) { g->chol_form_last = 4; CHK(cholesky_exec(g, T)); }
         else if (form2_ok && g_chol_df2_ll) { g->chol_form_last = 3; CHK(cholesky_dataflow3(g, T)); }
@@ -1366,6 +1377,7 @@ static int refit_once(bohip_gp* g, double jitter) {
         HIPCHK(hipStreamSynchronize(g->stream));
         unsigned aborted = 0;
         HIPCHK(hipMemcpy(&aborted, g->dchol_flags + chol_abort_word(T), sizeof(unsigned), hipMemcpyDeviceToHost));
+        df_lock.unlock();
         if (aborted) {
             // a flag never arrived (e.g. two of the streams share a hardware queue on this system, or a spinning launch kept a
             // persistent workgroup off the chip): every wait has returned, nothing hangs; the factor -- and any pivot failure it
