@@ -1230,6 +1230,11 @@ static int cholesky_exec(bohip_gp* g, int T) {
     fl.nsf = g_chol_nsf;
     hipLaunchKernelGGL(k_chol_chain, dim3(9 + g_chol_nsf + 6), dim3(CH_THREADS), CH_LDS_BYTES, g->stream, g->dL, ld, g->dS, T, fl, g->dinfo, g->dW, g->dWT);
     HIPCHK(hipGetLastError());
+    // The solved panels go home (S -> L) right behind the CHAIN kernel, not behind the executor: every S(i, k) feeds the diagonal tile of its
+    // row, so all of them are final -- and the tiles of L they replace have been read for the last time -- when the last pivot is done, while the
+    // executor still has the second half of W = L^-1 to grow (N = 10^4: 4.4 ms).  The copy runs beside that on the CUs the chain has left.
+    hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
+    HIPCHK(hipGetLastError());
     if (T > 3 || g->ex_qbeg[EX_NQ] > 0) {   // (T = 2, 3: no factorisation task, but the inverse's rows)
         ExQueues q{};
         q.tasks = g->dex_tasks;
@@ -1272,8 +1277,6 @@ static int cholesky_exec(bohip_gp* g, int T) {
         HIPCHK(hipEventRecord(g->ev_inv, g->col_stream));
         HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
     }
-    hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
-    HIPCHK(hipGetLastError());
     g->w_seeded = true;
     g->w_done = g->ex_qbeg[EX_QROWS + 1] > g->ex_qbeg[EX_QROWS];
     return 0;

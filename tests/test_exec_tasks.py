@@ -158,6 +158,7 @@ def replay(T, order, seed=0, inv_g=INV_G, groups=False):
     snap = {}
     heads = [qbeg[q] for q in range(NQ)]
     chain_k = 0   # next block of the chain
+    copied = False
 
     def chain_can_run():
         return chain_k < T and (chain_k == 0 or flags[lay["rest"] + chain_k - 1] >= 24 or chain_k + 2 >= T)
@@ -259,17 +260,26 @@ def replay(T, order, seed=0, inv_g=INV_G, groups=False):
             else:
                 tf_step(pick[1])
         else:
-            run_task(tasks[heads[pick]])
+            t_ = tasks[heads[pick]]
+            if copied:   # the copy S -> L has run: whatever is left (the inverse) must not touch L any more
+                assert all((t_[o] & ~((1 << 44) - 1)) != BASE_L for o in ("A", "B", "C") if t_[o]) and (not t_["P"] or (t_["P"] & ~((1 << 44) - 1)) != BASE_L), \
+                    "a task reads or writes L after the chain kernel has ended"
+            run_task(t_)
             heads[pick] += 1
         steps += 1
+        if not copied and chain_k == T and tf_k == [max(T - 3 - f, 0) for f in range(NSF)] and g3_k == max(T - 3, 0):
+            # k_copy_offdiag_tiles runs right behind the chain KERNEL (cholesky_exec), beside what the executor still has to do: the solved
+            # panels go home now
+            for i in range(T):
+                for j in range(i):
+                    assert not np.isnan(tile(BASE_S, i, j)).any(), f"S({i}, {j}) not solved when the chain kernel ends"
+                    tile(BASE_L, i, j)[:, :] = tile(BASE_S, i, j)
+            copied = True
     assert chain_k == T, f"dead-lock: chain stopped at block {chain_k} of {T}, queue heads {heads} of {qbeg}"
     assert tf_k == [max(T - 3 - f, 0) for f in range(NSF)] and g3_k == max(T - 3, 0)
     assert heads == qbeg[1:], f"records left over: heads {heads}, queues {qbeg}"
-    # k_copy_offdiag_tiles: the solved panels go home
+    assert copied
     L = mats[BASE_L]
-    for i in range(T):
-        for j in range(i):
-            tile(BASE_L, i, j)[:, :] = tile(BASE_S, i, j)
     ref = np.linalg.cholesky(K)
     got = np.tril(L[:N, :N])
     err = np.abs(got - ref).max() / np.abs(ref).max()
