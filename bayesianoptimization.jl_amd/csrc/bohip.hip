@@ -313,6 +313,7 @@ static int g_chol_inv_grp_min = 40;   // row tiles from which the inverse queues
 static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
                                    // of contraction (BOHIP_CHOL_INV_G; 0 = off: the level-by-level inverse runs after the factorisation)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
+static int g_chol_copy_early = 1;   // BOHIP_CHOL_COPY_EARLY=0: the copy S -> L behind the executor instead of behind the chain kernel (cholesky_exec)
 static int g_chol_exec_urgent = -1; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT); -1: 32, and 16 from 56 row tiles on
                                     // (N = 10^4: 14.0-14.2 against 14.3 ms; 8 starve the chain at N = 6000: 4.75 against 3.95; profiles/r04_inverse_group_form.txt)
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
@@ -367,6 +368,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_EXEC_MIN")) g_chol_exec_min = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_PAIRS")) g_chol_exec_pairs = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL")) g_chol_exec_fill = atoi(e);
+    if (const char* e = getenv("BOHIP_CHOL_COPY_EARLY")) g_chol_copy_early = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_URGENT")) g_chol_exec_urgent = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(CH_NSF_MAX, std::max(1, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_EXEC_PATIENCE_US")) g_chol_exec_patience_us = std::max(0, atoi(e));
@@ -1233,8 +1235,10 @@ static int cholesky_exec(bohip_gp* g, int T) {
     // The solved panels go home (S -> L) right behind the CHAIN kernel, not behind the executor: every S(i, k) feeds the diagonal tile of its
     // row, so all of them are final -- and the tiles of L they replace have been read for the last time -- when the last pivot is done, while the
     // executor still has the second half of W = L^-1 to grow (N = 10^4: 4.4 ms).  The copy runs beside that on the CUs the chain has left.
-    hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
-    HIPCHK(hipGetLastError());
+    if (g_chol_copy_early) {
+        hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
+        HIPCHK(hipGetLastError());
+    }
     if (T > 3 || g->ex_qbeg[EX_NQ] > 0) {   // (T = 2, 3: no factorisation task, but the inverse's rows)
         ExQueues q{};
         q.tasks = g->dex_tasks;
@@ -1276,6 +1280,10 @@ static int cholesky_exec(bohip_gp* g, int T) {
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g->ev_inv, g->col_stream));
         HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
+    }
+    if (!g_chol_copy_early) {
+        hipLaunchKernelGGL(k_copy_offdiag_tiles, dim3(T * (T - 1) / 2), dim3(256), 0, g->stream, g->dS, g->dL, ld, T);
+        HIPCHK(hipGetLastError());
     }
     g->w_seeded = true;
     g->w_done = g->ex_qbeg[EX_QROWS + 1] > g->ex_qbeg[EX_QROWS];
