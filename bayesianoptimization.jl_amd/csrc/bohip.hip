@@ -322,7 +322,8 @@ static int g_chol_exec_second = 1;   // BOHIP_CHOL_EXEC_SECOND=0: every executor
 static int g_chol_exec_nbu = 2;      // BOHIP_CHOL_EXEC_NBU: rows behind the solve followers whose row step (Solve, Late) sits in the urgent queue
 static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: where CUs hold two executor workgroups and the chain paces, 33 ... 48 row tiles: up to 112)
 static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue in earliest-deadline order from a host-side simulation (round-4 experiment: same total, see exec_task_list)
-static int g_chol_exec_pairs = 1;  // queues 1 and 2 are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=0: one)
+static int g_chol_exec_pairs = -1; // early sums and bulk updates are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=1; 0: one); p >= 2: the bulk 2 p
+                                    // records (p tiles) per claim.  -1: 1, and 2 from 72 row tiles on (N = 10^4 14.05 -> 13.8 ms, N = 12000 23.1 -> 22.6; N = 8000 the same, N = 6000 4.0 -> 4.25)
 static int g_chol_exec_wgs = -1;  // executor workgroups (BOHIP_CHOL_EXEC_WGS); -1: by size -- ONE per free CU up to 32 row tiles, two from 45 on (see cholesky_exec)
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int64_t g_chunk_rows_forced = 0;   // BOHIP_CHUNK_ROWS: candidates per K*' chunk (tools: chunk-size sweeps), 0 = the rule in chunk_rows
@@ -1267,7 +1268,8 @@ static int cholesky_exec(bohip_gp* g, int T) {
         // (36 more workgroups than fit beside the chain -- they start on its 18 CUs when it has ended, at N = 10^4 with 6 ms still to go --
         // were measured: 15.4-15.6 ms either way.  What ran last then was the inverse's row chain, not a lack of workgroups.)
         q.nfast = std::max(0, std::min(exec_wgs / 4, g_chol_exec_fast >= 0 ? g_chol_exec_fast : (T <= 48 && per_cu > 1.0 ? (int)(112 * (per_cu - 1.0)) : 0)));
-        q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
+        const int pairs_ = g_chol_exec_pairs >= 0 ? g_chol_exec_pairs : (T >= 72 ? 2 : 1);
+        q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = pairs_ ? 2 : 1; q.stride[EX_QBULK] = pairs_ >= 2 ? 2 * std::min(pairs_, 4) : (pairs_ ? 2 : 1);
         q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
         q.fill_inv = g_chol_exec_fill_inv;
         q.patience_ticks = (unsigned)g_chol_exec_patience_us * 100u;
@@ -2966,7 +2968,8 @@ int bohip_debug_exec_throughput(bohip_gp* g, unsigned qmask, int hot, int wgs, d
     q.fill = g_chol_exec_fill;
     const int exec_wgs = wgs > 0 ? wgs : std::max(2, std::min(g_chol_exec_wgs > 0 ? g_chol_exec_wgs : 1 << 20, 2 * std::max(1, device_cus() - (9 + g_chol_nsf + 6))));
     q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent > 0 ? g_chol_exec_urgent : (T >= 56 ? 16 : 32)));
-    q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = g_chol_exec_pairs ? 2 : 1; q.stride[EX_QBULK] = g_chol_exec_pairs >= 2 ? 4 : (g_chol_exec_pairs ? 2 : 1);
+    const int pairs_ = g_chol_exec_pairs >= 0 ? g_chol_exec_pairs : (T >= 72 ? 2 : 1);
+        q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = pairs_ ? 2 : 1; q.stride[EX_QBULK] = pairs_ >= 2 ? 2 * std::min(pairs_, 4) : (pairs_ ? 2 : 1);
     q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
     q.fill_inv = g_chol_exec_fill_inv;
     q.patience_ticks = (unsigned)g_chol_exec_patience_us * 100u;

@@ -876,6 +876,10 @@ print("RESULT" + json.dumps(out))
         # the same without the inverse queues (W = L^-1 level by level after the factorisation), and with short pieces
         "executor-inverse-after": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_G="0"),
         "executor-inverse-pieces-of-2": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_G="2"),
+        # the inverse queues in their GROUP form (the default from 40 row tiles on) forced at every size, groups of 8 and of 3 blocks
+        "executor-inverse-groups": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_GRP_MIN="0"),
+        "executor-inverse-groups-of-3": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_GRP_MIN="0",
+                                             BOHIP_CHOL_INV_G="3"),
     }
     res = {}
     for name, env in variants.items():
