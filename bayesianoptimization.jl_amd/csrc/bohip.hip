@@ -84,6 +84,7 @@ struct bohip_gp {
     bool w_seeded = false;                        // the diagonal blocks of W were produced during the factorisation (k_chol_inverter)
     ExTask* dex_tasks = nullptr;                  // task records of the executor form (kernels_exec.hip), built once per (buffers, T)
     size_t ex_cap = 0;
+    bool ex_bulk4_ok = false;   // the bulk queue may be claimed two tiles at a time (exec_bulk_stride_ok)
     int ex_T = 0, ex_nsf = 0, ex_inv_g = -1, ex_grp_min = -1, ex_qbeg[EX_NQ + 1] = {0};
     bool w_done = false;       // the last factorisation also produced W = L^-1 (executor form with its inverse queue)
     // scoring scratch
@@ -1202,6 +1203,19 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
         qbeg[qi + 1] = (int)all.size();
     }
 }
+// May the bulk queue be claimed `stride` records at a time?  A claim starts when ALL its records' counters are in and runs them back to back,
+// and claims are the consecutive blocks of `stride` records from the queue's start (one fetch-and-add each) -- so no record of a block may wait
+// for another record of the SAME block: that claim would wait for itself.  In the bulk queue that is two rounds on one tile next to each other,
+// which happens where a group has a single tile left (T = 4 m + 9: the last round of the last diagonal tile directly behind the round before).
+static bool exec_bulk_stride_ok(const std::vector<ExTask>& all, const int* qbeg, int stride) {
+    for (int b = qbeg[EX_QBULK]; b < qbeg[EX_QBULK + 1]; b += stride) {
+        const int e = std::min(b + stride, qbeg[EX_QBULK + 1]);
+        for (int x = b; x < e; ++x)
+            for (int y = x + 1; y < e; ++y)
+                if (all[x].C == all[y].C) return false;
+    }
+    return true;
+}
 static int build_exec_tasks(bohip_gp* g, int T) {
     if (g->ex_T == T && g->dex_tasks && g->ex_nsf == g_chol_nsf && g->ex_inv_g == g_chol_inv_g && g->ex_grp_min == g_chol_inv_grp_min) return 0;
     std::vector<ExTask> all;
@@ -1214,6 +1228,7 @@ static int build_exec_tasks(bohip_gp* g, int T) {
     }
     HIPCHK(hipMemcpyAsync(g->dex_tasks, all.data(), all.size() * sizeof(ExTask), hipMemcpyHostToDevice, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));   // `all` is pageable host memory that dies with this frame
+    g->ex_bulk4_ok = exec_bulk_stride_ok(all, g->ex_qbeg, 4);
     g->ex_T = T;
     g->ex_nsf = g_chol_nsf;
     g->ex_inv_g = g_chol_inv_g;
@@ -1268,7 +1283,8 @@ static int cholesky_exec(bohip_gp* g, int T) {
         // (36 more workgroups than fit beside the chain -- they start on its 18 CUs when it has ended, at N = 10^4 with 6 ms still to go --
         // were measured: 15.4-15.6 ms either way.  What ran last then was the inverse's row chain, not a lack of workgroups.)
         q.nfast = std::max(0, std::min(exec_wgs / 4, g_chol_exec_fast >= 0 ? g_chol_exec_fast : (T <= 48 && per_cu > 1.0 ? (int)(112 * (per_cu - 1.0)) : 0)));
-        const int pairs_ = g_chol_exec_pairs >= 0 ? g_chol_exec_pairs : (T >= 72 ? 2 : 1);
+        int pairs_ = g_chol_exec_pairs >= 0 ? g_chol_exec_pairs : (T >= 72 ? 2 : 1);
+        if (pairs_ >= 2 && !(pairs_ == 2 && g->ex_bulk4_ok)) pairs_ = 1;   // (more than two tiles per claim: never checked, never faster)
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = pairs_ ? 2 : 1; q.stride[EX_QBULK] = pairs_ >= 2 ? 2 * std::min(pairs_, 4) : (pairs_ ? 2 : 1);
         q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
         q.fill_inv = g_chol_exec_fill_inv;
@@ -2904,6 +2920,7 @@ int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base
     layout[10] = nsf;
     layout[11] = (int64_t)chol_inv_word(T);
     layout[12] = (int64_t)chol_xp3_word(T);
+    layout[13] = exec_bulk_stride_ok(all, qb, 4) ? 2 : 1;   // bulk tiles per claim the library may use at this T
     if ((int64_t)all.size() <= cap && out) std::memcpy(out, all.data(), all.size() * sizeof(bohip::ExTask));
     return (int64_t)all.size();
 }
@@ -2968,7 +2985,7 @@ int bohip_debug_exec_throughput(bohip_gp* g, unsigned qmask, int hot, int wgs, d
     q.fill = g_chol_exec_fill;
     const int exec_wgs = wgs > 0 ? wgs : std::max(2, std::min(g_chol_exec_wgs > 0 ? g_chol_exec_wgs : 1 << 20, 2 * std::max(1, device_cus() - (9 + g_chol_nsf + 6))));
     q.nurgent = std::max(1, std::min(exec_wgs / 8, g_chol_exec_urgent > 0 ? g_chol_exec_urgent : (T >= 56 ? 16 : 32)));
-    const int pairs_ = g_chol_exec_pairs >= 0 ? g_chol_exec_pairs : (T >= 72 ? 2 : 1);
+    const int pairs_ = g_chol_exec_pairs == 0 ? 0 : 1;
         q.stride[0] = 1; q.stride[1] = 1; q.stride[2] = pairs_ ? 2 : 1; q.stride[EX_QBULK] = pairs_ >= 2 ? 2 * std::min(pairs_, 4) : (pairs_ ? 2 : 1);
     q.stride[EX_QROWS] = q.stride[EX_QWAVE] = g_chol_exec_inv_pairs ? 2 : 1;
     q.fill_inv = g_chol_exec_fill_inv;

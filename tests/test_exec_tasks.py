@@ -41,7 +41,7 @@ def get_tasks(T, ld, inv_g=INV_G, groups=False):
     n = f(T, ld, BASE_L, BASE_S, BASE_W, BASE_WT, inv_g, None, 0, qbeg, layout)
     buf = np.zeros((n, 16), dtype=np.uint64)
     assert f(T, ld, BASE_L, BASE_S, BASE_W, BASE_WT, inv_g, buf.ctypes.data_as(C.c_void_p), n, qbeg, layout) == n
-    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp", "nsf", "inv", "xp3"]
+    names = ["panel", "solved", "crit", "rest", "col", "farall", "fol", "colall", "colr", "xp", "nsf", "inv", "xp3", "bulk_tiles_per_claim"]
     del os.environ["BOHIP_CHOL_INV_GRP_MIN"]
     return buf, list(qbeg), dict(zip(names, layout))
 
@@ -348,3 +348,19 @@ def test_every_tile_gets_every_block_once():
     for (i, c, half), blocks in cover.items():
         want_last = c - 1 if i >= c + 3 else i - 4   # the chain applies the remaining blocks itself (its window spans three rows)
         assert sorted(blocks) == list(range(0, want_last + 1)), ((i, c, half), sorted(blocks), want_last)
+
+
+def test_bulk_claims_of_two_tiles_never_wait_for_themselves():
+    """From 72 row tiles on the bulk queue is claimed two tiles (four records) at a time.  A claim starts when the counters of ALL its
+    records are in, and claims are the consecutive blocks of four records from the queue's start -- so two rounds on ONE tile must never
+    share a block (the claim would wait for itself: 200 ms, then the fall-back).  That happens where a group has a single tile left
+    (T = 4 m + 9); the library checks the record list and goes back to one tile per claim there (`exec_bulk_stride_ok`)."""
+    seen = set()
+    for T in range(60, 97):
+        ld = TILE * T + 16
+        recs, qbeg, lay = get_tasks(T, ld, 8, groups=True)
+        C_ = [int(r[2]) for r in recs[qbeg[4]:qbeg[5]]]
+        ok = all(len(set(C_[b:b + 4])) == len(C_[b:b + 4]) for b in range(0, len(C_), 4))
+        assert lay["bulk_tiles_per_claim"] == (2 if ok else 1), T
+        seen.add(ok)
+    assert seen == {True, False}   # (both cases occur in the range, so the check is alive)
