@@ -167,7 +167,7 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
     best_f, best_X = f.copy(), X.copy()
     while evals < maxeval and active.any():
         # two-loop recursion, vectorised over columns, in the FREE SUBSPACE of every column: a coordinate on a bound with the gradient
-        # pushing outward takes no part (kernels_ascent_step.hip asc_direction_one: 22-35 passes instead of 228-309 on the headline model,
+        # pushing outward takes no part (kernels_ascent.hip asc_direction_one: 22-35 passes instead of 228-309 on the headline model,
         # where UCB peaks in the corners of the box; with no bound active the arithmetic is unchanged)
         free = ~(((X <= lbc) & (G < 0)) | ((X >= ubc) & (G > 0)))
         q = np.where(free, G, 0.0)
@@ -216,7 +216,7 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
         df = fn - f
         moved = np.sqrt(np.einsum("dr,dr->r", s_, s_))
         active = active & (df > ftol_rel * np.maximum(np.abs(fn), 1e-300)) & (moved > xtol_abs)
-        # NLopt's other stop tests (kernels_ascent_step.hip asc_goes_on): ftol_abs, xtol_rel per coordinate, stopval
+        # NLopt's other stop tests (kernels_ascent.hip asc_goes_on): ftol_abs, xtol_rel per coordinate, stopval
         active = active & (df > ftol_abs) & ~(fn >= stopval)
         if xtol_rel > 0.0:
             active = active & (np.abs(s_) > xtol_rel * np.abs(Xn)).any(axis=0)

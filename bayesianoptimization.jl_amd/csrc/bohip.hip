@@ -18,7 +18,6 @@
 #include "kernels_linalg.hip"
 #include "kernels_chol.hip"
 #include "kernels_exec.hip"
-#include "kernels_ascent_step.hip"
 #include "kernels_score.hip"
 #include "kernels_ascent.hip"
 
@@ -115,7 +114,6 @@ struct bohip_gp {
     int64_t batch_hint = 0;      // bohip_gp_set_batch_hint: choose the scoring path as if the batch had at least this many candidates
     double* dsplit = nullptr;    // split-K partial planes (batches of a few hundred candidates)
     int64_t split_cap = 0;
-    AscFuse asc_fuse{};          // set by acquire_max's free-running loop around a pass (score_grad_core takes it where it can)
     double* dgparts = nullptr;   // [SMALL_MAX][16][2 DMAX] split partial sums of k_grad_finish (small batches)
     unsigned* dgcount = nullptr; // per-candidate arrival counters (left at zero by the kernel)
     // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
@@ -316,7 +314,6 @@ static int g_chol_inv_grp_min = 40;   // row tiles from which the inverse queues
 static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
                                    // of contraction (BOHIP_CHOL_INV_G; 0 = off: the level-by-level inverse runs after the factorisation)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
-static int g_asc_fuse_step = 1;     // BOHIP_ASC_FUSE_STEP=0: the ascent's step as its own launch (k_asc_step) everywhere
 static int g_chol_copy_early = 1;   // BOHIP_CHOL_COPY_EARLY=0: the copy S -> L behind the executor instead of behind the chain kernel (cholesky_exec)
 static int g_chol_exec_urgent = -1; // executor workgroups that serve the urgent queue only (BOHIP_CHOL_EXEC_URGENT); -1: 32, and 16 from 56 row tiles on
                                     // (N = 10^4: 14.0-14.2 against 14.3 ms; 8 starve the chain at N = 6000: 4.75 against 3.95; profiles/r04_inverse_group_form.txt)
@@ -373,7 +370,6 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_EXEC_MIN")) g_chol_exec_min = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_PAIRS")) g_chol_exec_pairs = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL")) g_chol_exec_fill = atoi(e);
-    if (const char* e = getenv("BOHIP_ASC_FUSE_STEP")) g_asc_fuse_step = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_COPY_EARLY")) g_chol_copy_early = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_URGENT")) g_chol_exec_urgent = std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(CH_NSF_MAX, std::max(1, atoi(e)));
@@ -2066,11 +2062,7 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
         CHK(launch_rows_trimv(g, g->dWT, N, g->dApp, (int)R, g->dApp + (int64_t)APP_UT_ROW0 * g->ld, 1));
         t_end(g);
         t_begin(g, "grad");
-        GradQ gq{g->dApp, g->ld, std::exp(2.0 * g->logsig), g->beta, g->dmu, g->dvar, d_score, AscFuse{}};
-        if (g->asc_fuse.on == 1 && g_asc_fuse_step && g->asc_fuse.st.Xt == dXs && g->asc_fuse.st.Gt == d_grad && g->asc_fuse.st.ft == d_score) {
-            gq.asc = g->asc_fuse;
-            g->asc_fuse.on = 2;   // taken: the caller does not launch k_asc_step
-        }
+        GradQ gq{g->dApp, g->ld, std::exp(2.0 * g->logsig), g->beta, g->dmu, g->dvar, d_score};
         CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld, gq));
         t_end(g);
         return 0;
@@ -2708,17 +2700,10 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
                 return v - 1;
             };
             for (; evals < maxeval && !out_of_time(); ++e) {
-                // the step of every start point rides in the tail of the pass's last kernel where that is the small-batch gradient kernel
-                // (k_grad_finish, AscFuse); anywhere else it is its own launch
-                g->asc_fuse = AscFuse{1, (int)R, (int)(e % ASC_RING), dlb, dub, ftol_rel, xtol_abs, st};
-                const int rc_pass = score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt);
-                const bool fused = g->asc_fuse.on == 2;
-                g->asc_fuse.on = 0;
-                CHK(rc_pass);
+                CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
                 ++evals;
-                if (!fused)
-                    hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, 0.1 * span, ftol_rel, xtol_abs,
-                                       (int)(e % ASC_RING));
+                hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, 0.1 * span, ftol_rel, xtol_abs,
+                                   (int)(e % ASC_RING));
                 HIPCHK(hipGetLastError());
                 if (e >= LAG) {
                     const int n = read_count(e - LAG);

@@ -1,8 +1,389 @@
-// kernels_ascent.hip -- SURVEY.md section 8(f) N1, second part: the whole ascent of a small model in ONE launch (k_ascent_wg) and the
-// arg-max over the start points (k_asc_final).  State, step functions and the batched kernels: kernels_ascent_step.hip.
+// kernels_ascent.hip -- SURVEY.md section 8(f) N1: the local search of acquire_max (reference src/acquisition.jl:48-68,
+// NLopt :LD_LBFGS with box bounds, :23-35) as a LOCK-STEP projected L-BFGS ascent of all R start points on the device.
+// One wave per start point, lane k = coordinate k (d <= 64), inner products by wave butterflies; the expensive part of an
+// iteration -- value and gradient of the acquisition at R trial points -- is ONE score_grad pass of the model.
+// The state (X, f, G, curvature pairs, best point seen) never leaves HBM; per evaluation the host reads one
+// int per start point from pinned memory to steer the backtracking.
+//   k_asc_start      X <- clip(starts), first trial = X
+//   k_asc_adopt      after the first evaluation: f, G, active, best
+//   k_asc_direction  two-loop recursion over the (<= 8) curvature pairs, bound blocking, first trial point
+//   k_asc_linesearch Armijo test of the trial; on failure halve the step and write the next trial
+//   k_asc_update     curvature pair, convergence tests (ftol_rel, xtol_abs), best point
+//   k_asc_final      arg-max over the start points, strict '>' => first maximum wins (:58-66)
 #include "common.h"
 
 namespace bohip {
+
+constexpr int ASC_M = 8;   // curvature pairs kept
+
+struct AscentState {
+    double *X, *f, *G;          // [R][d], [R], [R][d]   current point
+    double *Xt, *ft, *Gt;       // trial point and its evaluation (Xt is the candidate block of score_grad)
+    double *Xn, *fn, *Gn;       // accepted point of this iteration
+    double *D, *Gp, *step;      // direction, projected gradient, step length
+    double *S, *Y;              // [ASC_M][R][d] curvature pairs (zero rows where s'y was not positive)
+    double *best_f, *best_X;
+    int *active, *accepted;
+    int *h_accepted, *h_active; // pinned host mirrors read by the driver loop
+    // free-running form (k_asc_step): per start point its own iteration count and backtracking count, and per evaluation pass a
+    // ring slot: how many start points are still active after it (device counters + the word the host polls, value + 1)
+    int *it, *bt;
+    unsigned *nact, *ticket;    // nact: [ASC_RING] 64-bit counters (arrivals | active << 32), 8-byte aligned; ticket: unused half
+    int *h_cnt;                 // [ASC_RING] pinned
+    // NLopt's remaining stop criteria (bohip_gp_set_ascent_stop; the reference forwards them, src/acquisition.jl:24-27, and its own
+    // test sets ftol_abs = eps(), test/acquisition.jl:6,9): 0 / 0 / +Inf = off
+    double ftol_abs, xtol_rel, stopval;
+};
+__device__ __forceinline__ double asc_wsum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// The same sum when only the lanes k < d (one coordinate each) hold anything but zero -- every inner product of the ascent's step.
+// __shfl_xor is two ds_bpermute_b32 per level, a trip through the LDS crossbar each: k_asc_step was 384 of them in 192 dependent round
+// trips (32 sums x 6 levels), ~7 us for a few hundred flops.  Here the levels that matter (lane distance < the power of two above d) are
+// DPP moves -- quad_perm for 1 and 2, row_shl / row_shr with complementary bank masks for 4 and 8 (checked lane for lane on the chip) --
+// in the butterfly's own order, largest distance first, and lane 0's total is handed to every lane with one readlane: the value is the
+// butterfly's bit for bit (its upper levels only ever added zeros).  d > 16 (more than one DPP row): the butterfly itself.
+template <int CTRL_A, int BANK_A, int CTRL_B, int BANK_B>
+__device__ __forceinline__ double asc_dpp_pair(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int l2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL_A, 0xf, BANK_A, false), h2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL_A, 0xf, BANK_A, false);
+    if constexpr (CTRL_B != 0) {
+        l2 = __builtin_amdgcn_update_dpp(l2, lo, CTRL_B, 0xf, BANK_B, false);
+        h2 = __builtin_amdgcn_update_dpp(h2, hi, CTRL_B, 0xf, BANK_B, false);
+    }
+    return __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double asc_csum(double v, int d) {
+    if (d > 16) return asc_wsum(v);
+    if (d > 8) v += asc_dpp_pair<0x108, 0x3, 0x118, 0xc>(v);   // lane ^ 8: row_shl:8 into lanes 0-7, row_shr:8 into lanes 8-15
+    if (d > 4) v += asc_dpp_pair<0x104, 0x5, 0x114, 0xa>(v);   // lane ^ 4
+    if (d > 2) v += asc_dpp_pair<(2 | (3 << 2) | (0 << 4) | (1 << 6)), 0xf, 0, 0>(v);   // lane ^ 2: quad_perm [2, 3, 0, 1]
+    if (d > 1) v += asc_dpp_pair<(1 | (0 << 2) | (3 << 4) | (2 << 6)), 0xf, 0, 0>(v);   // lane ^ 1: quad_perm [1, 0, 3, 2]
+    return readlane_f64(v, 0);
+}
+// A sum over all 64 lanes (k_ascent_wg: a row of W against k*, one partial sum per lane), the same way: four DPP levels inside every row
+// of 16 lanes, then the four row totals from lanes 0, 16, 32, 48.  Wave-uniform result.  (The association differs from the butterfly's --
+// rows first --: the one-workgroup form agrees with the batched kernels to rounding, as it always did, not bit for bit.)
+__device__ __forceinline__ double asc_wsum_dpp(double v) {
+    v += asc_dpp_pair<(1 | (0 << 2) | (3 << 4) | (2 << 6)), 0xf, 0, 0>(v);
+    v += asc_dpp_pair<(2 | (3 << 2) | (0 << 4) | (1 << 6)), 0xf, 0, 0>(v);
+    v += asc_dpp_pair<0x104, 0x5, 0x114, 0xa>(v);
+    v += asc_dpp_pair<0x108, 0x3, 0x118, 0xc>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+// Does start point r go on after an iteration that moved it by s (this lane's coordinate, new value xn) and changed the value by
+// df to fn?  NLopt's tests for a maximisation: ftol_rel, ftol_abs on the improvement, xtol_abs on the step (its norm, as before),
+// xtol_rel per coordinate (stop when EVERY |dx_k| <= xtol_rel |x_k|), stopval.  Wave-uniform (the sums are butterflies).
+__device__ __forceinline__ bool asc_goes_on(const AscentState& st, int d, bool on, double s, double xn, double df, double fn, double moved,
+                                            double ftol_rel, double xtol_abs) {
+    const double n_big = asc_csum((on && fabs(s) > st.xtol_rel * fabs(xn)) ? 1.0 : 0.0, d);   // coordinates that moved by more than xtol_rel |x|
+    return df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs && df > st.ftol_abs && (st.xtol_rel <= 0.0 || n_big > 0.0) &&
+           !(fn >= st.stopval);
+}
+constexpr int ASC_RING = 8;
+
+__device__ __forceinline__ double asc_clip(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+__global__ __launch_bounds__(64) void k_asc_start(AscentState st, int d, const double* __restrict__ starts,
+                                                  const double* __restrict__ lb, const double* __restrict__ ub) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    if (k >= d) return;
+    const double x = asc_clip(starts[(int64_t)r * d + k], lb[k], ub[k]);
+    st.X[(int64_t)r * d + k] = x;
+    st.Xt[(int64_t)r * d + k] = x;
+}
+
+__device__ __forceinline__ void asc_adopt_one(const AscentState& st, int r, int k, int d) {
+    const double f = st.ft[r];
+    if (k < d) {
+        st.G[(int64_t)r * d + k] = st.Gt[(int64_t)r * d + k];
+        st.best_X[(int64_t)r * d + k] = st.X[(int64_t)r * d + k];
+    }
+    if (k == 0) {
+        st.f[r] = f;
+        st.best_f[r] = f;
+        const int a = isfinite(f) ? 1 : 0;
+        st.active[r] = a;
+        st.h_active[r] = a;
+    }
+}
+__global__ __launch_bounds__(64) void k_asc_adopt(AscentState st, int d) { asc_adopt_one(st, blockIdx.x, threadIdx.x, d); }
+
+// nh curvature pairs are valid; the newest sits in slot (newest), older ones in the slots before it (ring of ASC_M)
+__device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, int k, int d, int R, int nh, int newest,
+                                                  const double* __restrict__ lb, const double* __restrict__ ub, double first_step_scale) {
+    const bool on = k < d;
+    const int64_t o = (int64_t)r * d + k;
+    const double x = on ? st.X[o] : 0.0, g = on ? st.G[o] : 0.0;
+    const double lo = on ? lb[k] : 0.0, hi = on ? ub[k] : 0.0;
+    // FREE SUBSPACE (round 4): a coordinate that sits on a bound with the gradient pushing outward takes no part in the two-loop
+    // recursion -- not in the vector it starts from and not in the curvature pairs' inner products.  Rounds 1-3 ran the recursion in the
+    // full space and zeroed the blocked components of the result: with many active bounds (UCB at the reference's beta_t ~ 10 peaks in
+    // the corners of the box) that is no quasi-Newton direction of the reduced problem, and the search crawled -- 228-309 evaluation
+    // passes for the headline model's ten starts where this form needs 22-35 and SciPy's L-BFGS-B 24, same or better maxima
+    // (tools/ascent_vs_scipy.py).  With no bound active the arithmetic is the old one, operation for operation.
+    const bool fr = on && !((x <= lo && g < 0.0) || (x >= hi && g > 0.0));
+    double q = fr ? g : 0.0;
+    double al[ASC_M], rho[ASC_M];
+#pragma unroll
+    for (int i = 0; i < ASC_M; ++i) {   // newest -> oldest
+        if (i >= nh) break;
+        const int slot = (newest - i + ASC_M) % ASC_M;
+        const int64_t ho = ((int64_t)slot * R + r) * d + k;
+        const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
+        const double sy = asc_csum(y * s, d);
+        rho[i] = sy > 1e-14 ? 1.0 / sy : 0.0;     // (a pair without curvature in the free subspace is skipped)
+        al[i] = rho[i] * asc_csum(s * q, d);
+        q -= al[i] * y;
+    }
+    if (nh > 0) {
+        const int64_t ho = ((int64_t)newest * R + r) * d + k;
+        const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
+        const double sy = asc_csum(s * y, d), yy = fmax(asc_csum(y * y, d), 1e-300);
+        q *= sy > 1e-14 ? sy / yy : 1.0;
+    }
+#pragma unroll
+    for (int i = ASC_M - 1; i >= 0; --i) {   // oldest -> newest
+        if (i >= nh) continue;
+        const int slot = (newest - i + ASC_M) % ASC_M;
+        const int64_t ho = ((int64_t)slot * R + r) * d + k;
+        const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
+        const double b = rho[i] * asc_csum(y * q, d);
+        q += (al[i] - b) * s;
+    }
+    // do not push active constraints outward; fall back to the projected gradient if that is no ascent direction
+    double D = q;
+    if ((x <= lo && D < 0.0) || (x >= hi && D > 0.0)) D = 0.0;
+    const double gp = ((x <= lo && g < 0.0) || (x >= hi && g > 0.0)) ? 0.0 : g;
+    double slope = asc_csum(on ? gp * D : 0.0, d);
+    if (!(slope > 0.0)) {
+        D = gp;
+        slope = asc_csum(on ? gp * gp : 0.0, d);
+    }
+    const int active = st.active[r];
+    double step = 1.0;
+    if (nh == 0) step = 1.0 / fmax(sqrt(asc_csum(on ? D * D : 0.0, d)), 1e-12) * first_step_scale;
+    if (!(active && slope > 0.0)) step = 0.0;
+    if (on) {
+        st.D[o] = D;
+        st.Gp[o] = gp;
+        st.Xn[o] = x;
+        st.Gn[o] = g;
+        st.Xt[o] = asc_clip(x + step * D, lo, hi);
+    }
+    if (k == 0) {
+        st.step[r] = step;
+        st.fn[r] = st.f[r];
+        const int acc = (!active || !(slope > 0.0)) ? 1 : 0;
+        st.accepted[r] = acc;
+        st.h_accepted[r] = acc;
+    }
+}
+__global__ __launch_bounds__(64) void k_asc_direction(AscentState st, int d, int R, int nh, int newest,
+                                                      const double* __restrict__ lb, const double* __restrict__ ub,
+                                                      double first_step_scale) {
+    asc_direction_one(st, blockIdx.x, threadIdx.x, d, R, nh, newest, lb, ub, first_step_scale);
+}
+
+__global__ __launch_bounds__(64) void k_asc_linesearch(AscentState st, int d, const double* __restrict__ lb,
+                                                       const double* __restrict__ ub) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    if (st.accepted[r]) return;
+    const bool on = k < d;
+    const int64_t o = (int64_t)r * d + k;
+    const double x = on ? st.X[o] : 0.0, xt = on ? st.Xt[o] : 0.0, gp = on ? st.Gp[o] : 0.0;
+    const double dot = asc_csum(on ? gp * (xt - x) : 0.0, d);
+    const double ft = st.ft[r], f = st.f[r];
+    const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
+    if (ok) {
+        if (on) {
+            st.Xn[o] = xt;
+            st.Gn[o] = st.Gt[o];
+        }
+        if (k == 0) {
+            st.fn[r] = ft;
+            st.accepted[r] = 1;
+            st.h_accepted[r] = 1;
+        }
+    } else {
+        const double step = st.step[r] * 0.5;
+        if (on) st.Xt[o] = asc_clip(x + step * st.D[o], lb[k], ub[k]);
+        if (k == 0) st.step[r] = step;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R, int slot, double ftol_rel, double xtol_abs) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    const bool on = k < d;
+    const int64_t o = (int64_t)r * d + k;
+    const double x = on ? st.X[o] : 0.0, xn = on ? st.Xn[o] : 0.0, g = on ? st.G[o] : 0.0, gn = on ? st.Gn[o] : 0.0;
+    const double s = xn - x, y = -(gn - g);
+    const double f = st.f[r], fn = st.fn[r], df = fn - f, best_before = st.best_f[r];
+    const double moved = sqrt(asc_csum(s * s, d));
+    const bool good = asc_csum(s * y, d) > 1e-14;
+    int active = st.active[r];
+    active = (active && asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs)) ? 1 : 0;
+    if (on) {
+        const int64_t ho = ((int64_t)slot * R + r) * d + k;
+        st.S[ho] = good ? s : 0.0;
+        st.Y[ho] = good ? y : 0.0;
+        st.X[o] = xn;
+        st.G[o] = gn;
+        st.Xt[o] = xn;
+        if (fn > best_before) st.best_X[o] = xn;
+    }
+    if (k == 0) {
+        st.f[r] = fn;
+        if (fn > best_before) st.best_f[r] = fn;
+        st.active[r] = active;
+        st.h_active[r] = active;
+    }
+}
+
+// FREE-RUNNING form: one launch per evaluation pass does, for every start point on its own, whatever comes next in ITS iteration --
+// the Armijo test of its trial; on failure the halved step (up to 12 trials, as in the lock-step driver); on success (or after
+// the 12th failure) the update of k_asc_update and at once the next direction of k_asc_direction with its first trial point.
+// A start point's sequence of trial points, values and curvature pairs is exactly that of the lock-step form (its arithmetic
+// never looks at another start point, and a score_grad result does not depend on what else is in the batch), but no start
+// point waits for the slowest line search of the batch, and the HOST takes no decision between two passes: it enqueues pass
+// after pass and reads, two passes behind, how many start points were still active (a pinned word written by the last
+// workgroup of a pass).  Lock-step: five launches + a stream synchronisation per pass, 94-117 us at N = 3000 with 10 starts.
+// (one wave: lane k = coordinate k of start point r; ring_slot < 0: no pass bookkeeping -- the one-workgroup-per-start kernel)
+__device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k, int d, int R, const double* __restrict__ lb,
+                                             const double* __restrict__ ub, double ftol_rel, double xtol_abs, int ring_slot) {
+    const bool on = k < d;
+    const int64_t o = (int64_t)r * d + k;
+    // everything the step may need, in ONE round of loads (taken one by one as the branches reach them they were a chain of
+    // five or six dependent memory round trips: 8 us for a few hundred flops)
+    int active = st.active[r];
+    const double lo = on ? lb[k] : 0.0, hi = on ? ub[k] : 0.0;
+    const double x = on ? st.X[o] : 0.0, xt = on ? st.Xt[o] : 0.0, gpo = on ? st.Gp[o] : 0.0;
+    const double g_old = on ? st.G[o] : 0.0, g_trial = on ? st.Gt[o] : 0.0, d_old = on ? st.D[o] : 0.0;
+    const double ft = st.ft[r], f = st.f[r], step_old = st.step[r], best_before = st.best_f[r];
+    const int bt = st.bt[r], it = st.it[r];
+    double sv[ASC_M], yv[ASC_M];   // the curvature pairs (slot order), also in flight now
+#pragma unroll
+    for (int i = 0; i < ASC_M; ++i) {
+        const int64_t ho = ((int64_t)i * R + r) * d + k;
+        sv[i] = on ? st.S[ho] : 0.0;
+        yv[i] = on ? st.Y[ho] : 0.0;
+    }
+    if (active) {
+        const double dot = asc_csum(on ? gpo * (xt - x) : 0.0, d);
+        const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
+        if (!ok && bt < 11) {
+            const double step = step_old * 0.5;
+            if (on) st.Xt[o] = asc_clip(x + step * d_old, lo, hi);
+            if (k == 0) { st.step[r] = step; st.bt[r] = bt + 1; }
+        } else {
+            // ---- the iteration ends (k_asc_update with Xn = the accepted trial, or X itself after 12 failures)
+            const double g = g_old;
+            const double xn = ok ? xt : x, gn = ok ? g_trial : g, fn = ok ? ft : f;
+            const double s = xn - x, y = -(gn - g), df = fn - f;
+            const double moved = sqrt(asc_csum(s * s, d));
+            const bool good = asc_csum(s * y, d) > 1e-14;
+            active = asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs) ? 1 : 0;
+            const int slot = it % ASC_M;
+            const double s_new = good ? s : 0.0, y_new = good ? y : 0.0;
+            if (on) {
+                const int64_t ho = ((int64_t)slot * R + r) * d + k;
+                st.S[ho] = s_new;
+                st.Y[ho] = y_new;
+                st.X[o] = xn;
+                st.G[o] = gn;
+                if (fn > best_before) st.best_X[o] = xn;
+            }
+            if (k == 0) {
+                st.f[r] = fn;
+                if (fn > best_before) st.best_f[r] = fn;
+                st.it[r] = it + 1;
+                st.bt[r] = 0;
+            }
+            double xt_new = xn;
+            if (active) {
+                // ---- the next direction (k_asc_direction at x = xn, g = gn; the newest pair is the one just written: taken
+                // from registers, the older ones were loaded up front by slot -- every lane reads only elements it wrote itself)
+                const int nh = it + 1 < ASC_M ? it + 1 : ASC_M, newest = slot;
+                auto pair_s = [&](int i) {   // i-th newest pair (i = 0: the one just made)
+                    const int sl = (newest - i + ASC_M) % ASC_M;
+                    double v = 0.0;
+#pragma unroll
+                    for (int t = 0; t < ASC_M; ++t) v = t == sl ? sv[t] : v;
+                    return i == 0 ? s_new : v;
+                };
+                auto pair_y = [&](int i) {
+                    const int sl = (newest - i + ASC_M) % ASC_M;
+                    double v = 0.0;
+#pragma unroll
+                    for (int t = 0; t < ASC_M; ++t) v = t == sl ? yv[t] : v;
+                    return i == 0 ? y_new : v;
+                };
+                // (the free subspace of asc_direction_one: coordinates on a bound with the gradient pushing outward stay out)
+                const bool fr = on && !((xn <= lo && gn < 0.0) || (xn >= hi && gn > 0.0));
+                double q = fr ? gn : 0.0;
+                double al[ASC_M], rho[ASC_M];
+#pragma unroll
+                for (int i = 0; i < ASC_M; ++i) {   // newest -> oldest
+                    if (i >= nh) break;
+                    const double ps = fr ? pair_s(i) : 0.0, py = fr ? pair_y(i) : 0.0;
+                    const double sy = asc_csum(py * ps, d);
+                    rho[i] = sy > 1e-14 ? 1.0 / sy : 0.0;
+                    al[i] = rho[i] * asc_csum(ps * q, d);
+                    q -= al[i] * py;
+                }
+                {
+                    const double sf = fr ? s_new : 0.0, yf = fr ? y_new : 0.0;
+                    const double sy = asc_csum(sf * yf, d), yy = fmax(asc_csum(yf * yf, d), 1e-300);
+                    q *= sy > 1e-14 ? sy / yy : 1.0;
+                }
+#pragma unroll
+                for (int i = ASC_M - 1; i >= 0; --i) {   // oldest -> newest
+                    if (i >= nh) continue;
+                    const double ps = fr ? pair_s(i) : 0.0, py = fr ? pair_y(i) : 0.0;
+                    const double b = rho[i] * asc_csum(py * q, d);
+                    q += (al[i] - b) * ps;
+                }
+                double D = q;
+                if ((xn <= lo && D < 0.0) || (xn >= hi && D > 0.0)) D = 0.0;
+                const double gp = ((xn <= lo && gn < 0.0) || (xn >= hi && gn > 0.0)) ? 0.0 : gn;
+                double slope = asc_csum(on ? gp * D : 0.0, d);
+                if (!(slope > 0.0)) {
+                    D = gp;
+                    slope = asc_csum(on ? gp * gp : 0.0, d);
+                }
+                if (slope > 0.0) {
+                    if (on) {
+                        st.D[o] = D;
+                        st.Gp[o] = gp;
+                    }
+                    if (k == 0) st.step[r] = 1.0;
+                    xt_new = asc_clip(xn + D, lo, hi);
+                } else {
+                    active = 0;   // no ascent direction left: the lock-step form spends one more pass to find s = 0
+                }
+            }
+            if (on) st.Xt[o] = xt_new;
+            if (k == 0) st.active[r] = active;
+        }
+    }
+    if (k == 0 && ring_slot >= 0) {
+        // ONE 64-bit counter per pass: arrivals in the low word, still-active start points in the high word -- no fence between
+        // two counters (a __threadfence() is an L2 write-back here: microseconds per workgroup)
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(st.nact) + ring_slot;
+        const unsigned long long before = atomicAdd(cnt, 1ull + ((unsigned long long)(active ? 1 : 0) << 32));
+        if ((unsigned)(before & 0xffffffffull) == (unsigned)R - 1u) {   // the last workgroup of this pass publishes the count and clears the slot
+            const unsigned n = (unsigned)(before >> 32) + (active ? 1u : 0u);
+            __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.h_cnt + ring_slot, (int)n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host reads nothing else on the strength of it: no release, which would be a cache write-back)
+        }
+    }
+}
+__global__ __launch_bounds__(64) void k_asc_step(AscentState st, int d, int R, const double* __restrict__ lb,
+                                                 const double* __restrict__ ub, double first_step_scale, double ftol_rel,
+                                                 double xtol_abs, int ring_slot) {
+    asc_step_one(st, blockIdx.x, threadIdx.x, d, R, lb, ub, ftol_rel, xtol_abs, ring_slot);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // SMALL MODELS: the whole ascent of one start point inside ONE workgroup, ONE launch for the whole acquire_max.

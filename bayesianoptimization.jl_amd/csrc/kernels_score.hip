@@ -581,23 +581,11 @@ __device__ __forceinline__ void posterior_like_small_finish(double sigma2, doubl
     if (s2 < 0.0) s2 = 0.0;  // predict_f: max(sigma2, 0)
     mu = beta + mu_raw;
 }
-// The free-running ascent's step of start point r (k_asc_step) in the TAIL of this kernel: the workgroup that finishes candidate r's value and
-// gradient -- the only one, or the last of its splits to arrive -- goes on with wave 0 as that start point's step (accept / backtrack / new
-// direction / next trial point, asc_step_one: one wave per start point, lane = coordinate).  A start point never looks at another one, its
-// trial point (this kernel's candidate r) has been read by every split before the last one counts itself in, and the numbers are the
-// separate launch's bit for bit -- one launch and ~9 us per evaluation pass less (acquire_max's loop sets `on`).
-struct AscFuse {
-    int on, R, ring_slot;
-    const double *lb, *ub;
-    double ftol_rel, xtol_abs;
-    AscentState st;
-};
 struct GradQ {
     const double* VT;   // [R][ldv]  V' rows; entry N of a row is mu - beta
     int64_t ldv;
     double sigma2, beta;
     double *mu_out, *var_out, *score_out;
-    AscFuse asc;
 };
 template <int DT>
 __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ X, int64_t N,
@@ -709,10 +697,6 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
         acq_partials(ap, m, v, dmu, ds2);
         // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
         grad[r * d + k] = dmu * a + (v > 0.0 ? ds2 * (-2.0 * b) : 0.0);
-    }
-    if (gq.asc.on && threadIdx.x < 64) {   // (d <= 64: the lanes that wrote value and gradient are this wave's)
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // value and gradient are read back through this CU's L1
-        asc_step_one(gq.asc.st, (int)r, (int)threadIdx.x, d, gq.asc.R, gq.asc.lb, gq.asc.ub, gq.asc.ftol_rel, gq.asc.xtol_abs, gq.asc.ring_slot);
     }
 }
 

@@ -614,7 +614,7 @@ def test_device_ascent_matches_host_restatement(bohip, orc):
 
 
 def test_free_running_ascent_follows_the_lock_step_trajectories():
-    """csrc/kernels_ascent_step.hip k_asc_step: every start point on its own schedule (no host decision between two evaluation
+    """csrc/kernels_ascent.hip k_asc_step: every start point on its own schedule (no host decision between two evaluation
     passes) against the lock-step driver (BOHIP_ASC_LOCKSTEP=1).  A start point's arithmetic never looks at another one, so with
     room to converge the end points and values are identical bit for bit, and the free-running form needs no more passes."""
     import json
