@@ -2666,14 +2666,29 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         t_collect(g);
         return 0;
     }
+    const bool free_run = !g_asc_lockstep;
+    if (free_run) {
+        // (the counters of a pass clear themselves; this is for a call that was cut short -- queued before the start kernel, where the device
+        // waits for the host's copy anyway)
+        HIPCHK(hipMemsetAsync(st.nact, 0, (size_t)2 * ASC_RING * sizeof(unsigned), g->stream));
+        for (int i = 0; i < ASC_RING; ++i) st.h_cnt[i] = 0;
+    }
     hipLaunchKernelGGL(k_asc_start, dim3(nR), dim3(64), 0, g->stream, st, d, g->asc_dio + 2 * d, dlb, dub);
     CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
-    hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(g->stream));
+    bool any_active = true;
+    if (free_run) {
+        // no synchronisation here: how many start points are active at all is counted by the adopt kernel into the ring slot the host reads
+        // once the first pass is queued (below)
+        hipLaunchKernelGGL(k_asc_adopt_count, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, ASC_RING - 1);
+        HIPCHK(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(g->stream));
+        any_active = any_of(st.h_active, 1);
+    }
     int64_t evals = 1;
     int nh = 0, it = 0;
-    bool any_active = any_of(st.h_active, 1);
     const auto t_start = std::chrono::steady_clock::now();
     auto out_of_time = [&]() {   // NLopt's maxtime (reference src/acquisition.jl:24-27 forwards it): checked once per iteration
         return g->asc_maxtime > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= g->asc_maxtime;
@@ -2684,11 +2699,9 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         // LAG passes run beyond convergence.  Same per-start-point trajectories as the lock-step form below.
         const int LAG = 1;   // (2 until round 4: with 17 passes per call instead of 228 a wasted pass is 5 % of it; one queued pass keeps the device fed)
         if (any_active) {
-            HIPCHK(hipMemsetAsync(st.it, 0, (size_t)2 * g->asc_cap * sizeof(int), g->stream));   // it, bt
-            HIPCHK(hipMemsetAsync(st.nact, 0, (size_t)2 * ASC_RING * sizeof(unsigned), g->stream));
-            for (int i = 0; i < ASC_RING; ++i) st.h_cnt[i] = 0;
             hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, 0, 0, dlb, dub, 0.1 * span);
             int64_t e = 0, converged_at = -1;
+            bool none_active = false;
             auto read_count = [&](int64_t pass) -> int {   // active start points after `pass` (waits for it if need be)
                 volatile int* w = st.h_cnt + (pass % ASC_RING);
                 const auto t0 = std::chrono::steady_clock::now();
@@ -2705,6 +2718,11 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
                 hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, 0.1 * span, ftol_rel, xtol_abs,
                                    (int)(e % ASC_RING));
                 HIPCHK(hipGetLastError());
+                if (e == 0) {   // the adopt kernel's count (the device is busy with the first pass meanwhile)
+                    const int n0 = read_count(ASC_RING - 1);
+                    if (n0 < 0) return fail(BOHIP_E_HIP, "device ascent: the first evaluation did not report back within 30 s");
+                    if (n0 == 0) { none_active = true; ++e; break; }   // no start point with a finite value: the queued pass changes nothing
+                }
                 if (e >= LAG) {
                     const int n = read_count(e - LAG);
                     if (n < 0) return fail(BOHIP_E_HIP, "device ascent: an evaluation pass did not report back within 30 s");
@@ -2716,6 +2734,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
                 for (int64_t p2 = std::max<int64_t>(0, e - LAG); p2 < e && converged_at < 0; ++p2)
                     if (st.h_cnt[p2 % ASC_RING] == 1) converged_at = p2;
             if (converged_at >= 0) evals = 2 + converged_at;   // passes that were needed: the first one + passes 0 .. converged_at
+            if (none_active) evals = 1;
         }
     } else {
     while (evals < maxeval && any_active && !out_of_time()) {

@@ -109,6 +109,25 @@ __device__ __forceinline__ void asc_adopt_one(const AscentState& st, int r, int 
     }
 }
 __global__ __launch_bounds__(64) void k_asc_adopt(AscentState st, int d) { asc_adopt_one(st, blockIdx.x, threadIdx.x, d); }
+// The free-running form's adopt: the same, plus this start point's iteration / backtracking counters zeroed (two memset launches per call
+// before) and the number of start points that are active at all counted into ring slot `slot` the way a pass counts (see asc_step_one): the
+// host reads it while the first pass is already queued, where it used to synchronise the stream to look at h_active (~20 us per call).
+__global__ __launch_bounds__(64) void k_asc_adopt_count(AscentState st, int d, int R, int slot) {
+    const int r = blockIdx.x, k = threadIdx.x;
+    asc_adopt_one(st, r, k, d);
+    if (k == 0) {
+        st.it[r] = 0;
+        st.bt[r] = 0;
+        const int active = isfinite(st.ft[r]) ? 1 : 0;
+        unsigned long long* cnt = reinterpret_cast<unsigned long long*>(st.nact) + slot;
+        const unsigned long long before = atomicAdd(cnt, 1ull + ((unsigned long long)active << 32));
+        if ((unsigned)(before & 0xffffffffull) == (unsigned)R - 1u) {
+            const unsigned n = (unsigned)(before >> 32) + (unsigned)active;
+            __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.h_cnt + slot, (int)n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 // nh curvature pairs are valid; the newest sits in slot (newest), older ones in the slots before it (ring of ASC_M)
 __device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, int k, int d, int R, int nh, int newest,
