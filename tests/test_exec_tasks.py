@@ -11,7 +11,11 @@ delivers S(k+3, k)):
   * the replay must never dead-lock, every record must be consumed, and the factor must equal numpy's Cholesky.
 
 A dependency the builder forgot shows up as a wrong factor in the "tasks first" order; a circular or mis-indexed one as a
-dead-lock.  (No GPU needed: this is host logic.)"""
+dead-lock.  Three more rules of the device that a sequential replay would not notice by itself are enforced on the way: a location
+read through LDS-DMA is never written afterwards; W / W' tiles that are read through LDS-DMA are written exactly once (the XCDs' L2s
+do not see each other's stores); and the copy S -> L happens when the chain kernel's roles are done, after which nothing touches L.
+Both forms of the inverse queues are replayed (row by row, and the group form the library uses from 40 row tiles on).
+(No GPU needed: this is host logic.)"""
 import ctypes as C
 
 import numpy as np
