@@ -193,7 +193,7 @@ struct Walker {   // the (row block, chunk) steps of one workgroup, in order (al
 // chunks of 256 contraction indices.  One ring slot = the 8 x 256 tile of W (16 KiB) + the 16 x 256 tile of the right-hand sides
 // (32 KiB), all of it brought by LDS-DMA: every step is exactly SIX 1-KiB pieces per wave (2 of W, 4 of its own right-hand
 // sides), issued D steps ahead, so s_waitcnt vmcnt(6 (D - 1)) is exact and nothing async ever lands in a register.
-template <int D>
+template <int D, int ABL = 0>   // ABL (diagnostics, results wrong): 1 no FMAs, 2 no LDS reads, 4 no block-end reduction, 8 no right-hand-side DMA
 __global__ __launch_bounds__(512) void k_trimv_dma(const double* __restrict__ W, int64_t ld, int64_t N0_,
                                                    const double* __restrict__ rows, int64_t ldr, int P,
                                                    double* __restrict__ out, int64_t ldo, int upper) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512) void k_trimv_dma(const double* __restrict__ W,
         double* dst = ring + slot * SLOT + wave * 256;
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + 128), (lds_void_ptr)(dst + 128), 16, 0, 0);
-        if (live) {
+        if (live && (ABL & 8) == 0) {
             double* rdst = ring + slot * SLOT + WT + (rg * 4) * 256 + kh * 128;   // its own four right-hand sides, its own contraction half
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void k_trimv_dma(const double* __restrict__ W,
     while (cw.valid) {
         // step s has landed when only the steps issued after it are outstanding: VM instructions each
         const int later = issued - 1;
-        if (live) {
+        if (live && (ABL & 8) == 0) {
             if (later >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM * (D - 1)) : "memory");
             else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM * 2) : "memory");
             else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM * 1) : "memory");
@@ -255,10 +255,16 @@ __global__ __launch_bounds__(512) void k_trimv_dma(const double* __restrict__ W,
         const uint32_t a = ring_addr + (uint32_t)(slot * SLOT + kh * 128 + lane * 2) * 8u;
         const uint32_t ar = a + (uint32_t)(WT + rg * 4 * 256) * 8u;
         d2 wr[8], rcur[4];
+        if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wr[i] = d2{1.0 + lane, 2.0};
+            rcur[0] = rcur[1] = rcur[2] = rcur[3] = d2{0.5, 0.25 * lane};
+        } else {
         if (live) { rcur[0] = lds_read128<0>(ar); rcur[1] = lds_read128<2048>(ar); rcur[2] = lds_read128<4096>(ar); rcur[3] = lds_read128<6144>(ar); }
         else { rcur[0] = rcur[1] = rcur[2] = rcur[3] = d2{0.0, 0.0}; }
         wr[0] = lds_read128<0>(a); wr[1] = lds_read128<2048>(a); wr[2] = lds_read128<4096>(a); wr[3] = lds_read128<6144>(a);
         wr[4] = lds_read128<8192>(a); wr[5] = lds_read128<10240>(a); wr[6] = lds_read128<12288>(a); wr[7] = lds_read128<14336>(a);
+        }
         const int cj0 = cw.j0, cc = cw.c, c_first = cw.c_first, c_last = cw.c_last;
         // the slot of step s - 1 is free now (everybody passed the barrier): issue step s + D into it
         --issued;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(512) void k_trimv_dma(const double* __restrict__ W,
                 if (!oky) wr[i].y = 0.0;
             }
         }
-        if (live) {
+        if (live && (ABL & 1) == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -290,11 +296,16 @@ __global__ __launch_bounds__(512) void k_trimv_dma(const double* __restrict__ W,
                 acc[i][r] += wr[i].x * rcur[r].x;
                 acc[i][r] += wr[i].y * rcur[r].y;
             }
+        } else if (live) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i][0] += wr[i].x + rcur[i & 3].y;
         }
         slot = slot == NS - 1 ? 0 : slot + 1;
         const bool block_ends = cc == c_last;
         cw.advance();
-        if (block_ends) {
+        if (block_ends && (ABL & 4) != 0) {
+            if (tid < 128 && cj0 + (tid & 7) < N0 && (tid >> 3) < P) out[(int64_t)(tid >> 3) * ldo + cj0 + (tid & 7)] = acc[tid & 7][0];
+        } else if (block_ends) {
             // 32 sums per lane -> after five halving levels every lane pair holds one; sum id = lane bits 5..1
             double a32[32];
 #pragma unroll
@@ -330,6 +341,143 @@ __global__ __launch_bounds__(512) void k_trimv_dma(const double* __restrict__ W,
     }
 }
 
+
+// The same with row blocks of SIXTEEN rows (acc 16 x 4 per lane): one right-hand-side tile serves twice the rows (the rhs pieces are two thirds
+// of the LDS-DMA traffic of the 8-row form), half the steps and barriers.  Slot = (16 + 16) x 256 doubles = 64 KiB: ring depth 1.
+// Same summation order per (row, right-hand side) as the 8-row form: bit-identical results.
+template <int D>
+__global__ __launch_bounds__(512) void k_trimv_dma16(const double* __restrict__ W, int64_t ld, int64_t N0_,
+                                                     const double* __restrict__ rows, int64_t ldr, int P,
+                                                     double* __restrict__ out, int64_t ldo, int upper) {
+    constexpr int NS = D + 1, WT = 16 * 256, SLOT = 32 * 256, VM = 8;
+    extern __shared__ __attribute__((aligned(16))) double ring[];   // [NS][16 + 16][256] + red[8][64]
+    double* red = ring + NS * SLOT;
+    const int N0 = (int)N0_;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave & 1, rg = wave >> 1;
+    const int r_base = blockIdx.y * 16 + rg * 4;
+    const bool live = r_base < P;
+    Walker pw, cw;
+    pw.init(gridDim.x, blockIdx.x, upper, N0, 16);
+    cw.init(gridDim.x, blockIdx.x, upper, N0, 16);
+    const uint32_t ring_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)ring;
+    const double* rsrc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rsrc[r] = rows + (int64_t)min(r_base + r, max(P - 1, 0)) * ldr + kh * 128 + lane * 2;
+    auto issue = [&](const Walker& x, int slot) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                               // W: wave w brings rows w and w + 8 of the tile (two 1-KiB halves each)
+            const int row = min(x.j0 + wave + 8 * h, N0 - 1);
+            const double* src = W + (int64_t)row * ld + (x.c << 8) + lane * 2;
+            double* dst = ring + slot * SLOT + (wave + 8 * h) * 256;
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)src, (lds_void_ptr)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)(src + 128), (lds_void_ptr)(dst + 128), 16, 0, 0);
+        }
+        if (live) {
+            double* rdst = ring + slot * SLOT + WT + (rg * 4) * 256 + kh * 128;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)(rsrc[r] + (x.c << 8)), (lds_void_ptr)(rdst + r * 256), 16, 0, 0);
+        }
+    };
+    int issued = 0;
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        if (pw.valid) { issue(pw, u); ++issued; }
+        pw.advance();
+    }
+    double acc[16][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = 0.0;
+    int slot = 0;
+    while (cw.valid) {
+        const int later = issued - 1;
+        if (live) {
+            if (later >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM * (D - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (later >= D - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (D - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const uint32_t a = ring_addr + (uint32_t)(slot * SLOT + kh * 128 + lane * 2) * 8u;
+        const uint32_t ar = a + (uint32_t)(WT + rg * 4 * 256) * 8u;
+        d2 wr[16], rcur[4];
+        if (live) { rcur[0] = lds_read128<0>(ar); rcur[1] = lds_read128<2048>(ar); rcur[2] = lds_read128<4096>(ar); rcur[3] = lds_read128<6144>(ar); }
+        else { rcur[0] = rcur[1] = rcur[2] = rcur[3] = d2{0.0, 0.0}; }
+        wr[0] = lds_read128<0>(a); wr[1] = lds_read128<2048>(a); wr[2] = lds_read128<4096>(a); wr[3] = lds_read128<6144>(a);
+        wr[4] = lds_read128<8192>(a); wr[5] = lds_read128<10240>(a); wr[6] = lds_read128<12288>(a); wr[7] = lds_read128<14336>(a);
+        wr[8] = lds_read128<16384>(a); wr[9] = lds_read128<18432>(a); wr[10] = lds_read128<20480>(a); wr[11] = lds_read128<22528>(a);
+        wr[12] = lds_read128<24576>(a); wr[13] = lds_read128<26624>(a); wr[14] = lds_read128<28672>(a); wr[15] = lds_read128<30720>(a);
+        const int cj0 = cw.j0, cc = cw.c, c_first = cw.c_first, c_last = cw.c_last;
+        --issued;
+        if (pw.valid) { issue(pw, slot == 0 ? NS - 1 : slot - 1); ++issued; }
+        pw.advance();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wr[0]), "+v"(wr[1]), "+v"(wr[2]), "+v"(wr[3]), "+v"(wr[4]), "+v"(wr[5]), "+v"(wr[6]), "+v"(wr[7]),
+                                              "+v"(wr[8]), "+v"(wr[9]), "+v"(wr[10]), "+v"(wr[11]), "+v"(wr[12]), "+v"(wr[13]), "+v"(wr[14]), "+v"(wr[15]),
+                                              "+v"(rcur[0]), "+v"(rcur[1]), "+v"(rcur[2]), "+v"(rcur[3]));
+        const int k = (cc << 8) + kh * 128 + lane * 2;
+        const bool edge = upper ? (cc == c_first || cc == c_last) : cc == c_last;
+        if (edge && live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (k >= N0) rcur[r].x = 0.0;
+                if (k + 1 >= N0) rcur[r].y = 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int j = cj0 + i;
+                const bool okx = k < N0 && (upper ? k >= j : k <= j), oky = k + 1 < N0 && (upper ? k + 1 >= j : k + 1 <= j);
+                if (!okx) wr[i].x = 0.0;
+                if (!oky) wr[i].y = 0.0;
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[i][r] += wr[i].x * rcur[r].x;
+                    acc[i][r] += wr[i].y * rcur[r].y;
+                }
+        }
+        slot = slot == NS - 1 ? 0 : slot + 1;
+        const bool block_ends = cc == c_last;
+        cw.advance();
+        if (block_ends) {
+            double a64[64];
+#pragma unroll
+            for (int t = 0; t < 64; ++t) a64[t] = acc[t >> 2][t & 3];
+#pragma unroll
+            for (int o = 32, n = 64; o >= 1; o >>= 1, n >>= 1) {
+                const bool up = (lane & o) != 0;
+#pragma unroll
+                for (int t = 0; t < n / 2; ++t) {
+                    const double send = up ? a64[t] : a64[t + n / 2];
+                    const double keep = up ? a64[t + n / 2] : a64[t];
+                    a64[t] = keep + __shfl_xor(send, o);
+                }
+            }
+            const int id = ((lane >> 5) & 1) * 32 + ((lane >> 4) & 1) * 16 + ((lane >> 3) & 1) * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 1) & 1) * 2 + (lane & 1);
+            red[(kh * 4 + rg) * 64 + id] = a64[0];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 256) {      // 16 rows x 16 right-hand sides: contraction half 0 + half 1
+                const int g = tid >> 6, id2 = tid & 63, i = id2 >> 2, r = id2 & 3;
+                const int rr = blockIdx.y * 16 + g * 4 + r;
+                const double sum = red[g * 64 + id2] + red[(4 + g) * 64 + id2];
+                if (rr < P && cj0 + i < N0) out[(int64_t)rr * ldo + cj0 + i] = sum;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] = 0.0;
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : 3000;
     const int P = argc > 2 ? atoi(argv[2]) : 10;
@@ -356,7 +504,14 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipFuncSetAttribute((const void*)k_trimv_dma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     CK(hipFuncSetAttribute((const void*)k_trimv_dma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    std::vector<double> hO(hR.size());
+    CK(hipFuncSetAttribute((const void*)k_trimv_dma<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_trimv_dma<2, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_trimv_dma<2, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_trimv_dma<2, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_trimv_dma<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_trimv_dma<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)k_trimv_dma16<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    std::vector<double> hO(hR.size()), hO8(hR.size());
     auto run = [&](const char* name, int upper, auto launch) {
         CK(hipMemset(dO, 0, hR.size() * 8));
         for (int i = 0; i < 20; ++i) launch(upper);
@@ -396,6 +551,18 @@ int main(int argc, char** argv) {
             run(nm, upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma<1>), dim3(wpc * cus, (P + 15) / 16), dim3(512), (2 * 6144 + 256) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
             snprintf(nm, sizeof nm, "LDS-DMA ring D=2, %d wg/CU", wpc);
             run(nm, upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma<2>), dim3(wpc * cus, (P + 15) / 16), dim3(512), (3 * 6144 + 256) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
+        }
+        hO8 = hO;   // (the D = 2 ring's result, one workgroup per CU ... two per CU: the same bits)
+        run("LDS-DMA ring D=1, 16-ROW blocks, 1 wg/CU", upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma16<1>), dim3(cus, (P + 15) / 16), dim3(512), (2 * 8192 + 512) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
+        { size_t diff = 0; for (int r = 0; r < P; ++r) for (int64_t j = 0; j < N; ++j) diff += hO[r * ld + j] != hO8[r * ld + j];
+          printf("    16-row form against the 8-row ring: %zu of %lld entries differ in some bit\n", diff, (long long)(P * N)); }
+        if (upper == 0) {
+            run("  ablation: ring D=2 without the FMAs", upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma<2, 1>), dim3(cus, (P + 15) / 16), dim3(512), (3 * 6144 + 256) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
+            run("  ablation: ... without FMAs and LDS reads", upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma<2, 3>), dim3(cus, (P + 15) / 16), dim3(512), (3 * 6144 + 256) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
+            run("  ablation: ... and without the block-end tree", upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma<2, 7>), dim3(cus, (P + 15) / 16), dim3(512), (3 * 6144 + 256) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
+            run("  ablation: ... and without the rhs DMA", upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma<2, 15>), dim3(cus, (P + 15) / 16), dim3(512), (3 * 6144 + 256) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
+            run("  ablation: only the block-end tree removed", upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma<2, 4>), dim3(cus, (P + 15) / 16), dim3(512), (3 * 6144 + 256) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
+            run("  ablation: only the rhs DMA removed", upper, [&](int up) { hipLaunchKernelGGL((k_trimv_dma<2, 8>), dim3(cus, (P + 15) / 16), dim3(512), (3 * 6144 + 256) * 8, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
         }
         run("balanced: 4 rows x 16 rhs, 512 thr, 1 wg/CU", upper, [&](int up) {
             hipLaunchKernelGGL((k_trimv_bal<16, 4, 512>), dim3(cus), dim3(512), 0, 0, dW, ld, N, dR, ld, P, dO, ld, up); });
