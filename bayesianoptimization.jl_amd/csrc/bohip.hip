@@ -29,6 +29,10 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 #include <queue>
@@ -1237,6 +1241,32 @@ static int build_exec_tasks(bohip_gp* g, int T) {
 }
 
 static std::mutex g_df_mutex[64];   // per device: see refit_once
+// ... and the same between PROCESSES that share a device (two ranks on one GPU in the sharded bench's test mode, several BO loops per GPU): an
+// advisory file lock named after the device's PCI address, taken inside the host lock and released with it (the kernel drops it if the process
+// dies).  No lock file (read-only /tmp, BOHIP_DF_FILE_LOCK=0): the refit goes ahead as before and the time-out remains the safety net.
+struct DfFileLock {
+    int fd = -1;
+    explicit DfFileLock(int device) {
+        static int enabled = [] { const char* e = getenv("BOHIP_DF_FILE_LOCK"); return e ? atoi(e) : 1; }();
+        if (!enabled) return;
+        static int fds[64];
+        static std::once_flag once[64];
+        const int dv = device & 63;
+        std::call_once(once[dv], [&] {
+            char bus[64] = "dev";
+            if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", device);
+            for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+            char path[160];
+            snprintf(path, sizeof path, "/tmp/.bohip_refit_%s.lock", bus);
+            fds[dv] = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+            if (fds[dv] >= 0) (void)fchmod(fds[dv], 0666);   // (other users' processes on the same device: best effort)
+        });
+        fd = fds[dv];
+        if (fd >= 0 && flock(fd, LOCK_EX) != 0) fd = -1;
+    }
+    void release() { if (fd >= 0) { flock(fd, LOCK_UN); fd = -1; } }
+    ~DfFileLock() { release(); }
+};
 static int device_cus();
 static int cholesky_exec(bohip_gp* g, int T) {
     const int64_t ld = g->ld;
@@ -1385,6 +1415,7 @@ static int refit_once(bohip_gp* g, double jitter) {
         // time-out and fell back (tools/w_stress.py: 6 time-outs in 64 refits on 8 threads).  The refit is synchronous anyway (the abort word is
         // read back below), so a host lock from the first launch to that read costs nothing a contended chip would not have cost.
         std::unique_lock<std::mutex> df_lock(g_df_mutex[g->device & 63]);
+        DfFileLock df_file(g->device);
         g->w_done = false;
         if (exec_ok) { g->chol_form_last = 4; CHK(cholesky_exec(g, T)); }
         else if (form2_ok && g_chol_df2_ll) { g->chol_form_last = 3; CHK(cholesky_dataflow3(g, T)); }
@@ -1406,6 +1437,7 @@ static int refit_once(bohip_gp* g, double jitter) {
         HIPCHK(hipStreamSynchronize(g->stream));
         unsigned aborted = 0;
         HIPCHK(hipMemcpy(&aborted, g->dchol_flags + chol_abort_word(T), sizeof(unsigned), hipMemcpyDeviceToHost));
+        df_file.release();
         df_lock.unlock();
         if (aborted) {
             // a flag never arrived (e.g. two of the streams share a hardware queue on this system, or a spinning launch kept a
