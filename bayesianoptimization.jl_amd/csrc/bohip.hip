@@ -118,6 +118,7 @@ struct bohip_gp {
     int64_t batch_hint = 0;      // bohip_gp_set_batch_hint: choose the scoring path as if the batch had at least this many candidates
     double* dsplit = nullptr;    // split-K partial planes (batches of a few hundred candidates)
     int64_t split_cap = 0;
+    const unsigned* asc_go = nullptr;   // set around the passes of the free-running ascent: the pass's big kernels return at once when the word is 0
     double* dgparts = nullptr;   // [SMALL_MAX][16][2 DMAX] split partial sums of k_grad_finish (small batches)
     unsigned* dgcount = nullptr; // per-candidate arrival counters (left at zero by the kernel)
     // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
@@ -1609,7 +1610,7 @@ static int launch_rows_trimv(bohip_gp* g, const double* W, int64_t N0, const dou
     const int64_t nblk = (N0 + 7) / 8;
     const unsigned wgs = (unsigned)std::max<int64_t>(1, std::min<int64_t>(std::max(device_cus(), 1), nblk));
     hipLaunchKernelGGL(k_trimv_stream<TRIMV_D>, dim3(wgs, (unsigned)((P + 15) / 16)), dim3(TRIMV_THREADS), trimv_lds_bytes(TRIMV_D), g->stream,
-                       W, g->ld, N0, rows, g->ld, P, out, g->ld, upper);
+                       W, g->ld, N0, rows, g->ld, P, out, g->ld, upper, (const unsigned*)g->asc_go);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2094,7 +2095,7 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
         CHK(launch_rows_trimv(g, g->dWT, N, g->dApp, (int)R, g->dApp + (int64_t)APP_UT_ROW0 * g->ld, 1));
         t_end(g);
         t_begin(g, "grad");
-        GradQ gq{g->dApp, g->ld, std::exp(2.0 * g->logsig), g->beta, g->dmu, g->dvar, d_score};
+        GradQ gq{g->dApp, g->ld, std::exp(2.0 * g->logsig), g->beta, g->dmu, g->dvar, d_score, g->asc_go};
         CHK(launch_grad_any(g, dXs, 0, R, hp, ap, d_grad, g->dApp + (int64_t)APP_UT_ROW0 * g->ld, gq));
         t_end(g);
         return 0;
@@ -2582,8 +2583,8 @@ static int ensure_ascent(bohip_gp* g, int64_t R) {
     g->asc_block = nullptr; g->asc_ints = nullptr; g->asc_hints = nullptr; g->asc_cap = 0;
     const int64_t cap = std::max<int64_t>(R, 32), d = g->d, rd = cap * d;
     HIPCHK(hipMalloc(&g->asc_block, (size_t)((9 + 2 * ASC_M) * rd + 5 * cap) * 8));
-    HIPCHK(hipMalloc(&g->asc_ints, (size_t)(4 * cap + 2 * ASC_RING) * sizeof(int)));
-    HIPCHK(hipMemset(g->asc_ints, 0, (size_t)(4 * cap + 2 * ASC_RING) * sizeof(int)));
+    HIPCHK(hipMalloc(&g->asc_ints, (size_t)(4 * cap + 2 * ASC_RING + 2) * sizeof(int)));
+    HIPCHK(hipMemset(g->asc_ints, 0, (size_t)(4 * cap + 2 * ASC_RING + 2) * sizeof(int)));
     HIPCHK(hipHostMalloc((void**)&g->asc_hints, (size_t)(2 * cap + ASC_RING) * sizeof(int), hipHostMallocDefault));
     std::memset(g->asc_hints, 0, (size_t)(2 * cap + ASC_RING) * sizeof(int));
     if (!g->asc_bounds) HIPCHK(hipMalloc(&g->asc_bounds, (size_t)3 * DMAX * 8));
@@ -2597,7 +2598,7 @@ static int ensure_ascent(bohip_gp* g, int64_t R) {
     a.active = g->asc_ints; a.accepted = g->asc_ints + cap;
     a.h_accepted = g->asc_hints; a.h_active = g->asc_hints + cap;
     a.it = g->asc_ints + 2 * cap; a.bt = g->asc_ints + 3 * cap;
-    a.nact = reinterpret_cast<unsigned*>(g->asc_ints + 4 * cap); a.ticket = a.nact + ASC_RING;
+    a.nact = reinterpret_cast<unsigned*>(g->asc_ints + 4 * cap); a.ticket = a.nact + 2 * ASC_RING;
     a.h_cnt = g->asc_hints + 2 * cap;
     g->asc_cap = cap;
     return 0;
@@ -2721,6 +2722,8 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     }
     int64_t evals = 1;
     int nh = 0, it = 0;
+    int64_t fr_e = 0, fr_converged_at = -1;   // free-running form: what its loop leaves for after the call's one synchronisation
+    bool fr_none_active = false, fr_pending = false;
     const auto t_start = std::chrono::steady_clock::now();
     auto out_of_time = [&]() {   // NLopt's maxtime (reference src/acquisition.jl:24-27 forwards it): checked once per iteration
         return g->asc_maxtime > 0.0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= g->asc_maxtime;
@@ -2745,7 +2748,10 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
                 return v - 1;
             };
             for (; evals < maxeval && !out_of_time(); ++e) {
-                CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
+                g->asc_go = st.ticket;   // (written by the adopt kernel and by every pass's step: active start points)
+                const int rc_pass = score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt);
+                g->asc_go = nullptr;
+                CHK(rc_pass);
                 ++evals;
                 hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, 0.1 * span, ftol_rel, xtol_abs,
                                    (int)(e % ASC_RING));
@@ -2761,12 +2767,9 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
                     if (n == 0) { converged_at = e - LAG; ++e; break; }
                 }
             }
-            HIPCHK(hipStreamSynchronize(g->stream));
-            if (converged_at < 0)   // stopped by maxeval / maxtime, or converged within the last LAG passes
-                for (int64_t p2 = std::max<int64_t>(0, e - LAG); p2 < e && converged_at < 0; ++p2)
-                    if (st.h_cnt[p2 % ASC_RING] == 1) converged_at = p2;
-            if (converged_at >= 0) evals = 2 + converged_at;   // passes that were needed: the first one + passes 0 .. converged_at
-            if (none_active) evals = 1;
+            // (no synchronisation here: the final arg-max and the copy home are queued behind the last pass at once; the counts of the last
+            // LAG passes are looked at after the one synchronisation of the call, below)
+            fr_e = e; fr_converged_at = converged_at; fr_none_active = none_active; fr_pending = true;
         }
     } else {
     while (evals < maxeval && any_active && !out_of_time()) {
@@ -2794,6 +2797,14 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         double* hout = g->asc_hio + n_io;
         HIPCHK(hipMemcpyAsync(hout, dout, (n_out - R) * 8, hipMemcpyDeviceToHost, g->stream));
         HIPCHK(hipStreamSynchronize(g->stream));
+        if (fr_pending) {
+            const int LAG = 1;
+            if (fr_converged_at < 0)   // stopped by maxeval / maxtime, or converged within the last LAG passes
+                for (int64_t p2 = std::max<int64_t>(0, fr_e - LAG); p2 < fr_e && fr_converged_at < 0; ++p2)
+                    if (st.h_cnt[p2 % ASC_RING] == 1) fr_converged_at = p2;
+            if (fr_converged_at >= 0) evals = 2 + fr_converged_at;   // passes that were needed: the first one + passes 0 .. converged_at
+            if (fr_none_active) evals = 1;
+        }
         if (best) { best->val = hout[0]; best->idx = (long long)hout[1]; }
         if (best_x) for (int k = 0; k < d; ++k) best_x[k] = hout[1] >= 0.0 ? hout[2 + k] : lb[k];   // :56  maxx = lowerbounds when nothing beat -Inf
         if (f_out) std::memcpy(f_out, hout + 2 + d, (size_t)R * 8);

@@ -28,7 +28,9 @@ struct AscentState {
     // free-running form (k_asc_step): per start point its own iteration count and backtracking count, and per evaluation pass a
     // ring slot: how many start points are still active after it (device counters + the word the host polls, value + 1)
     int *it, *bt;
-    unsigned *nact, *ticket;    // nact: [ASC_RING] 64-bit counters (arrivals | active << 32), 8-byte aligned; ticket: unused half
+    unsigned *nact, *ticket;    // nact: [ASC_RING] 64-bit counters (arrivals | active << 32), 8-byte aligned; ticket: ONE word behind them: start points
+                                // still active after the last finished pass -- the kernels of a queued pass return at once when it is 0 (the pass the
+                                // host queued before it could know that everything had converged: ~50 us of a call)
     int *h_cnt;                 // [ASC_RING] pinned
     // NLopt's remaining stop criteria (bohip_gp_set_ascent_stop; the reference forwards them, src/acquisition.jl:24-27, and its own
     // test sets ftol_abs = eps(), test/acquisition.jl:6,9): 0 / 0 / +Inf = off
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(64) void k_asc_adopt_count(AscentState st, int d, i
         if ((unsigned)(before & 0xffffffffull) == (unsigned)R - 1u) {
             const unsigned n = (unsigned)(before >> 32) + (unsigned)active;
             __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.ticket, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(st.h_cnt + slot, (int)n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -394,6 +397,7 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
         if ((unsigned)(before & 0xffffffffull) == (unsigned)R - 1u) {   // the last workgroup of this pass publishes the count and clears the slot
             const unsigned n = (unsigned)(before >> 32) + (active ? 1u : 0u);
             __hip_atomic_store(cnt, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(st.ticket, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(st.h_cnt + ring_slot, (int)n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host reads nothing else on the strength of it: no release, which would be a cache write-back)
         }
     }

@@ -1048,7 +1048,8 @@ struct TrimvWalker {   // the (row block, chunk) steps of one workgroup, in orde
 template <int D>
 __global__ __launch_bounds__(TRIMV_THREADS) void k_trimv_stream(const double* __restrict__ W, int64_t ld, int64_t N0_,
                                                    const double* __restrict__ rows, int64_t ldr, int P,
-                                                   double* __restrict__ out, int64_t ldo, int upper) {
+                                                   double* __restrict__ out, int64_t ldo, int upper, const unsigned* __restrict__ go = nullptr) {
+    if (go && *go == 0u) return;   // (the free-running ascent: a pass that was queued before the host knew that every start point had stopped)
     constexpr int NS = D + 1, WT = 8 * 256, SLOT = 24 * 256, VM = 6;   // doubles per W tile / per ring slot; VMEM instructions per step and wave
     extern __shared__ __attribute__((aligned(16))) double ring[];   // [NS][8 + 16][256] + red[8][32]
     double* red = ring + NS * SLOT;

@@ -586,6 +586,7 @@ struct GradQ {
     int64_t ldv;
     double sigma2, beta;
     double *mu_out, *var_out, *score_out;
+    const unsigned* go;   // not null: return at once when the word is 0 (free-running ascent, see AscentState::ticket)
 };
 template <int DT>
 __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ X, int64_t N,
@@ -602,6 +603,7 @@ __global__ __launch_bounds__(256) void k_grad_finish(const double* __restrict__ 
     // result depends on (N, gridDim.y) only, never on the batch -- and leaves the counter at zero for the next call.
     __shared__ double red[4][2 * DT + 2];
     __shared__ int is_last;
+    if (gq.go && *gq.go == 0u) return;
     constexpr int PS = 2 * DT + 2;   // partial record of one split: 2 DT gradient sums + the split's part of q
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r = r_begin + blockIdx.x;
