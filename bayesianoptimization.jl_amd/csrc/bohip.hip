@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -315,8 +316,8 @@ static int g_chol_exec_min = -1;  // BOHIP_CHOL_EXEC_MIN, row tiles.  Default: 4
 static int g_chol_exec_patience_us = 1000;   // BOHIP_CHOL_EXEC_PATIENCE_US: how long a workgroup only polls a held record before it takes other work meanwhile
 static int g_chol_exec_fill_inv = 1;    // a workgroup waiting for the counters of a claimed task runs inverse-wave tasks meanwhile (BOHIP_CHOL_EXEC_FILL_INV)
 static int g_chol_exec_inv_pairs = 0;   // inverse queue claimed one record (0) or one tile = two records (1) at a time (BOHIP_CHOL_EXEC_INV_PAIRS)
-static int g_chol_inv_grp_min = 40;   // row tiles from which the inverse queues take the GROUP form (exec_task_list); BOHIP_CHOL_INV_GRP_MIN
-static int g_chol_inv_g = 8;       // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
+static std::atomic<int> g_chol_inv_grp_min{40};   // row tiles from which the inverse queues take the GROUP form (exec_task_list); BOHIP_CHOL_INV_GRP_MIN
+static std::atomic<int> g_chol_inv_g{8};      // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
                                    // of contraction (BOHIP_CHOL_INV_G; 0 = off: the level-by-level inverse runs after the factorisation)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)
 static int g_chol_copy_early = 1;   // BOHIP_CHOL_COPY_EARLY=0: the copy S -> L behind the executor instead of behind the chain kernel (cholesky_exec)
@@ -792,7 +793,8 @@ static int cholesky_dataflow3(bohip_gp* g, int T) {
 //   tile (c+1, c):          ver = farall[c], pver = fol[c];      tile (c, c):  ver = colall[c], pver = col[c]
 //   sver(i, k) = colr[k T + i];   queue cursors = the EX_NQ = 6 words behind the abort word
 static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsigned* flag_base, int64_t ld, int T, int CH_NSF, int inv_g,
-                           std::vector<ExTask>& all, int* qbeg) {
+                           std::vector<ExTask>& all, int* qbeg, int inv_grp_min = -1) {
+    if (inv_grp_min < 0) inv_grp_min = g_chol_inv_grp_min;   // (the test hook passes its own: no process-wide state is swapped)
     const CholFlags fl = chol_flags_layout_at(flag_base, nullptr, T);
     auto widx = [&](const unsigned* p) { return (uint32_t)(p - flag_base); };
     auto nb = [](int c) { return std::max(c / 4 - 1, 0); };         // bulk groups that touch column c
@@ -1026,7 +1028,7 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
     // far rows, then the products of group m+1 (their inputs were claimed a thousand records earlier), then the other half (which separates
     // the products from the rounds of group m+1 that need them).  Counters: word 3 of tile (g0, j) counts the completed P' tiles of group g
     // and column j, word 2 of the same tile its finished products, word 3 of the diagonal tile (g0, g0) the finished tiles of D_g.
-    const bool inv_groups = inv_g >= 2 && T >= g_chol_inv_grp_min;   // (a group of one row has no D_g: nothing would mark W as grown)
+    const bool inv_groups = inv_g >= 2 && T >= inv_grp_min;   // (a group of one row has no D_g: nothing would mark W as grown)
     if (inv_groups) {
         const int G = inv_g, NG = (T + G - 1) / G;
         const uint32_t ivb = (uint32_t)chol_inv_word(T);
@@ -1244,26 +1246,59 @@ static int build_exec_tasks(bohip_gp* g, int T) {
 static std::mutex g_df_mutex[64];   // per device: see refit_once
 // ... and the same between PROCESSES that share a device (two ranks on one GPU in the sharded bench's test mode, several BO loops per GPU): an
 // advisory file lock named after the device's PCI address, taken inside the host lock and released with it (the kernel drops it if the process
-// dies).  No lock file (read-only /tmp, BOHIP_DF_FILE_LOCK=0): the refit goes ahead as before and the time-out remains the safety net.
+// dies).  Round 5 (advisor): the lock file lives in a PER-USER directory ($XDG_RUNTIME_DIR, else /tmp/bohip-<uid> created 0700 and checked to be
+// ours), is opened O_NOFOLLOW | O_CLOEXEC with mode 0600 and never chmod'ed (a planted symlink or file cannot redirect it); the lock is taken
+// NON-blocking with a bounded retry (BOHIP_DF_FILE_LOCK_MS, 300 ms) -- a stopped or hung holder no longer blocks every refit on the GPU: the
+// refit then goes ahead unlocked and the flags' 200 ms time-out + launch-chain fall-back stay the safety net; the descriptor is re-opened in a
+// forked child (parent and child would share ONE open file description and not exclude each other).  No lock file (read-only directory,
+// BOHIP_DF_FILE_LOCK=0): the refit goes ahead as before.  Processes of DIFFERENT users on one device do not see each other's lock.
 struct DfFileLock {
     int fd = -1;
+    static int open_lock_file(int device) {
+        char bus[64] = "dev";
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", device);
+        for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+        char dir[128];
+        const char* xdg = getenv("XDG_RUNTIME_DIR");
+        struct stat st;
+        if (xdg && xdg[0] == '/' && strlen(xdg) < 100 && stat(xdg, &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == geteuid()) {
+            snprintf(dir, sizeof dir, "%s", xdg);
+        } else {
+            snprintf(dir, sizeof dir, "/tmp/bohip-%u", (unsigned)geteuid());
+            if (mkdir(dir, 0700) != 0 && errno != EEXIST) return -1;
+            if (lstat(dir, &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & 077)) return -1;   // not ours / a link / open to others
+        }
+        char path[256];
+        snprintf(path, sizeof path, "%s/bohip_refit_%s.lock", dir, bus);
+        return open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
+    }
     explicit DfFileLock(int device) {
         static int enabled = [] { const char* e = getenv("BOHIP_DF_FILE_LOCK"); return e ? atoi(e) : 1; }();
+        static int wait_ms = [] { const char* e = getenv("BOHIP_DF_FILE_LOCK_MS"); return e ? std::max(0, atoi(e)) : 300; }();
         if (!enabled) return;
         static int fds[64];
-        static std::once_flag once[64];
+        static pid_t owner[64];
+        static std::mutex open_mutex;
         const int dv = device & 63;
-        std::call_once(once[dv], [&] {
-            char bus[64] = "dev";
-            if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) snprintf(bus, sizeof bus, "dev%d", device);
-            for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.' || *c == '/') *c = '_';
-            char path[160];
-            snprintf(path, sizeof path, "/tmp/.bohip_refit_%s.lock", bus);
-            fds[dv] = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-            if (fds[dv] >= 0) (void)fchmod(fds[dv], 0666);   // (other users' processes on the same device: best effort)
-        });
-        fd = fds[dv];
-        if (fd >= 0 && flock(fd, LOCK_EX) != 0) fd = -1;
+        {
+            std::lock_guard<std::mutex> lk(open_mutex);
+            const pid_t me = getpid();
+            if (owner[dv] != me) {                        // first use in this process, or we are a forked child: an own open file description
+                if (owner[dv] != 0 && fds[dv] >= 0) close(fds[dv]);
+                fds[dv] = open_lock_file(device);
+                owner[dv] = me;
+            }
+            fd = fds[dv];
+        }
+        if (fd < 0) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            if (flock(fd, LOCK_EX | LOCK_NB) == 0) return;
+            if (errno != EWOULDBLOCK && errno != EINTR) break;
+            if (std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(wait_ms)) break;
+            usleep(200);
+        }
+        fd = -1;                                          // not ours: go ahead unlocked (the time-out fall-back is the safety net)
     }
     void release() { if (fd >= 0) { flock(fd, LOCK_UN); fd = -1; } }
     ~DfFileLock() { release(); }
@@ -2968,11 +3003,10 @@ int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base
     // one-time setup may not have run yet), and the process-wide setting is left alone
     int nsf = g_chol_nsf;
     if (const char* e = getenv("BOHIP_CHOL_NSF")) nsf = std::min(bohip::CH_NSF_MAX, std::max(1, atoi(e)));
-    const int grp_min = g_chol_inv_grp_min;
-    if (const char* e = getenv("BOHIP_CHOL_INV_GRP_MIN")) g_chol_inv_grp_min = std::max(0, atoi(e));
+    int grp_min = g_chol_inv_grp_min;
+    if (const char* e = getenv("BOHIP_CHOL_INV_GRP_MIN")) grp_min = std::max(0, atoi(e));
     exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W),
-                   reinterpret_cast<double*>(base_WT), fb, ld, T, nsf, inv_g, all, qb);
-    g_chol_inv_grp_min = grp_min;
+                   reinterpret_cast<double*>(base_WT), fb, ld, T, nsf, inv_g, all, qb, grp_min);
     for (int i = 0; i <= bohip::EX_NQ; ++i) qbeg[i] = qb[i];
     const bohip::CholFlags fl = chol_flags_layout_at(fb, nullptr, T);
     const unsigned* ptrs[10] = {fl.panel, fl.solved, fl.crit, fl.rest, fl.col, fl.farall, fl.fol, fl.colall, fl.colr, fl.xp};
@@ -2996,9 +3030,7 @@ int bohip_debug_trigemm_pieces(int T, int64_t alpha_row, int* out, int cap) {
 // tools and bench.py: switch the executor's inverse queues at run time (returns the previous chunk size; 0 = off: the factorisation
 // alone can then be timed against its own flop count)
 int bohip_debug_set_chol_inv_g(int g_new) {
-    const int old = g_chol_inv_g;
-    g_chol_inv_g = std::min(64, std::max(0, g_new));
-    return old;
+    return g_chol_inv_g.exchange(std::min(64, std::max(0, g_new)));   // (atomic; a refit in flight on another thread may see either value)
 }
 // tools only (tools/exec_throughput.py): how fast does the executor kernel get through its task list when NOTHING has to be waited for?
 // The records of the queues in `qmask` run with their counters removed (every task runnable at once, no chain kernel beside them), on

@@ -183,7 +183,8 @@ int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
 /* Benchmarks only (bench.py, tools/): the executor form of the factorisation grows W = L^-1 behind the pivot chain in
  * pieces of `blocks` 128-blocks (default 8).  0 switches those queues off -- the factorisation then runs alone and can
  * be timed against its own N^3/3 flops, the inverse follows as a stage of its own.  PROCESS-wide (every handle),
- * returns the previous value.  Same effect as env BOHIP_CHOL_INV_G at load time.                                  */
+ * returns the previous value.  Same effect as env BOHIP_CHOL_INV_G at load time.  NOT a synchronisation point:
+ * call it while no model update is running on another thread (one in flight may use either setting).            */
 int bohip_debug_set_chol_inv_g(int blocks);
 /* Sharded scoring: candidates are scored by one of three summation schedules chosen by batch size
  * (row-wise, split-K, whole-K MFMA jobs); they agree to ~1e-11 relative but not bit for bit.  A rank that scores a
