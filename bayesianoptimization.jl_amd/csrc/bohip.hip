@@ -19,6 +19,7 @@
 #include "kernels_chol.hip"
 #include "kernels_exec.hip"
 #include "kernels_score.hip"
+#include "kernels_small.hip"
 #include "kernels_ascent.hip"
 
 #include <algorithm>
@@ -122,6 +123,11 @@ struct bohip_gp {
     const unsigned* asc_go = nullptr;   // set around the passes of the free-running ascent: the pass's big kernels return at once when the word is 0
     double* dgparts = nullptr;   // [SMALL_MAX][16][2 DMAX] split partial sums of k_grad_finish (small batches)
     unsigned* dgcount = nullptr; // per-candidate arrival counters (left at zero by the kernel)
+    // round 5: the small-batch pass as two MFMA kernels (kernels_small.hip): one scratch block [part | v16 | qpart | mupart | post | fstash | gpart]
+    double* dsm = nullptr;
+    size_t sm_bytes = 0;
+    unsigned* dsm_cnt = nullptr;
+    int sm_cnt_T = 0;
     // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
     // 2-3 device-to-host copies of a call cost more than its kernels (each ~8 us of API + DMA set-up)
     double* hpin = nullptr;      // [score 32 | mu 32 | var 32 | best 2 | grad 32 DMAX]
@@ -289,6 +295,8 @@ static int g_asc_wg_nmax = 256;  // BOHIP_ASC_WG_NMAX: models up to this many ob
                                  // (kernels_ascent.hip k_ascent_wg); 0: never
 static int g_asc_lockstep = 0;   // BOHIP_ASC_LOCKSTEP=1: the lock-step driver of the device ascent (five launches + a stream synchronisation per
                                  // evaluation pass) instead of the free-running one (k_asc_step)
+static int g_small_mfma = 1;   // BOHIP_SMALL_MFMA: the small-batch pass as two MFMA kernels (kernels_small.hip); 0 = round 4's five kernels
+static int g_small_m = 0;      // BOHIP_SMALL_M: 128-chunks of the contraction index per tile of those kernels; 0 = by size
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
                             // candidates one 64-wide MFMA tile column leaves single workgroups walking the whole K extent
@@ -402,6 +410,8 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_ASC_WG_NMAX")) g_asc_wg_nmax = std::max(0, atoi(e));
     if (const char* e = getenv("BOHIP_ASC_LOCKSTEP")) g_asc_lockstep = atoi(e) != 0;
     if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_MAX, std::max(0, atoi(e)));
+    if (const char* e = getenv("BOHIP_SMALL_MFMA")) g_small_mfma = atoi(e);
+    if (const char* e = getenv("BOHIP_SMALL_M")) g_small_m = std::max(0, atoi(e));
     done = true;
     return 0;
 }
@@ -1899,9 +1909,97 @@ static int64_t small_limit(const bohip_gp* g) {
 }
 // the batch size the path decision is based on (see bohip_gp_set_batch_hint)
 static int64_t path_R(const bohip_gp* g, int64_t R) { return std::max(R, g->batch_hint); }
+// ---- round 5: the small-batch pass as two MFMA kernels (kernels_small.hip) ------------------------------------------------------------
+#ifdef BOHIP_SMALL_TRACE
+static unsigned long long* g_small_trace = nullptr;
+extern "C" int bohip_debug_small_trace_read(unsigned long long* out) {   // measurement build only (tools/small_pass_trace.py)
+    if (!g_small_trace) return -1;
+    return hipMemcpy(out, g_small_trace, 8192 * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
+template <int DT, int G>
+static void launch_small_pass(bohip_gp* g, const SmallCommon& sc, const SmallV& sv, const SmallU* su, const KernelHyper& hp, int npass) {
+    hipLaunchKernelGGL((k_small_v<DT, G>), dim3((unsigned)sc.ntiles, (unsigned)npass), dim3(SP_THREADS), 0, g->stream, sc, sv, hp);
+    if (su) {
+        SmallCommon scu = sc;
+        scu.A = g->dW;
+        hipLaunchKernelGGL((k_small_u<DT, G>), dim3((unsigned)sc.ntiles, (unsigned)npass), dim3(SP_THREADS), 0, g->stream, scu, *su, hp);
+    }
+}
+template <int DT>
+static void launch_small_pass_g(bohip_gp* g, int G, const SmallCommon& sc, const SmallV& sv, const SmallU* su, const KernelHyper& hp, int npass) {
+    if constexpr (DT <= 16) {     // (the wide-dimension instantiations are compiled for four MFMA groups only: build time)
+        if (G == 1) return launch_small_pass<DT, 1>(g, sc, sv, su, hp, npass);
+        if (G == 2) return launch_small_pass<DT, 2>(g, sc, sv, su, hp, npass);
+        if (G == 3) return launch_small_pass<DT, 3>(g, sc, sv, su, hp, npass);
+    }
+    launch_small_pass<DT, 4>(g, sc, sv, su, hp, npass);
+}
+// all R <= SMALL_MAX candidates: values (mu, sigma^2, score, arg-max record) and, with d_grad, the gradient of the score
+static int small_pass_mfma(bohip_gp* g, const double* dXs, int64_t R, const AcqParams& ap, double* d_mu, double* d_var, double* d_score,
+                           Best* d_best, int64_t best_off, double* d_grad) {
+    const int N = (int)g->n, T = (N + TILE - 1) / TILE, P = (int)R, npass = (P + 15) / 16, DTm = g->d <= 2 ? 2 : g->d <= 4 ? 4 : g->d <= 8 ? 8 : g->d <= 16 ? 16 : g->d <= 32 ? 32 : 64;
+    // chunks per tile: every tile's partial sums cost one 16-KiB write and one read by the block's finisher, a column block's finisher adds up
+    // to ceil(T / m) of them; BOHIP_SMALL_M overrides (tools/small_batch_bench.py sweeps it)
+    // (one workgroup of these kernels per CU: all tiles of a pass are resident at once when there are no more tiles than CUs)
+    int m = g_small_m;
+    if (m <= 0) { const int cus = std::max(device_cus(), 1); for (m = 1; m < T && small_ntiles(T, m) > cus; ++m) {} }
+    const int ntiles = small_ntiles(T, m);
+    const size_t n_part = (size_t)npass * ntiles * 2048, n_v16 = (size_t)npass * T * 128 * 16, n_rec = (size_t)npass * T * 16,
+                 n_g = (size_t)npass * T * 16 * 2 * DTm;
+    const size_t need = (n_part + 2 * n_v16 + 2 * n_rec + (size_t)npass * 32 + SMALL_MAX + n_g) * 8;
+    if (need > g->sm_bytes) {
+        if (g->dsm) { HIPCHK(hipStreamSynchronize(g->stream)); HIPCHK(hipFree(g->dsm)); g->dsm = nullptr; g->sm_bytes = 0; }
+        HIPCHK(hipMalloc(&g->dsm, need + need / 4));
+        g->sm_bytes = need + need / 4;
+    }
+    if (!g->dsm_cnt || T > g->sm_cnt_T) {
+        if (g->dsm_cnt) { HIPCHK(hipStreamSynchronize(g->stream)); HIPCHK(hipFree(g->dsm_cnt)); g->dsm_cnt = nullptr; }
+        const int Tc = T + 16;
+        const size_t words = (size_t)(SMALL_MAX / 16) * (Tc + 1) + 1;
+        HIPCHK(hipMalloc(&g->dsm_cnt, words * sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(g->dsm_cnt, 0, words * sizeof(unsigned), g->stream));
+        g->sm_cnt_T = Tc;
+    }
+    const KernelHyper hp = make_hyper(g);
+    SmallCommon sc{};
+    sc.A = g->dWT; sc.ld = g->ld; sc.N = N; sc.T = T; sc.m = m; sc.P = P; sc.part = g->dsm; sc.ntiles = ntiles; sc.cnt = g->dsm_cnt;
+    sc.X = g->dX; sc.Xs = dXs; sc.alpha = g->dalpha; sc.go = (const unsigned*)g->asc_go;
+#ifdef BOHIP_SMALL_TRACE
+    if (!g_small_trace) { HIPCHK(hipMalloc(&g_small_trace, 8192 * 16 * 8)); }
+    HIPCHK(hipMemsetAsync(g_small_trace, 0, 8192 * 16 * 8, g->stream));
+    sc.trace = g_small_trace;
+#endif
+    SmallV sv{};
+    sv.v16 = g->dsm + n_part; sv.qpart = sv.v16 + n_v16; sv.mupart = sv.qpart + n_rec;
+    sv.fstash = sv.mupart + n_rec + (size_t)npass * 32;
+    sv.sigma2 = std::exp(2.0 * g->logsig); sv.beta = g->beta; sv.ap = ap;
+    sv.mu_out = d_mu; sv.var_out = d_var; sv.score_out = d_score; sv.best_out = d_best; sv.idx_off = (long long)best_off;
+    sv.finish = d_grad ? 0 : 1;
+    SmallU su{};
+    sv.ks16 = sv.fstash + SMALL_MAX;
+    su.v16 = sv.v16; su.sv = sv; su.gpart = sv.ks16 + n_v16; su.grad = d_grad;
+    const SmallU* sup = d_grad ? &su : nullptr;
+    const int G = (std::min(P, 16) + 3) / 4;
+    t_begin(g, d_grad ? "small_V+U" : "small_V");
+    switch (DTm) {
+        case 2: launch_small_pass_g<2>(g, G, sc, sv, sup, hp, npass); break;
+        case 4: launch_small_pass_g<4>(g, G, sc, sv, sup, hp, npass); break;
+        case 8: launch_small_pass_g<8>(g, G, sc, sv, sup, hp, npass); break;
+        case 16: launch_small_pass_g<16>(g, G, sc, sv, sup, hp, npass); break;
+        case 32: launch_small_pass_g<32>(g, G, sc, sv, sup, hp, npass); break;
+        default: launch_small_pass_g<64>(g, G, sc, sv, sup, hp, npass); break;
+    }
+    HIPCHK(hipGetLastError());
+    t_end(g);
+    g->q_tiles = 0;
+    return 0;
+}
+
 // candidates [r0, r1), at most SMALL_MAX of them; the output pointers are indexed by the GLOBAL candidate number
 static int small_posterior(bohip_gp* g, const double* dXs, int64_t r0, int64_t r1, bool want_u, const AcqParams& ap,
                            double* d_mu, double* d_var, double* d_score, Best* d_best, int64_t best_off = 0) {
+    if (g_small_mfma && r0 == 0 && !want_u) return small_pass_mfma(g, dXs, r1, ap, d_mu, d_var, d_score, d_best, best_off, nullptr);
     CHK(ensure_small_counters(g));
     const int64_t N = g->n, Npad = round_up(N + 1, TILE), ld = g->ld;
     const int P = (int)(r1 - r0);
@@ -2117,6 +2215,8 @@ static int score_grad_core(bohip_gp* g, int acq_id, const double* acq_params, co
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
     if (path_R(g, R) <= small_limit(g) && R <= SMALL_MAX) {  // the reference's default: a handful of L-BFGS restarts per call
+        // round 5: two MFMA kernels (kernels_small.hip): K*' + V' + posterior finish, U' + gradient
+        if (g_small_mfma) return small_pass_mfma(g, dXs, R, ap, g->dmu, g->dvar, d_score, nullptr, 0, d_grad);
         // K*' -> V' = K*' W' rows (row-wise) -> U' = V' W rows -> ONE finishing kernel: q, mu, sigma^2, value and gradient
         CHK(ensure_small_counters(g));
         t_begin(g, "kstar");
@@ -2252,6 +2352,8 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dgparts) hipFree(g->dgparts);
     if (g->dsplit) hipFree(g->dsplit);
     if (g->dgcount) hipFree(g->dgcount);
+    if (g->dsm) hipFree(g->dsm);
+    if (g->dsm_cnt) hipFree(g->dsm_cnt);
     if (g->hpin) hipHostFree(g->hpin);
     if (g->asc_block) hipFree(g->asc_block);
     if (g->asc_ints) hipFree(g->asc_ints);

@@ -1,0 +1,629 @@
+// kernels_small.hip -- round 5: the small-batch posterior pass (what the reference's DEFAULT usage runs: 10 L-BFGS restarts per
+// acquire_max, reference src/acquisition.jl:4-6,54-68, each evaluation a value + gradient of <= 16 candidates) as TWO kernels:
+//
+//   k_small_v   K*' assembly (in the prologue of the tiles that need it)  ->  V' = K*' W'  ->  q = sum v^2, mu, sigma^2, the
+//               acquisition value and the arg-max of the batch                               (replaces k_kstar + k_trimv_stream + k_small_finish)
+//   k_small_u   U' = V' W  ->  the analytic gradient of the acquisition                     (replaces k_trimv_stream + k_grad_finish)
+//
+// Round 4's pass was five kernels whose dependent latency chains abutted (kstar 5 us, V' 15.4, U' 17.2, gradient 15.6 at N = 3000): each
+// triangular product was a barrier-stepped LDS-DMA ring at 0.35 of the plain read rate of W, and the gradient kernel a 15 us chain for
+// 0.4 MB.  Here a triangular product with <= 16 right-hand sides is a dense contraction against K-MAJOR tiles of the resident matrix:
+//   out[c][r] = sum_k A[k][c] rhs[k][r],   A = W' (k <= c) for V',  A = W (k >= c) for U'
+// (row k of A contiguous in c: a lane loads 16 bytes of ONE row, a wave four rows x 256 bytes, every byte of the triangle exactly once, no
+// LDS staging of the matrix, no barrier inside the stream) on v_mfma_f64_4x4x4_4b: the four blocks of one instruction are four groups
+// of four COLUMNS c against the same 4 x 4 block of right-hand sides (the A operand is read from LDS with an address that ignores the
+// block index, which replicates it for free), i.e. 16 columns x 4 right-hand sides x 4 contraction indices in 16 cycles, ceil(P / 4)
+// instructions per k-step -- the 16x16x4 form of the same product runs at 100-140 cycles per instruction on this chip (gemm_core.h).
+// Work decomposition: a workgroup (8 waves = 2 contraction halves x 4 column strips of 32) owns a TILE = one 128-column block x a
+// segment of m 128-chunks of the contraction index; the tiles of a column block leave their partial sums in a scratch plane (16-byte
+// write-through stores), count themselves in, and the LAST ARRIVER adds them in segment order -- the result depends on (N, m) only,
+// never on the batch, the candidate's position in it or which workgroup came last (reference property test/acquisitionfunctions.jl:
+// 8-11: batch == single, bit for bit).  The column block's finisher goes straight on: sum v^2 over its 128 columns (V pass) or the
+// gradient sums over its 128 observations (U pass) into a per-block record; the finisher of the LAST column block adds the records in
+// block order and writes mu, sigma^2, value, arg-max / the gradient.  Counters are left at zero.
+// Right-hand-side SLOTS: candidate r of a pass of 16 lives in slot 4 (r % 4) + r / 4 of every [.][16] array (the lane that holds the
+// results of MFMA g for right-hand side 4 g + q then owns four consecutive slots 4 q ... 4 q + 3).
+#include "gemm_core.h"
+
+namespace bohip {
+
+constexpr int SP_THREADS = 512;
+
+struct SmallCommon {
+    const double* A;        // W' (V pass) or W (U pass), K-major, leading dimension ld
+    int64_t ld;
+    int N, T, m, P;         // observations, 128-blocks, chunks per tile segment, candidates of the call
+    double* part;           // [pass][ntiles][128][16] partial tiles
+    int ntiles;
+    unsigned* cnt;          // [pass][T] tile arrivals per column block, then [pass] finished column blocks, then [1] finished passes
+    const double* X;        // [N][d]
+    const double* Xs;       // [P][d] candidates
+    const double* alpha;
+    const unsigned* go;     // not null: return at once when the word is 0 (free-running ascent)
+#ifdef BOHIP_SMALL_TRACE
+    unsigned long long* trace;   // [2][workgroup][16] wall-clock marks (tools/small_pass_trace.py; measurement build only)
+#endif
+};
+#ifdef BOHIP_SMALL_TRACE
+#define SM_MARK(sc, kern, i) do { if (threadIdx.x == 0) (sc).trace[(((kern) * 4096 + blockIdx.y * gridDim.x + blockIdx.x) & 8191) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define SM_MARK(sc, kern, i) do { } while (0)
+#endif
+struct SmallV {
+    double* v16;            // [pass][T * 128][16]   V' in slot layout (the U pass's right-hand sides)
+    double* qpart;          // [pass][T][16]
+    double* mupart;         // [pass][T][16]
+    double* fstash;         // [SMALL_MAX] scores of all passes (arg-max over several passes)
+    double* ks16;           // [pass][T * 128][16]   K*' in slot layout: written by the tile that holds a column block's diagonal chunk, read by the U
+                            // pass's finisher of that block (SE kernels: d k*_j / d x = -k*_j (x - X_j) / l^2, no second exponential)
+    double sigma2, beta;
+    AcqParams ap;
+    double *mu_out, *var_out, *score_out;
+    Best* best_out;
+    long long idx_off;
+    int finish;             // 1: this kernel also finishes the posterior (value-only call); 0: k_small_u's last workgroup does (one counter level and
+                            // one serial tail less in front of the U pass)
+};
+struct SmallU {
+    const double* v16;
+    SmallV sv;              // the posterior finish rides in this kernel's last workgroup (same device function as the value-only call: same bits)
+    double* gpart;          // [pass][T][16][2 DT]
+    double* grad;           // [P][d]
+};
+
+__device__ __forceinline__ int small_slot_to_r(int slot) { return 4 * (slot & 3) + (slot >> 2); }
+
+// which tile is workgroup b: column blocks heaviest first (lower: T-1 ... 0, upper: 0 ... T-1), a block's segments in contraction order
+template <int UPPER>
+__device__ __forceinline__ void small_tile(int b, int T, int m, int& cb, int& kc0, int& kc1, int& t0, int& nseg) {
+    // the extents run T, T - 1, ..., 1 in both forms; nseg = ceil(ext / m) drops by one every m steps (no integer division on the scalar unit)
+    t0 = 0;
+    int ext = T, rem = T % m;                     // rem = ext mod m
+    nseg = T / m + (rem ? 1 : 0);
+    for (int o = 0; o < T; ++o) {
+        if (b < nseg) break;
+        b -= nseg;
+        t0 += nseg;
+        --ext;
+        if (rem == 1) --nseg;                     // ext went from q m + 1 to q m
+        rem = rem == 0 ? m - 1 : rem - 1;
+        if (m == 1) nseg = ext;
+    }
+    cb = UPPER ? T - ext : ext - 1;
+    const int klo = UPPER ? cb : 0;
+    kc0 = klo + b * m;
+    kc1 = min(klo + ext, kc0 + m);
+}
+static int small_ntiles(int T, int m) {
+    int n = 0;
+    for (int e = 1; e <= T; ++e) n += (e + m - 1) / m;
+    return n;
+}
+
+
+// The contraction of one tile: chunks [kc0, kc1) of the contraction index against the workgroup's 128 columns; every wave leaves its
+// partial sums in acc (lane (q, p), wave strip wc: column cb * 128 + 32 wc + 2 p + e, right-hand sides 4 g + q).
+// Order of issue = order of need: the first right-hand-side tile's inputs (pre), the candidates / observations for LDS (setup_load;
+// setup_store writes them and ends with a barrier), then the 16 loads of the matrix; from there on the next chunk's inputs are requested BEFORE the current
+// chunk's products so that they land behind them:  pre(kc) -> registers,  fill(kc, registers, tile) -> LDS.  Two LDS tiles: the fill of
+// chunk kc + 1 writes the tile that chunk kc - 1 used, and every wave has left chunk kc - 1 when it passes chunk kc's barrier.
+// On return rt2 + ((kc1 - 1 - kc0) & 1) * 2048 holds the tile of chunk kc1 - 1.
+template <int UPPER, int G, class SetupL, class SetupS, class Pre, class Fill>
+__device__ __forceinline__ void small_contract(const SmallCommon& sc, double* rt2, int cb, int kc0, int kc1, SetupL&& setup_load, SetupS&& setup_store, Pre&& pre, Fill&& fill,
+                                               double (&acc)[2][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wc = wave & 3, q = lane >> 4, p = lane & 15;
+    const int N = sc.N;
+    const int c0 = cb * 128 + wc * 32;
+    const int64_t ld = sc.ld;
+    const double* ap = sc.A + (int64_t)(kc0 * 128 + 64 * kh + q) * ld + c0 + 2 * p;
+    // (loads return in order: what is needed first is requested first -- the first right-hand-side tile's inputs, the candidates, then the
+    // sixteen loads of the matrix; the tile is then built while the matrix is on its way)
+    auto regs = pre(kc0);
+    auto sregs = setup_load();
+    d2 w[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) w[s] = *(const d2*)(ap + (int64_t)(4 * s) * ld);
+    SM_MARK(sc, UPPER, 1);
+    setup_store(sregs);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[e][g] = 0.0;
+    for (int kc = kc0; kc < kc1; ++kc) {
+        double* rt = rt2 + ((kc - kc0) & 1) * 2048;
+        fill(kc, regs, rt);
+        __syncthreads();
+        if (kc == kc0) SM_MARK(sc, UPPER, 2);
+        const bool edge = kc == cb || kc * 128 + 128 > N, more = kc + 1 < kc1;
+        if (more) regs = pre(kc + 1);
+        const double* apn = ap + (int64_t)(kc + 1 - kc0) * 128 * ld;
+        const double* ra = rt + (64 * kh + q) * 16 + 4 * (lane & 3);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const d2 a01 = *(const d2*)(ra + s * 64);
+            d2 a23 = {0.0, 0.0};
+            if (G > 2) a23 = *(const d2*)(ra + s * 64 + 2);
+            d2 wv = w[s];
+            if (more) w[s] = *(const d2*)(apn + (int64_t)(4 * s) * ld);
+            if (edge) {
+                const int k = kc * 128 + 64 * kh + 4 * s + q, c = c0 + 2 * p;
+                const bool okx = k < N && (UPPER ? k >= c : k <= c), oky = k < N && (UPPER ? k >= c + 1 : k <= c + 1);
+                if (!okx) wv.x = 0.0;
+                if (!oky) wv.y = 0.0;
+            }
+            acc[0][0] = mfma444(a01.x, wv.x, acc[0][0]);
+            acc[1][0] = mfma444(a01.x, wv.y, acc[1][0]);
+            if (G > 1) { acc[0][1] = mfma444(a01.y, wv.x, acc[0][1]); acc[1][1] = mfma444(a01.y, wv.y, acc[1][1]); }
+            if (G > 2) { acc[0][2] = mfma444(a23.x, wv.x, acc[0][2]); acc[1][2] = mfma444(a23.x, wv.y, acc[1][2]); }
+            if (G > 3) { acc[0][3] = mfma444(a23.y, wv.x, acc[0][3]); acc[1][3] = mfma444(a23.y, wv.y, acc[1][3]); }
+        }
+    }
+}
+// Publication of the tile + the column block's combine.  Returns true in the LAST ARRIVER of the column block, with the combined sums of
+// pieces (tid, tid + 512) in sum[0..1]: piece e = c_local * 8 + sp  <->  out[cb * 128 + c_local][slots 2 sp, 2 sp + 1].
+// meanwhile(): what the last arriver does while the partial tiles are on their way (one round trip to the memory side: ~2 us).  The
+// loads are plain compiler-tracked 8-byte agent-scope loads, so code between their issue and their use is safe (running it in EVERY
+// workgroup under the stores' acknowledgement was measured: 2.5 us on the critical path of every tile instead of one).
+template <int UPPER, class Meanwhile>
+__device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int pass, double* red, int* flag, int cb, int t0, int nseg,
+                                                      const double (&acc)[2][4], d2 (&sum)[2], Meanwhile&& meanwhile) {
+    SM_MARK(sc, UPPER, 3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wc = wave & 3, q = lane >> 4, p = lane & 15;
+    // contraction half 1 hands its sums to half 0 (fixed order: half 0 + half 1), which publishes the tile
+    if (kh == 1) {
+        double* dst = red + (wc * 64 + lane) * 8;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { *(d2*)(dst + 4 * e) = d2{acc[e][0], acc[e][1]}; *(d2*)(dst + 4 * e + 2) = d2{acc[e][2], acc[e][3]}; }
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const double* src = red + (wc * 64 + lane) * 8;
+        double* pt = sc.part + ((int64_t)pass * sc.ntiles + blockIdx.x) * 2048;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const d2 r01 = *(const d2*)(src + 4 * e), r23 = *(const d2*)(src + 4 * e + 2);
+            double* dst = pt + (wc * 32 + 2 * p + e) * 16 + 4 * q;      // lane (q, p) holds column c0 + 2 p + e, right-hand sides 4 g + q = slots 4 q + g
+            st_agent2(dst, acc[e][0] + r01.x, acc[e][1] + r01.y);
+            st_agent2(dst + 2, acc[e][2] + r23.x, acc[e][3] + r23.y);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tile (and whatever else this workgroup published) has left the CU before it is counted in
+    __syncthreads();
+    SM_MARK(sc, UPPER, 4);
+    if (tid == 0) *flag = atomicAdd(&sc.cnt[pass * sc.T + cb], 1u) == (unsigned)(nseg - 1);
+    __syncthreads();
+    SM_MARK(sc, UPPER, 5);
+    if (!*flag) return false;
+    if (tid == 0) sc.cnt[pass * sc.T + cb] = 0u;
+    const double* p0 = sc.part + ((int64_t)pass * sc.ntiles + t0) * 2048 + 2 * tid;
+    sum[0] = d2{0.0, 0.0};
+    sum[1] = d2{0.0, 0.0};
+    for (int s0 = 0; s0 < nseg; s0 += 12) {         // twelve segments in flight per piece (one round trip to the memory side, ~2 us), added in segment order
+        double v[12][4];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const double* src = p0 + (int64_t)min(s0 + j, nseg - 1) * 2048;
+            v[j][0] = ld_agent(src); v[j][1] = ld_agent(src + 1); v[j][2] = ld_agent(src + 1024); v[j][3] = ld_agent(src + 1025);
+        }
+        if (s0 == 0) meanwhile();
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+            if (s0 + j < nseg) { sum[0].x += v[j][0]; sum[0].y += v[j][1]; sum[1].x += v[j][2]; sum[1].y += v[j][3]; }
+    }
+    SM_MARK(sc, UPPER, 6);
+    return true;
+}
+
+// The posterior finish of one pass of 16 candidates (k_small_finish's formulas): q = sum of the column blocks' records in block order,
+// mu - beta likewise, sigma^2 = max(s_f^2 - q, 0), the acquisition value.  The records are fetched by all threads at once (one round
+// trip), then added by one thread per slot from LDS.  buf: >= 4096 doubles of LDS.  Thread `slot` (< 16) returns (f, candidate index).
+template <class Meanwhile>
+__device__ __forceinline__ void small_posterior_final(const SmallV& sv, int pass, int T, int P, double* buf, double& f_out, long long& idx_out,
+                                                      double& mu_o, double& s2_o, Meanwhile&& meanwhile) {
+    const int tid = threadIdx.x;
+    double qs = 0.0, mr = 0.0;
+    for (int b0 = 0; b0 < T; b0 += 128) {
+        const int nb = min(128, T - b0);
+        __syncthreads();
+        double qv[4], mv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * SP_THREADS;
+            qv[i] = e < nb * 16 ? ld_agent(sv.qpart + ((int64_t)pass * T + b0) * 16 + e) : 0.0;
+            mv[i] = e < nb * 16 ? ld_agent(sv.mupart + ((int64_t)pass * T + b0) * 16 + e) : 0.0;
+        }
+        if (b0 == 0) meanwhile();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * SP_THREADS;
+            if (e < nb * 16) { buf[e] = qv[i]; buf[2048 + e] = mv[i]; }
+        }
+        __syncthreads();
+        if (tid < 16) {      // (eight LDS reads in flight per step: a rolled loop pays one LDS latency per addend)
+            for (int b = 0; b < nb; b += 8) {
+                double tq[8], tm[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { tq[j] = buf[min(b + j, nb - 1) * 16 + tid]; tm[j] = buf[2048 + min(b + j, nb - 1) * 16 + tid]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (b + j < nb) qs += tq[j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (b + j < nb) mr += tm[j];
+            }
+        }
+    }
+    f_out = -INFINITY;
+    idx_out = -1;
+    mu_o = 0.0; s2_o = 0.0;
+    if (tid < 16) {
+        const int rr = pass * 16 + small_slot_to_r(tid);
+        if (rr < P) {
+            double mu, s2;
+            posterior_like_small_finish(sv.sigma2, sv.beta, qs, mr, mu, s2);
+            mu_o = mu; s2_o = s2;
+            if (sv.mu_out) sv.mu_out[rr] = mu;
+            if (sv.var_out) sv.var_out[rr] = s2;
+            const double f = acq_eval(sv.ap, mu, s2);
+            if (sv.score_out) sv.score_out[rr] = f;
+            f_out = f;
+            idx_out = rr;
+        }
+    }
+}
+
+// ---- V pass ---------------------------------------------------------------------------------------------------------------------------
+template <int DT>
+struct SmallXRow { double x[DT]; };
+template <int DT, int G>
+__global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV sv, KernelHyper hp) {
+    if (sc.go && *sc.go == 0u) return;
+    __shared__ __attribute__((aligned(16))) double lbuf[3 * 2048];
+    double* const rt2 = lbuf;             // 2 x [128][16] right-hand-side tiles
+    double* const red = lbuf + 4096;      // [4][64][8] hand-over of the contraction halves, later the finishers' scratch
+    __shared__ double xs_l[16 * DT];
+    __shared__ double mured[16 * 16];
+    __shared__ Best shb[SP_THREADS / 64];
+    __shared__ int flag;
+    const int tid = threadIdx.x, pass = blockIdx.y, d = hp.d, N = sc.N, T = sc.T;
+    SM_MARK(sc, 0, 0);
+    int cb, kc0, kc1, t0, nseg;
+    small_tile<0>(blockIdx.x, T, sc.m, cb, kc0, kc1, t0, nseg);
+    // the pass's candidates (row = r): 16 DT <= 1024 values, two per thread
+    auto setup_load = [&]() {
+        d2 v = {0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = tid + u * SP_THREADS, r = t / DT, k = t % DT, rr = pass * 16 + r;
+            const double x = (t < 16 * DT && rr < sc.P && k < d) ? sc.Xs[(int64_t)rr * d + k] : 0.0;
+            if (u) v.y = x; else v.x = x;
+        }
+        return v;
+    };
+    auto setup_store = [&](const d2& v) {
+        if (tid < 16 * DT) xs_l[tid] = v.x;
+        if (tid + SP_THREADS < 16 * DT) xs_l[tid + SP_THREADS] = v.y;
+        __syncthreads();
+    };
+    // K*' of a chunk: thread = (observation k, right-hand sides 4 g + i for g < G); k_kstar's expression, operation for operation
+    auto pre = [&](int kc) {
+        SmallXRow<DT> xr;
+        const int k = kc * 128 + (tid >> 2);
+#pragma unroll
+        for (int kk = 0; kk < DT; ++kk) xr.x[kk] = (kk < d && k < N) ? sc.X[(int64_t)k * d + kk] : 0.0;
+        return xr;
+    };
+    auto fill = [&](int kc, const SmallXRow<DT>& xr, double* rt_) {
+        const int kl = tid >> 2, i = tid & 3, k = kc * 128 + kl;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int r = 4 * g + i;
+            double rr = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < DT; ++kk) {
+                const double t = xr.x[kk] - xs_l[r * DT + kk];
+                rr += (kk < d ? hp.il2[kk] : 0.0) * (t * t);
+            }
+            v[g] = (k < N && pass * 16 + r < sc.P) ? cov_from_r_fast(hp.kern, hp.sigma2, rr) : 0.0;
+        }
+        *(d2*)(rt_ + kl * 16 + 4 * i) = d2{v[0], v[1]};
+        *(d2*)(rt_ + kl * 16 + 4 * i + 2) = d2{v[2], v[3]};
+    };
+    d2 sum[2];
+    double acc[2][4];
+    small_contract<0, G>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
+    // mu - beta = alpha' k*: the tile that holds the DIAGONAL chunk of its column block (the last chunk of the block's last segment) adds that
+    // chunk's share in a fixed order from the K*' tile still in LDS, and publishes the record BEFORE it counts itself in
+    if (kc1 - 1 == cb) {
+        const double* rt = rt2 + ((kc1 - 1 - kc0) & 1) * 2048;
+        if (!sv.finish) {     // (gradient call) K*' of the chunk for the U pass's finisher; plain stores, the next KERNEL reads them
+            double* kd = sv.ks16 + ((int64_t)pass * T * 128 + cb * 128) * 16 + 4 * tid;
+            *(d2*)kd = *(const d2*)(rt + 4 * tid);
+            *(d2*)(kd + 2) = *(const d2*)(rt + 4 * tid + 2);
+        }
+        if (tid < 256) {
+            const int slot = tid & 15, pt = tid >> 4;
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = cb * 128 + pt * 8 + j;
+                s += (k < N ? sc.alpha[k] : 0.0) * rt[(pt * 8 + j) * 16 + slot];
+            }
+            mured[pt * 16 + slot] = s;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) s += mured[j * 16 + tid];
+            st_agent(sv.mupart + ((int64_t)pass * T + cb) * 16 + tid, s);
+        }
+    }
+    if (!small_publish_combine<0>(sc, pass, red, &flag, cb, t0, nseg, acc, sum, [] {})) return;
+    // ---- the column block's finisher: V' of its 128 columns, q record
+    const int sp = tid & 7, cl0 = tid >> 3;                 // pieces (cl0, sp) and (cl0 + 64, sp)
+    double* vrow = sv.v16 + ((int64_t)pass * T * 128 + cb * 128) * 16;
+    *(d2*)(vrow + (cl0) * 16 + 2 * sp) = sum[0];
+    *(d2*)(vrow + (cl0 + 64) * 16 + 2 * sp) = sum[1];
+    d2 qq = {0.0, 0.0};
+    if (cb * 128 + cl0 < N) { qq.x += sum[0].x * sum[0].x; qq.y += sum[0].y * sum[0].y; }
+    if (cb * 128 + cl0 + 64 < N) { qq.x += sum[1].x * sum[1].x; qq.y += sum[1].y * sum[1].y; }
+    *(d2*)(lbuf + cl0 * 16 + 2 * sp) = qq;                  // (the right-hand-side tiles are done with: every wave is past the contraction)
+    __syncthreads();
+    if (tid < 16) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) s += lbuf[j * 16 + tid];
+        st_agent(sv.qpart + ((int64_t)pass * T + cb) * 16 + tid, s);
+    }
+    SM_MARK(sc, 0, 7);
+    if (!sv.finish) return;                 // (gradient call: k_small_u's last workgroup finishes the posterior)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) flag = atomicAdd(&sc.cnt[gridDim.y * T + pass], 1u) == (unsigned)(T - 1);
+    __syncthreads();
+    if (!flag) return;
+    SM_MARK(sc, 0, 8);
+    if (tid == 0) sc.cnt[gridDim.y * T + pass] = 0u;
+    // ---- the pass's finisher: q, mu, sigma^2, value per candidate, arg-max of the batch
+    double f_best, mu_, s2_;
+    long long idx;
+    const int npass = gridDim.y;
+    small_posterior_final(sv, pass, T, sc.P, lbuf, f_best, idx, mu_, s2_, [] {});
+    SM_MARK(sc, 0, 9);
+    if (!sv.best_out) return;
+    if (npass > 1) {
+        if (idx >= 0) st_agent(sv.fstash + idx, f_best);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) flag = atomicAdd(&sc.cnt[npass * T + npass], 1u) == (unsigned)(npass - 1);
+        __syncthreads();
+        if (!flag) return;
+        if (tid == 0) sc.cnt[npass * T + npass] = 0u;
+        f_best = -INFINITY; idx = -1;
+        if (tid < sc.P) { f_best = ld_agent(sv.fstash + tid); idx = tid; }
+    }
+    if (!(f_best > -INFINITY)) idx = -1;   // NaN and -Inf never win (reference: `f > maxf` is false for NaN)
+    block_argmax(f_best, idx, shb);
+    SM_MARK(sc, 0, 10);
+    if (tid == 0) { sv.best_out->val = idx >= 0 ? f_best : -INFINITY; sv.best_out->idx = idx >= 0 ? idx + sv.idx_off : -1; }
+}
+
+// ---- U pass ---------------------------------------------------------------------------------------------------------------------------
+// U' = V' W (A = W, contraction k >= c), then the gradient (k_grad_finish's formulas: reference src/acquisition.jl:11-17 wrap_gradient's
+// role, analytic): the finisher of column block cb holds u_j for its 128 observations j and all slots, adds
+//   gm[k] = sum_j dk*_j/dx_k alpha_j,  gv[k] = sum_j dk*_j/dx_k u_j      over its observations in a fixed order
+// into a record; the finisher of the last block adds the records in block order and applies the chain rule.
+struct SmallVPair { d2 a, b; };
+template <int DT, int G>
+__global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU su, KernelHyper hp) {
+    if (sc.go && *sc.go == 0u) return;
+    __shared__ __attribute__((aligned(16))) double lbuf[3 * 2048];
+    double* const rt2 = lbuf;
+    double* const red = lbuf + 4096;
+    __shared__ double xs_l[16 * DT];
+    __shared__ double xc_l[128 * DT];     // the column block's 128 observations and their alpha: fetched at the START of the kernel by every
+    __shared__ double al_l[128];          // tile (8 KB at d = 8), so that the block's finisher finds them in LDS instead of behind four round trips
+    __shared__ __attribute__((aligned(16))) double ks_l[128 * 16];   // K*' of the block's observations (from k_small_v)
+    __shared__ double post_l[32];
+    __shared__ int flag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pass = blockIdx.y, d = hp.d, N = sc.N, T = sc.T;
+    SM_MARK(sc, 1, 0);
+    int cb, kc0, kc1, t0, nseg;
+    small_tile<1>(blockIdx.x, T, sc.m, cb, kc0, kc1, t0, nseg);
+    const double* vsrc = su.v16 + (int64_t)pass * T * 128 * 16;
+    auto setup_load = [&]() { return 0; };
+    auto setup_store = [&](int) {
+        // candidates, the block's observations and alpha: requested BEHIND the matrix loads (nothing waits for them before the tile is
+        // published), no barrier (read many barriers from here)
+        for (int t = tid; t < 16 * DT; t += SP_THREADS) {
+            const int r = t / DT, k = t % DT, rr = pass * 16 + r;
+            xs_l[t] = (rr < sc.P && k < d) ? sc.Xs[(int64_t)rr * d + k] : 0.0;
+        }
+        const int64_t e0 = (int64_t)cb * 128 * d, e1 = min((int64_t)N * d, e0 + 128 * d);
+        for (int t = tid; t < 128 * d; t += SP_THREADS) xc_l[t] = e0 + t < e1 ? sc.X[e0 + t] : 0.0;
+        if (tid < 128) al_l[tid] = cb * 128 + tid < N ? sc.alpha[cb * 128 + tid] : 0.0;
+        const double* ksrc = su.sv.ks16 + ((int64_t)pass * T * 128 + cb * 128) * 16 + 4 * tid;
+        *(d2*)(ks_l + 4 * tid) = *(const d2*)ksrc;
+        *(d2*)(ks_l + 4 * tid + 2) = *(const d2*)(ksrc + 2);
+    };
+    auto pre = [&](int kc) {                    // V' of the chunk (slot layout, written by k_small_v), rows beyond N as zeros
+        SmallVPair v{{0.0, 0.0}, {0.0, 0.0}};
+        if (kc * 128 + (tid >> 2) < N) {
+            const double* src = vsrc + (int64_t)kc * 2048 + 4 * tid;
+            v.a = *(const d2*)src;
+            v.b = *(const d2*)(src + 2);
+        }
+        return v;
+    };
+    auto fill = [&](int, const SmallVPair& v, double* rt_) {
+        *(d2*)(rt_ + 4 * tid) = v.a;
+        *(d2*)(rt_ + 4 * tid + 2) = v.b;
+    };
+    d2 sum[2];
+    double acc[2][4];
+    small_contract<1, G>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
+    // the block's finisher, while the partial tiles are on their way: everything of the gradient sums that does not need u -- the
+    // kernel factor of each of its four observations and the alpha-weighted sums
+    const int slot = tid & 15, cg = tid >> 4, r = small_slot_to_r(slot);
+    const bool active = pass * 16 + r < sc.P;
+    double gm[DT], gv[DT], fac[4];
+    auto meanwhile = [&]() {
+#pragma unroll
+        for (int k = 0; k < DT; ++k) { gm[k] = 0.0; gv[k] = 0.0; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cl = cg * 4 + i, j = cb * 128 + cl;
+            fac[i] = 0.0;
+            if (j < N && active) {
+                double t[DT], rr = 0.0;
+#pragma unroll
+                for (int k = 0; k < DT; ++k)
+                    if (k < d) {
+                        t[k] = xs_l[r * DT + k] - xc_l[cl * d + k];
+                        rr += hp.il2[k] * (t[k] * t[k]);
+                    }
+                if (hp.kern == KERN_MAT52ARD) {
+                    const double s = sqrt(5.0) * sqrt(rr);
+                    fac[i] = -(5.0 / 3.0) * hp.sigma2 * (1.0 + s) * exp(-s);
+                } else {
+                    fac[i] = -ks_l[cl * 16 + slot];      // = -(sigma2 exp(-rr / 2)): k_small_v's own value of it, same expression on the same rr
+                }
+                const double a = al_l[cl];
+#pragma unroll
+                for (int k = 0; k < DT; ++k)
+                    if (k < d) gm[k] += (fac[i] * t[k] * hp.il2[k]) * a;
+            }
+        }
+    };
+    if (!small_publish_combine<1>(sc, pass, red, &flag, cb, t0, nseg, acc, sum, meanwhile)) return;
+    // ---- the column block's finisher: u of its 128 observations -> LDS, then the u-weighted gradient sums of those observations
+    double* const ul = lbuf;                   // (the right-hand-side tiles are done with)
+    {
+        const int sp = tid & 7, cl0 = tid >> 3;
+        *(d2*)(ul + cl0 * 16 + 2 * sp) = sum[0];
+        *(d2*)(ul + (cl0 + 64) * 16 + 2 * sp) = sum[1];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cl = cg * 4 + i, j = cb * 128 + cl;
+        if (j < N && active) {
+            const double uj = ul[cl * 16 + slot];
+#pragma unroll
+            for (int k = 0; k < DT; ++k)
+                if (k < d) gv[k] += (fac[i] * (xs_l[r * DT + k] - xc_l[cl * d + k]) * hp.il2[k]) * uj;
+        }
+    }
+    SM_MARK(sc, 1, 7);
+    // the four lanes of a wave that share a slot (lane bits 4, 5), then the eight waves in wave order: rounds of 8 dimensions x {m, v}
+    double* grec = su.gpart + (((int64_t)pass * T + cb) * 16) * (2 * DT);
+#pragma unroll
+    for (int kb = 0; kb < DT; kb += 8) {
+        if (kb >= d) break;
+        double val[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double a = kb + k < DT ? gm[kb + k] : 0.0, b = kb + k < DT ? gv[kb + k] : 0.0;
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+            val[2 * k] = a; val[2 * k + 1] = b;
+        }
+        if (kb > 0) __syncthreads();         // (red: the previous round's readers are done; round 0: red was last read before the block's counter)
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) red[(wave * 16 + lane) * 16 + k] = val[k];
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int sl = tid & 15, vi = tid >> 4;
+            double s = 0.0;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; ++w8) s += red[(w8 * 16 + sl) * 16 + vi];
+            if (2 * kb + vi < 2 * DT) st_agent(grec + sl * (2 * DT) + 2 * kb + vi, s);
+        }
+    }
+    SM_MARK(sc, 1, 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) flag = atomicAdd(&sc.cnt[gridDim.y * T + pass], 1u) == (unsigned)(T - 1);
+    __syncthreads();
+    if (!flag) return;
+    SM_MARK(sc, 1, 9);
+    if (tid == 0) sc.cnt[gridDim.y * T + pass] = 0u;
+    // ---- the pass's finisher: the posterior of the pass's candidates (what k_small_v's finisher does in a value-only call: same function,
+    // same bits) and the gradient records in block order, both fetched in ONE round trip; then the chain rule through the reference's
+    // acquisition formulas.  (slot, dimension) pairs; the block records of a pair are fetched by `nparts` threads at once and the parts added
+    // in part order: the order depends on (T, d) only
+    const double* gp = su.gpart + ((int64_t)pass * T * 16) * (2 * DT);
+    const int npairs = 16 * d, nparts = max(1, min(8, SP_THREADS / npairs)), bpp = (T + nparts - 1) / nparts;
+    double* gfin = lbuf;                                 // [nparts][npairs][2]  (<= 8 * 64 * 2 or 2 * 256 * 2 doubles) -- behind small_posterior_final's use of lbuf
+    const bool fast = nparts > 1 && bpp <= 8;            // one round trip for everything (T <= 8 nparts)
+    double ga = 0.0, gb = 0.0;
+    const int pair = tid % npairs, part = tid / npairs;
+    auto fetch = [&]() {
+        if (!fast || tid >= npairs * nparts) return;
+        const double* src = gp + (int64_t)(pair / d) * (2 * DT) + 2 * (pair % d);
+        const int bl0 = part * bpp, bl1 = min(T, bl0 + bpp);
+        double va[8], vb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double* s2 = src + (int64_t)min(bl0 + j, T - 1) * 16 * (2 * DT);
+            va[j] = ld_agent(s2); vb[j] = ld_agent(s2 + 1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (bl0 + j < bl1) { ga += va[j]; gb += vb[j]; }
+    };
+    {
+        double f, mu_, s2_;
+        long long idx;
+        small_posterior_final(su.sv, pass, T, sc.P, lbuf, f, idx, mu_, s2_, fetch);
+        if (tid < 16) { post_l[2 * tid] = mu_; post_l[2 * tid + 1] = s2_; }
+        __syncthreads();
+    }
+    SM_MARK(sc, 1, 10);
+    for (int e0 = 0; e0 < npairs; e0 += SP_THREADS) {    // (one trip unless d > 32)
+        const int e = e0 + tid, pr = nparts > 1 ? pair : e, pt = nparts > 1 ? part : 0;
+        const bool mine = nparts > 1 ? tid < npairs * nparts : e < npairs;
+        const int sl = pr / d, k = pr % d;
+        double a = ga, b = gb;
+        if (mine && !fast) {
+            const double* src = gp + (int64_t)sl * (2 * DT) + 2 * k;
+            const int bl0 = pt * bpp, bl1 = min(T, bl0 + bpp);
+            for (int b0 = bl0; b0 < bl1; b0 += 8) {          // eight records in flight, added in block order
+                double va[8], vb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const double* s2 = src + (int64_t)min(b0 + j, bl1 - 1) * 16 * (2 * DT);
+                    va[j] = ld_agent(s2); vb[j] = ld_agent(s2 + 1);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (b0 + j < bl1) { a += va[j]; b += vb[j]; }
+            }
+        }
+        if (nparts > 1) {
+            if (mine) { gfin[(pt * npairs + pr) * 2] = a; gfin[(pt * npairs + pr) * 2 + 1] = b; }
+            __syncthreads();
+            if (tid >= npairs) continue;
+            a = 0.0; b = 0.0;
+#pragma unroll
+            for (int pp = 0; pp < 8; ++pp)
+                if (pp < nparts) { a += gfin[(pp * npairs + tid) * 2]; b += gfin[(pp * npairs + tid) * 2 + 1]; }
+        } else if (!mine) {
+            continue;
+        }
+        const int rr = pass * 16 + small_slot_to_r(sl);
+        if (rr >= sc.P) continue;
+        const double m = post_l[2 * sl], v = post_l[2 * sl + 1];
+        double dmu, ds2;
+        acq_partials(su.sv.ap, m, v, dmu, ds2);
+        // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
+        su.grad[(int64_t)rr * d + k] = dmu * a + (v > 0.0 ? ds2 * (-2.0 * b) : 0.0);
+    }
+    SM_MARK(sc, 1, 11);
+}
+
+}  // namespace bohip
