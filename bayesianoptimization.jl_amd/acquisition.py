@@ -230,7 +230,7 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
     return best_f, best_X
 
 
-def _batched_direct_l(f_batch, lb, ub, maxeval, stopval=math.inf):
+def _batched_direct_l(f_batch, lb, ub, maxeval, stopval=math.inf, maxtime=0.0):
     """DIviding RECTangles, locally biased (Gablonsky & Kelley 2001) -- the role of NLopt's :GN_DIRECT_L, which the reference uses
     by default for ThompsonSamplingSimple (src/acquisition.jl:7-9: restarts = 1, maxeval = 2000) -- for MAXIMISATION, with ALL the
     new points of one iteration evaluated in ONE device call: f_batch(X[d, n]) -> f[n].
@@ -239,7 +239,11 @@ def _batched_direct_l(f_batch, lb, ub, maxeval, stopval=math.inf):
     rectangle per size (Jones' epsilon = 0), a cube is trisected along every side -- best sampled value first, so the best points
     end up in the largest boxes -- and any other rectangle along its first longest side only.  What is NOT reproduced is NLopt's
     evaluation ORDER inside an iteration (irrelevant for a deterministic objective, a different random stream for a sampled one).
+    `maxtime` > 0: NLopt's wall-clock budget in seconds (the reference's test passes it; checked once per iteration).
     Returns (best value, best point, evaluations)."""
+    import time
+
+    deadline = time.monotonic() + maxtime if maxtime and maxtime > 0 else math.inf
     lb = np.asarray(lb, float); ub = np.asarray(ub, float)
     d = lb.size
     span = ub - lb
@@ -249,7 +253,7 @@ def _batched_direct_l(f_batch, lb, ub, maxeval, stopval=math.inf):
     F = np.asarray(f_batch(to_x(C)), float).reshape(-1)
     F = np.where(np.isnan(F), -math.inf, F)
     evals = 1
-    while evals < maxeval and not (F.max() >= stopval):
+    while evals < maxeval and not (F.max() >= stopval) and time.monotonic() < deadline:
         size = Lv.min(axis=0)                                     # key of the longest side (smaller = larger rectangle)
         keys = np.unique(size)
         best_of = {}
@@ -365,7 +369,7 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None, setparams
             def f_batch(X):
                 return model.score(a.acq_id, a.params(), X)[0]
         for _ in range(restarts):
-            f, x, _ = _batched_direct_l(f_batch, lb, ub, max(1, maxeval), sval)
+            f, x, _ = _batched_direct_l(f_batch, lb, ub, max(1, maxeval), sval, maxtime)
             if f > maxf:                                          # :62 strict '>'
                 maxf, maxx = f, x
             if not isinstance(a, ThompsonSamplingSimple):

@@ -330,19 +330,129 @@ function acquire_max_device(a::AbstractAcquisition, m::AbstractBOHipModel, lower
         check(rc)
         return best[].idx < 0 ? (maxf, maxx) : (best[].val, bx)
     end
-    # derivative-free methods (:GN_*, :LN_*): `maxeval` Latin-hypercube candidates per restart, ONE batch on the device
+    if occursin("DIRECT", uppercase(string(options.method)))
+        # :GN_DIRECT* -- dividing rectangles, every iteration's new points in ONE device call (same search as the Python mirror's
+        # acquisition._batched_direct_l; tests/test_julia_binding.py keeps the two from drifting).  DIRECT ignores the start point and the
+        # acquisition is deterministic: every restart would be the same run, so one run.
+        f_batch = X -> score(m, a, X)[1]
+        f, x, _ = _batched_direct_l(f_batch, lb, ub, max(1, options.maxeval); stopval = Float64(get(options, :stopval, Inf)),
+                                    maxtime = Float64(get(options, :maxtime, 0.0)))
+        return isfinite(f) ? (f, x) : (maxf, maxx)
+    end
+    # other derivative-free methods (:LN_*, non-DIRECT :GN_*): `maxeval` Latin-hypercube candidates per restart, ONE batch on the device
     n = clamp(options.maxeval * options.restarts, options.restarts, 1 << 20)
     cand = BO.latin_hypercube_sampling(lb, ub, n)
     _, f, j = score(m, a, cand; scores = false)
     j == 0 ? (maxf, maxx) : (f, cand[:, j])
 end
+
+"""
+DIviding RECTangles, locally biased (Gablonsky & Kelley 2001): the role of NLopt's `:GN_DIRECT_L`, the reference's default for
+`ThompsonSamplingSimple` (src/acquisition.jl:7-9: restarts = 1, maxeval = 2000), for MAXIMISATION, with ALL the new points of one
+iteration evaluated in ONE call `f_batch(X::Matrix) -> Vector` (columns are points).  NLopt's rules for this algorithm (cdirect.c,
+`which_alg = 13`): a rectangle's size is its longest side; the potentially optimal set is the upper convex hull of (size, best value
+of that size) from the incumbent's size up, one rectangle per size (Jones' epsilon = 0); a cube is trisected along every side, best
+sampled value first; any other rectangle along its first longest side only.  Not reproduced: NLopt's evaluation order inside an
+iteration.  Statement for statement the Python mirror's `_batched_direct_l`.  Returns (best value, best point, evaluations).
+"""
+function _batched_direct_l(f_batch, lb::Vector{Float64}, ub::Vector{Float64}, maxeval::Integer; stopval = Inf, maxtime = 0.0)
+    d = length(lb); span = ub .- lb
+    to_x(U) = lb .+ span .* U                                    # unit cube -> box, columns are points
+    deadline = maxtime > 0 ? time() + maxtime : Inf              # NLopt maxtime (the reference's test passes it)
+    C = fill(0.5, d, 1)                                          # centres (unit cube)
+    Lv = zeros(Int, d, 1)                                        # level per side: side length 3^-level
+    clean(v) = [isnan(x) ? -Inf : x for x in v]
+    F = clean(vec(f_batch(to_x(C))))
+    evals = 1
+    while evals < maxeval && !(maximum(F) >= stopval) && time() < deadline
+        size_ = vec(minimum(Lv, dims = 1))                       # key of the longest side (smaller = larger rectangle)
+        best_of = Dict{Int, Int}()
+        for k in sort(unique(size_))                             # one rectangle per size: the best, first on ties
+            idx = findall(==(k), size_)
+            best_of[k] = idx[argmax(F[idx])]
+        end
+        jmax = argmax(F)
+        # upper hull over (diameter, f) from the incumbent's size towards the larger rectangles
+        smax = size_[jmax]
+        cand = sort(filter(k -> k <= smax, collect(keys(best_of))), rev = true)           # increasing diameter
+        hull = Tuple{Float64, Float64, Int}[]
+        for k in cand
+            pt = (3.0^(-k), F[best_of[k]], best_of[k])
+            while length(hull) >= 2
+                (x1, y1, _) = hull[length(hull) - 1]; (x2, y2, _) = last(hull)
+                if (y2 - y1) * (pt[1] - x1) <= (pt[2] - y1) * (x2 - x1)                   # the middle point is not above the chord
+                    pop!(hull)
+                else
+                    break
+                end
+            end
+            push!(hull, pt)
+        end
+        chosen = [j for (_, _, j) in hull]
+        # new points of this iteration (capped by the evaluation budget)
+        plan = Tuple{Int, Vector{Int}, Int}[]; cols = Vector{Float64}[]
+        for j in chosen
+            lv = Lv[:, j]; kmin = minimum(lv)
+            longest = findall(==(kmin), lv)
+            dims = length(longest) == d ? longest : longest[1:1]                          # a cube: every side; otherwise the first longest side
+            if evals + length(cols) + 2 * length(dims) > maxeval
+                dims = dims[1:max(0, (maxeval - evals - length(cols)) ÷ 2)]
+            end
+            isempty(dims) && continue
+            delta = 3.0^(-(kmin + 1))
+            start = length(cols)
+            for i in dims, sgn in (+1.0, -1.0)
+                c = C[:, j]; c[i] += sgn * delta
+                push!(cols, c)
+            end
+            push!(plan, (j, dims, start))
+        end
+        isempty(cols) && break
+        Unew = reduce(hcat, cols)
+        Fnew = clean(vec(f_batch(to_x(Unew))))
+        evals += length(Fnew)
+        newL = Matrix{Int}(undef, d, length(Fnew))
+        for (j, dims, start) in plan
+            w = map(t -> max(Fnew[start + 2t - 1], Fnew[start + 2t]), 1:length(dims))
+            order = sortperm(-w, alg = MergeSort)                                         # best sampled value first (stable)
+            lv = Lv[:, j]
+            for t in order
+                lv[dims[t]] += 1                                 # the parent shrinks along i; the two children inherit the levels so far
+                newL[:, start + 2t - 1] = lv
+                newL[:, start + 2t] = lv
+            end
+            Lv[:, j] = lv
+        end
+        C = hcat(C, Unew); Lv = hcat(Lv, newL); F = vcat(F, Fnew)
+    end
+    jb = argmax(F)
+    F[jb], to_x(C[:, jb:jb])[:, 1], evals
+end
+
 function acquire_max_device(::ThompsonSamplingSimple, m::AbstractBOHipModel, lowerbounds, upperbounds, options)
     # acquisitionfunction(::ThompsonSamplingSimple, model) = x -> myrand(model, x) under a global derivative-free search
-    # (src/acquisitionfunctions.jl:107-108, defaults :GN_DIRECT_L): one posterior draw per candidate, arg-max on the device
+    # (src/acquisitionfunctions.jl:107-108, defaults :GN_DIRECT_L)
     _check_options(options)
     lb = Float64.(lowerbounds); ub = Float64.(upperbounds)
     maxf = -Inf; maxx = lb
     isempty(m.y) && return maxf, maxx
+    if occursin("DIRECT", uppercase(string(options.method)))
+        # the reference's default: dividing rectangles over x -> myrand(model, x), ONE posterior draw per new point
+        # (mu + sigma z, src/models/gp.jl:6), a whole iteration's points per device call; `restarts` fresh runs
+        f_batch = function (X)
+            mu, var = mean_var(m, X)
+            mu .+ sqrt.(max.(var, 0.0)) .* randn(length(mu))
+        end
+        for _ in 1:options.restarts
+            f, x, _ = _batched_direct_l(f_batch, lb, ub, max(1, options.maxeval); stopval = Float64(get(options, :stopval, Inf)),
+                                        maxtime = Float64(get(options, :maxtime, 0.0)))
+            if f > maxf                                          # src/acquisition.jl:62 strict '>'
+                maxf = f; maxx = x
+            end
+        end
+        return maxf, maxx
+    end
+    # other derivative-free methods: one posterior draw per Latin-hypercube candidate, arg-max on the device
     for _ in 1:options.restarts
         cand = BO.latin_hypercube_sampling(lb, ub, max(options.maxeval, 1))
         best = Ref(Best(-Inf, -1))

@@ -128,3 +128,36 @@ def test_julia_module_owns_the_loop_for_device_models():
     assert opens == ends, (opens, ends)
     for a, b in ("()", "[]", "{}"):
         assert code.count(a) == code.count(b), (a, code.count(a), code.count(b))
+
+
+def test_both_hosts_take_the_same_route_for_direct_methods():
+    """:GN_DIRECT* (the reference's default for ThompsonSamplingSimple, src/acquisition.jl:7-9) runs the SAME batched dividing-rectangles
+    search on both hosts: the Python mirror (acquisition._batched_direct_l) and the reference-side binding (julia/BOHip.jl).  Julia cannot
+    run here, so the rules are compared as text: every rule statement of one has its counterpart in the other, both dispatch on "DIRECT"
+    in the method name in the generic AND the ThompsonSamplingSimple method, and both honour maxtime / stopval."""
+    jl = open(JL).read()
+    py = open(os.path.join(ROOT, "bayesianoptimization.jl_amd", "acquisition.py")).read()
+    jfun = jl[jl.index("function _batched_direct_l("):jl.index("function acquire_max_device(::ThompsonSamplingSimple")]
+    pfun = py[py.index("def _batched_direct_l("):py.index("# NLopt.Opt properties the reference forwards")]
+    pairs = [
+        ("np.full((d, 1), 0.5)", "fill(0.5, d, 1)"),                                             # start: the centre of the unit cube
+        ("size = Lv.min(axis=0)", "minimum(Lv, dims = 1)"),                                      # a rectangle's size = its longest side
+        ("3.0 ** (-k)", "3.0^(-k)"),                                                             # hull abscissa
+        ("(y2 - y1) * (pt[0] - x1) <= (pt[1] - y1) * (x2 - x1)", "(y2 - y1) * (pt[1] - x1) <= (pt[2] - y1) * (x2 - x1)"),   # upper-hull test
+        ("longest if longest.size == d else longest[:1]", "length(longest) == d ? longest : longest[1:1]"),   # cube: all sides; else the first longest
+        ("3.0 ** (-(kmin + 1))", "3.0^(-(kmin + 1))"),                                           # trisection step
+        ("(maxeval - evals - len(cols)) // 2", "(maxeval - evals - length(cols)) ÷ 2"),          # evaluation budget
+        ("np.argsort(-w, kind=\"stable\")", "sortperm(-w, alg = MergeSort)"),                    # best sampled value first, stable
+        ("F.max() >= stopval", "maximum(F) >= stopval"),
+        ("time.monotonic() < deadline", "time() < deadline"),
+        ("np.where(np.isnan(F), -math.inf, F)", "isnan(x) ? -Inf : x"),                          # NaN never wins
+    ]
+    for a, b in pairs:
+        assert a in pfun, ("python", a)
+        assert b in jfun, ("julia", b)
+    assert jl.count('occursin("DIRECT", uppercase(string(options.method)))') == 2           # generic + ThompsonSamplingSimple
+    assert jl.count("_batched_direct_l(f_batch, lb, ub, max(1, options.maxeval)") == 2
+    assert py.count("_batched_direct_l(f_batch, lb, ub, max(1, maxeval), sval, maxtime)") == 1 and '"DIRECT" in method.upper()' in py
+    # one posterior draw per new point in both (mu + sigma z, src/models/gp.jl:6)
+    assert "mu .+ sqrt.(max.(var, 0.0)) .* randn(length(mu))" in jl
+    assert "np.sqrt(np.maximum(np.asarray(var), 0.0)) * gen.standard_normal(np.size(mu))" in py
