@@ -153,7 +153,26 @@ struct bohip_mgp {
     int64_t R_res = 0;
     std::vector<DevWorker*> workers;
     int64_t exchanges = 0;
+    // round 5: pinned staging of the candidates, one buffer per device (hipMemcpyAsync from pageable memory is staged by the runtime on the
+    // calling thread; from pinned memory the copy engines of nd devices really run side by side)
+    std::vector<double*> hstage;
+    std::vector<size_t> hstage_cap;
 };
+// host candidates -> device i: through that device's pinned staging buffer (filled on the device's worker thread), then one async copy
+static int mgp_stage_h2d(bohip_mgp* m, int i, double* dst, const double* src, size_t n_doubles, hipStream_t st) {
+    if (n_doubles == 0) return 0;
+    if (m->hstage_cap[i] < n_doubles) {
+        if (m->hstage[i]) { HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipHostFree(m->hstage[i])); m->hstage[i] = nullptr; m->hstage_cap[i] = 0; }
+        const size_t cap = n_doubles + n_doubles / 2 + 64;
+        HIPCHK(hipHostMalloc((void**)&m->hstage[i], cap * 8, hipHostMallocPortable));
+        m->hstage_cap[i] = cap;
+    } else {
+        HIPCHK(hipStreamSynchronize(st));   // (an earlier copy out of this buffer must have left it; the calls of this library are synchronous anyway)
+    }
+    std::memcpy(m->hstage[i], src, n_doubles * 8);
+    HIPCHK(hipMemcpyAsync(dst, m->hstage[i], n_doubles * 8, hipMemcpyHostToDevice, st));
+    return 0;
+}
 
 // run fn(i) for every device: on the device's worker thread, or inline (BOHIP_MGP_THREADS=0 / one device)
 static int mgp_for_each(bohip_mgp* m, const std::function<int(int)>& fn) {
@@ -188,7 +207,10 @@ static int mgp_ensure_records(bohip_mgp* m, int64_t S) {
     }
     if (m->hfinal) HIPCHK(hipHostFree(m->hfinal));
     m->hfinal = nullptr;
-    HIPCHK(hipHostMalloc((void**)&m->hfinal, (size_t)m->nd * S * sizeof(Best), hipHostMallocDefault));
+    // every device's reduce kernel writes its copy into this block: portable (pinned for every device context, whichever was current
+    // here) and mapped (device-visible through the host address under unified addressing) -- requested explicitly, not left to the default
+    HIPCHK(hipSetDevice(m->devs[0]));
+    HIPCHK(hipHostMalloc((void**)&m->hfinal, (size_t)m->nd * S * sizeof(Best), hipHostMallocPortable | hipHostMallocMapped));
     m->rec_cap = S;
     return 0;
 }
@@ -204,16 +226,15 @@ static int mgp_exchange(bohip_mgp* m, int64_t S, Best* out) {
         if (r != ncclSuccess) { R->GroupEnd(); return fail(BOHIP_E_COMM, std::string("ncclAllGather: ") + R->GetErrorString(r)); }
     }
     NCCLCHK(R->GroupEnd());
-    for (int i = 0; i < m->nd; ++i) {
+    // reduce + drain per device on the device's own worker thread: nd streams are waited for side by side, not one after another
+    CHK(mgp_for_each(m, [&](int i) -> int {
         HIPCHK(hipSetDevice(m->devs[i]));
         hipLaunchKernelGGL(k_reduce_records, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, m->h[i]->stream, m->drecv[i],
                            m->nd * m->spd, (int)S, m->hfinal + (int64_t)i * S);
         HIPCHK(hipGetLastError());
-    }
-    for (int i = 0; i < m->nd; ++i) {
-        HIPCHK(hipSetDevice(m->devs[i]));
         HIPCHK(hipStreamSynchronize(m->h[i]->stream));
-    }
+        return 0;
+    }));
     // every device reduced the same gathered records with the same kernel: its copy can only differ if the collective delivered
     // different data to different ranks.  Checked on request (BOHIP_MGP_VERIFY=1, and in the tests), not on every step.
     static const bool verify = getenv("BOHIP_MGP_VERIFY") != nullptr && atoi(getenv("BOHIP_MGP_VERIFY")) != 0;
@@ -286,6 +307,8 @@ int bohip_mgp_create(int64_t d, int64_t capacity, int kernel_id, const int* devi
     m->drecv.assign(n_devices, nullptr);
     m->dcand.assign(n_devices, nullptr);
     m->cand_cap.assign(n_devices, 0);
+    m->hstage.assign(n_devices, nullptr);
+    m->hstage_cap.assign(n_devices, 0);
     m->threads = n_devices > 1;
     if (const char* e = getenv("BOHIP_MGP_THREADS")) m->threads = atoi(e) != 0;
     int rc = 0;
@@ -339,6 +362,7 @@ void bohip_mgp_destroy(bohip_mgp* m) {
         if (m->h[i]) bohip_gp_destroy(m->h[i]);
     }
     if (m->hfinal) hipHostFree(m->hfinal);
+    for (double* p : m->hstage) if (p) hipHostFree(p);
     (void)hipGetLastError();   // a failed call above must not surface as the "last error" of an unrelated later launch
     delete m;
 }
@@ -395,7 +419,7 @@ int bohip_mgp_score(bohip_mgp* m, int acq_id, const double* acq_params, const do
         if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
         CHK(ensure_xs(g, std::max<int64_t>(Rd, 1)));
         CHK(ensure_score_scratch(g, std::max<int64_t>(Rd, 1)));
-        if (Rd > 0) HIPCHK(hipMemcpyAsync(g->dXs, Xs + lo * g->d, (size_t)Rd * g->d * 8, hipMemcpyHostToDevice, g->stream));
+        CHK(mgp_stage_h2d(m, i, g->dXs, Xs + lo * g->d, (size_t)Rd * g->d, g->stream));
         CHK(mgp_score_device(m, i, acq_id, acq_params, g->dXs, R, score != nullptr));
         if (score && Rd > 0) HIPCHK(hipMemcpyAsync(score + lo, g->dscore, (size_t)Rd * 8, hipMemcpyDeviceToHost, g->stream));
         return 0;
@@ -416,7 +440,7 @@ int bohip_mgp_set_candidates(bohip_mgp* m, const double* Xs, int64_t R) {
             HIPCHK(hipMalloc(&m->dcand[i], std::max<size_t>(8, (size_t)Rd * g->d * 8)));
             m->cand_cap[i] = Rd * g->d;
         }
-        if (Rd > 0) HIPCHK(hipMemcpyAsync(m->dcand[i], Xs + lo * g->d, (size_t)Rd * g->d * 8, hipMemcpyHostToDevice, g->stream));
+        CHK(mgp_stage_h2d(m, i, m->dcand[i], Xs + lo * g->d, (size_t)Rd * g->d, g->stream));
         HIPCHK(hipStreamSynchronize(g->stream));
         return 0;
     }));
@@ -456,7 +480,7 @@ int bohip_mgp_thompson(bohip_mgp* m, const double* Xs, int64_t R, int64_t S, uin
         const int64_t Rd = hi_dev - lo_dev;
         CHK(ensure_xs(g, std::max<int64_t>(Rd, 1)));
         CHK(ensure_score_scratch(g, std::max<int64_t>(Rd, 1)));
-        if (Rd > 0) HIPCHK(hipMemcpyAsync(g->dXs, Xs + lo_dev * g->d, (size_t)Rd * g->d * 8, hipMemcpyHostToDevice, g->stream));
+        CHK(mgp_stage_h2d(m, i, g->dXs, Xs + lo_dev * g->d, (size_t)Rd * g->d, g->stream));
         HintGuard hint(g, R);
         for (int ls = 0; ls < m->spd; ++ls) {
             const int64_t s = (int64_t)i * m->spd + ls, lo = shard_lo(R, G, s), hi = shard_lo(R, G, s + 1);
