@@ -297,6 +297,10 @@ def report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_
                      **({"sustained_clock_mhz": clock_mhz, "peak_at_sustained_clock": FP64_PEAK_TFLOPS * clock_mhz / 2400.0,
                          "frac_of_peak_at_sustained_clock": achieved / (FP64_PEAK_TFLOPS * clock_mhz / 2400.0)} if clock_mhz > 0 else {})},
         "stage_ms": {**{k: v for k, v in info_ms.items() if k != "trigemm_sq"}, **stage_ms},
+        "stage_ms_note": "trigemm_sq: HIP events around the kernel over the TIMED steps (what roofline.achieved uses; the kernel trace in "
+                         "profiles/ agrees).  Every other stage: event brackets of the warm-up steps with ALL stages bracketed -- a bracket adds "
+                         "the launch gap and two event records (~10-12 us) to a short kernel: `kstar` reads ~40 us here where the kernel trace "
+                         "says 28 us for k_kstar itself (2.5 vs 3.6 TB/s of K*' written); the trace is the kernel, the bracket is the stage",
         "model_update_ms": fit_ms.get("model_update_ms", fit_ms),
         "cholesky": ({"N": N_OBS, "gflops": fit_ms["cholesky_alone_tflops"] * 1e3,
                       "sample": "median of 7 full refits with the executor's inverse queues off (factorisation alone)",
@@ -408,11 +412,12 @@ def main_single_process(args):
         for name, ms in model.timing(4096):
             stage_sum[name] = stage_sum.get(name, 0.0) + ms
         clock_mhz = model.info(_lib.INFO_KERNEL_CLOCK_MHZ)   # core clock under k_trigemm_sq over the timed region (sampled workgroups)
-        # UNTIMED: one more second of the same step, so that a coarse GPU-activity sampler around this process sees the device busy
-        # (the timed region is ~20 ms of a run whose remainder is the CPU baseline)
+        # UNTIMED: eleven more seconds of the same step, so that a coarse GPU-activity sampler around this process (one sample every 5 s)
+        # sees the device busy at least twice (the timed region is ~20 ms of a run whose remainder is the CPU baseline; one second was
+        # not enough: `gpu_busy` read 0 in three rounds running)
         model.enable_timing(0)
         t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < 1.0:
+        while time.perf_counter() - t_spin < float(os.environ.get("BOHIP_BENCH_SPIN_S", "11")):
             step()
         n_launch = C.c_int64(0)
         _lib.check(lib.bohip_gp_info(model._h, _lib.INFO_SCORE_LAUNCHES, C.byref(n_launch)))
@@ -421,8 +426,10 @@ def main_single_process(args):
                                       "call), 16-byte record out; `value` is the HBM-resident rate",
                  "host_buffers_same_winner": bool(hv == val and hi == idx)}
         extra["default_usage"] = default_usage(model, tau)
+        extra["mll_grad_ms"] = {"N=3000": mll_grad_ms(model)}      # value + gradient of the marginal likelihood (optimizemodel!)
         if not args.no_c4:
             extra["cholesky_c4"] = cholesky_c4(bohip)
+            extra["mll_grad_ms"]["N=10000"] = extra["cholesky_c4"].pop("_mll_grad_ms")
         report(args, 1, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, "one handle", extra)
         return
     # ---- N > 1 in one process: bohip_mgp_* -------------------------------------------------------------------
@@ -528,6 +535,18 @@ def default_usage_small():
             "us_per_evaluation": t / max(ev, 1) * 1e6}
 
 
+def mll_grad_ms(model, reps=5):
+    """bohip_gp_mll_grad (row N2: what every evaluation of the reference's optimizemodel! costs, src/models/gp.jl:42-77): refit +
+    cK^-1 = W'W + one pass over K and dK; median of `reps` host calls."""
+    model.mll_grad()
+    runs = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        model.mll_grad()
+        runs.append(time.perf_counter() - t0)
+    return float(np.median(runs)) * 1e3
+
+
 def cholesky_c4(bohip):
     """BASELINE configs[3]: N=10000 obs, d=16, SEArd -- the blocked-Cholesky path at the size BASELINE.json names, beside the
     headline workload: kernel-matrix assembly (HBM-write bound), factorisation (MFMA bound), triangular inverse."""
@@ -539,13 +558,15 @@ def cholesky_c4(bohip):
     m.enable_timing(True)
     m.append_(X.T, y)
     fig = refit_figures(m, N, reps=5)
+    m.enable_timing(False)
+    mg = mll_grad_ms(m, reps=3)
     m.close()
     ms = fig["model_update_ms"]
     ch = fig["cholesky_alone_ms"]
     bc = ms.get("build_cov", float("nan"))
     return {"N": N, "d": d, **fig, "cholesky_tflops": (N ** 3 / 3.0) / (ch * 1e-3) / 1e12,
             "cholesky_frac_of_fp64_peak": (N ** 3 / 3.0) / (ch * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-            "build_cov_gb_per_s": 8.0 * N * (N + 1) / 2 / (bc * 1e-3) / 1e9, "sample": "median of 5 full refits, each way"}
+            "build_cov_gb_per_s": 8.0 * N * (N + 1) / 2 / (bc * 1e-3) / 1e9, "sample": "median of 5 full refits, each way", "_mll_grad_ms": mg}
 
 
 def main():

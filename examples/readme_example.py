@@ -10,6 +10,9 @@ f = lambda x: float(np.sum((x - 1) ** 2) + np.random.randn())            # noisy
 model = bo.ElasticGPE(2,                                                   # 2 input dimensions
                       mean=bo.MeanConst(0.0), kernel=bo.SEArd([0.0, 0.0], 5.0), logNoise=0.0,
                       capacity=3000)                                       # the initial capacity of the GP is 3000 samples
+# NOT PORTED: README.md:27 `set_priors!(model.mean, [Normal(1, 2)])` -- a prior on the mean-function parameter for the MAP fit of
+# optimizemodel!.  Priors on hyper-parameters live in GaussianProcesses.jl / Distributions.jl on the host and are out of this build's
+# scope: the MAP fit below maximises the marginal likelihood alone, within the bounds.
 modeloptimizer = bo.MAPGPOptimizer(every=50, noisebounds=[-4, 3],          # bounds of the logNoise
                                    kernbounds=[[-1, -1, 0], [4, 4, 10]],   # bounds of the 3 parameters GaussianProcesses.get_param_names(model.kernel)
                                    maxeval=40)

@@ -100,6 +100,7 @@ def test_batch_equals_single_bitexact_on_device(bohip, acq, params):
 
 
 # ---- seeded synthetic cases against the oracle, every acquisition ------------------------------------
+_ARGMAX_EXEMPT = []   # (N, d, acquisition) cases of test_seeded_vs_oracle that took the near-tie exemption: printed, and bounded below
 @pytest.mark.parametrize("N,d,R,lsig,lnoise,beta", [
     (1, 1, 5, 0.0, -2.0, 0.0), (7, 2, 3, 0.5, -1.0, 0.3), (127, 3, 129, 0.0, -2.0, 0.0), (128, 4, 128, 0.0, -2.0, -1.0),
     (129, 5, 257, 0.3, -1.5, 0.0), (500, 2, 1000, 5.0, 0.0, 0.0), (1000, 8, 1500, 0.0, -2.0, 0.0), (700, 16, 300, 0.0, -2.0, 0.2)])
@@ -127,7 +128,17 @@ def test_seeded_vs_oracle(bohip, orc, N, d, R, lsig, lnoise, beta):
         top2 = np.sort(sc_o)[-2:] if R > 1 else np.array([-np.inf, sc_o[0]])
         if top2[1] - top2[0] > 4 * np.max(floor):
             assert bi == bi_o, (acq, bi, bi_o)
+        else:
+            _ARGMAX_EXEMPT.append((N, d, acq))
         assert sc[bi] == bv
+    print(f"test_seeded_vs_oracle: arg-max exemptions so far (oracle's top two closer than the floor): {len(_ARGMAX_EXEMPT)} {_ARGMAX_EXEMPT}")
+
+
+def test_seeded_vs_oracle_argmax_exemptions_are_rare():
+    """Of the 40 (shape, acquisition) cases above, how many skipped the exact arg-max assertion because the ORACLE's own top two scores were
+    closer than the documented floor?  Reported (run with -s) and bounded: the exemption must stay the exception."""
+    print(f"arg-max exemptions: {len(_ARGMAX_EXEMPT)} of 40: {_ARGMAX_EXEMPT}")
+    assert len(_ARGMAX_EXEMPT) <= 4, _ARGMAX_EXEMPT
 
 
 def test_mat52ard_and_seiso_kernels(bohip, orc):
