@@ -40,6 +40,12 @@ struct SmallCommon {
     const double* Xs;       // [P][d] candidates
     const double* alpha;
     const unsigned* go;     // not null: return at once when the word is 0 (free-running ascent)
+    // fused form (k_small_vu: V tiles and U tiles in ONE launch): [pass][T][2] words -- [0] = epoch when V' of the column block is out (and
+    // K*' of its diagonal chunk, and its mu record), [1] = epoch when its q record is out too; null in the two-launch form
+    unsigned* vflag;
+    unsigned epoch;
+    unsigned* err;          // receives the epoch of a launch in which a wait ran into its time-out (that call then returns NaN: loud, never a hang)
+    unsigned long long spin_ticks;
 #ifdef BOHIP_SMALL_TRACE
     unsigned long long* trace;   // [2][workgroup][16] wall-clock marks (tools/small_pass_trace.py; measurement build only)
 #endif
@@ -108,7 +114,7 @@ static int small_ntiles(int T, int m) {
 // chunk's products so that they land behind them:  pre(kc) -> registers,  fill(kc, registers, tile) -> LDS.  Two LDS tiles: the fill of
 // chunk kc + 1 writes the tile that chunk kc - 1 used, and every wave has left chunk kc - 1 when it passes chunk kc's barrier.
 // On return rt2 + ((kc1 - 1 - kc0) & 1) * 2048 holds the tile of chunk kc1 - 1.
-template <int UPPER, int G, class SetupL, class SetupS, class Pre, class Fill>
+template <int UPPER, int G, bool PRE_FIRST, class SetupL, class SetupS, class Pre, class Fill>
 __device__ __forceinline__ void small_contract(const SmallCommon& sc, double* rt2, int cb, int kc0, int kc1, SetupL&& setup_load, SetupS&& setup_store, Pre&& pre, Fill&& fill,
                                                double (&acc)[2][4]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,13 +125,16 @@ __device__ __forceinline__ void small_contract(const SmallCommon& sc, double* rt
     const double* ap = sc.A + (int64_t)(kc0 * 128 + 64 * kh + q) * ld + c0 + 2 * p;
     // (loads return in order: what is needed first is requested first -- the first right-hand-side tile's inputs, the candidates, then the
     // sixteen loads of the matrix; the tile is then built while the matrix is on its way)
-    auto regs = pre(kc0);
+    // (PRE_FIRST = false -- the U pass: its right-hand sides may have to be WAITED for in the fused form, the matrix must be on its way by then)
+    decltype(pre(kc0)) regs;
+    if (PRE_FIRST) regs = pre(kc0);
     auto sregs = setup_load();
     d2 w[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) w[s] = *(const d2*)(ap + (int64_t)(4 * s) * ld);
     SM_MARK(sc, UPPER, 1);
     setup_store(sregs);
+    if (!PRE_FIRST) regs = pre(kc0);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -166,7 +175,7 @@ __device__ __forceinline__ void small_contract(const SmallCommon& sc, double* rt
 // loads are plain compiler-tracked 8-byte agent-scope loads, so code between their issue and their use is safe (running it in EVERY
 // workgroup under the stores' acknowledgement was measured: 2.5 us on the critical path of every tile instead of one).
 template <int UPPER, class Meanwhile>
-__device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int pass, double* red, int* flag, int cb, int t0, int nseg,
+__device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int pass, int tile, double* red, int* flag, int cb, int t0, int nseg,
                                                       const double (&acc)[2][4], d2 (&sum)[2], Meanwhile&& meanwhile) {
     SM_MARK(sc, UPPER, 3);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,7 +189,7 @@ __device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int
     __syncthreads();
     if (kh == 0) {
         const double* src = red + (wc * 64 + lane) * 8;
-        double* pt = sc.part + ((int64_t)pass * sc.ntiles + blockIdx.x) * 2048;
+        double* pt = sc.part + ((int64_t)pass * sc.ntiles + tile) * 2048;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const d2 r01 = *(const d2*)(src + 4 * e), r23 = *(const d2*)(src + 4 * e + 2);
@@ -214,6 +223,17 @@ __device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int
     }
     SM_MARK(sc, UPPER, 6);
     return true;
+}
+
+// Fused form: wait until a flag word carries this launch's epoch (every wave polls for itself; bounded by wall clock; a time-out marks the
+// call as failed).  The waiting workgroup's block index is HIGHER than that of every workgroup it waits for: those were dispatched before it
+// and never wait themselves, so they are running or done -- no dead-lock whatever the residency.
+__device__ __forceinline__ void small_wait_flag(const SmallCommon& sc, const unsigned* f) {
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sc.epoch) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > sc.spin_ticks) { __hip_atomic_store(sc.err, sc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
 }
 
 // The posterior finish of one pass of 16 candidates (k_small_finish's formulas): q = sum of the column blocks' records in block order,
@@ -275,20 +295,40 @@ __device__ __forceinline__ void small_posterior_final(const SmallV& sv, int pass
 // ---- V pass ---------------------------------------------------------------------------------------------------------------------------
 template <int DT>
 struct SmallXRow { double x[DT]; };
+// LDS of one workgroup of these kernels (the fused kernel runs either body in the same block)
+template <int DT>
+struct SmallLds {
+    double* lbuf;      // [3][2048]: two right-hand-side tiles + the hand-over of the contraction halves; the finishers' scratch afterwards
+    double* xs_l;      // [16][DT] candidates of the pass
+    double* xc_l;      // [128][DT] the column block's observations (U pass)
+    double* al_l;      // [128] their alpha (U pass)
+    double* small;     // [256] mu partial sums (V pass) / [32] posterior of the pass (U pass)
+    Best* shb;         // [SP_THREADS / 64]
+    int* flag;
+};
+#define SMALL_LDS_DECL(DT_, L_)                                                          \
+    __shared__ __attribute__((aligned(16))) double sl_lbuf_[3 * 2048];                    \
+    __shared__ double sl_xs_[16 * DT_];                                                   \
+    __shared__ double sl_xc_[128 * DT_];                                                  \
+    __shared__ double sl_al_[128];                                                        \
+    __shared__ double sl_small_[256];                                                     \
+    __shared__ Best sl_shb_[SP_THREADS / 64];                                             \
+    __shared__ int sl_flag_;                                                              \
+    SmallLds<DT_> L_{sl_lbuf_, sl_xs_, sl_xc_, sl_al_, sl_small_, sl_shb_, &sl_flag_}
+
 template <int DT, int G>
-__global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV sv, KernelHyper hp) {
-    if (sc.go && *sc.go == 0u) return;
-    __shared__ __attribute__((aligned(16))) double lbuf[3 * 2048];
+__device__ __forceinline__ void small_v_body(const SmallCommon& sc, const SmallV& sv, const KernelHyper& hp, int tile, const SmallLds<DT>& L) {
+    double* const lbuf = L.lbuf;
     double* const rt2 = lbuf;             // 2 x [128][16] right-hand-side tiles
     double* const red = lbuf + 4096;      // [4][64][8] hand-over of the contraction halves, later the finishers' scratch
-    __shared__ double xs_l[16 * DT];
-    __shared__ double mured[16 * 16];
-    __shared__ Best shb[SP_THREADS / 64];
-    __shared__ int flag;
+    double* const xs_l = L.xs_l;
+    double* const mured = L.small;
+    Best* const shb = L.shb;
+    int& flag = *L.flag;
     const int tid = threadIdx.x, pass = blockIdx.y, d = hp.d, N = sc.N, T = sc.T;
     SM_MARK(sc, 0, 0);
     int cb, kc0, kc1, t0, nseg;
-    small_tile<0>(blockIdx.x, T, sc.m, cb, kc0, kc1, t0, nseg);
+    small_tile<0>(tile, T, sc.m, cb, kc0, kc1, t0, nseg);
     // the pass's candidates (row = r): 16 DT <= 1024 values, two per thread
     auto setup_load = [&]() {
         d2 v = {0.0, 0.0};
@@ -332,15 +372,16 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV s
     };
     d2 sum[2];
     double acc[2][4];
-    small_contract<0, G>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
+    small_contract<0, G, true>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
     // mu - beta = alpha' k*: the tile that holds the DIAGONAL chunk of its column block (the last chunk of the block's last segment) adds that
     // chunk's share in a fixed order from the K*' tile still in LDS, and publishes the record BEFORE it counts itself in
     if (kc1 - 1 == cb) {
         const double* rt = rt2 + ((kc1 - 1 - kc0) & 1) * 2048;
-        if (!sv.finish) {     // (gradient call) K*' of the chunk for the U pass's finisher; plain stores, the next KERNEL reads them
+        if (!sv.finish) {     // (gradient call) K*' of the chunk for the U pass's finisher
             double* kd = sv.ks16 + ((int64_t)pass * T * 128 + cb * 128) * 16 + 4 * tid;
-            *(d2*)kd = *(const d2*)(rt + 4 * tid);
-            *(d2*)(kd + 2) = *(const d2*)(rt + 4 * tid + 2);
+            const d2 k0 = *(const d2*)(rt + 4 * tid), k1 = *(const d2*)(rt + 4 * tid + 2);
+            if (sc.vflag) { st_agent2(kd, k0.x, k0.y); st_agent2(kd + 2, k1.x, k1.y); }    // (fused form: read inside this launch; acknowledged before the tile counts itself in)
+            else { *(d2*)kd = k0; *(d2*)(kd + 2) = k1; }
         }
         if (tid < 256) {
             const int slot = tid & 15, pt = tid >> 4;
@@ -360,12 +401,20 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV s
             st_agent(sv.mupart + ((int64_t)pass * T + cb) * 16 + tid, s);
         }
     }
-    if (!small_publish_combine<0>(sc, pass, red, &flag, cb, t0, nseg, acc, sum, [] {})) return;
+    if (!small_publish_combine<0>(sc, pass, tile, red, &flag, cb, t0, nseg, acc, sum, [] {})) return;
     // ---- the column block's finisher: V' of its 128 columns, q record
     const int sp = tid & 7, cl0 = tid >> 3;                 // pieces (cl0, sp) and (cl0 + 64, sp)
     double* vrow = sv.v16 + ((int64_t)pass * T * 128 + cb * 128) * 16;
-    *(d2*)(vrow + (cl0) * 16 + 2 * sp) = sum[0];
-    *(d2*)(vrow + (cl0 + 64) * 16 + 2 * sp) = sum[1];
+    if (sc.vflag) {       // fused form: the U tiles of THIS launch read it -- write-through stores, then the block's first flag
+        st_agent2(vrow + (cl0) * 16 + 2 * sp, sum[0].x, sum[0].y);
+        st_agent2(vrow + (cl0 + 64) * 16 + 2 * sp, sum[1].x, sum[1].y);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sc.vflag + ((int64_t)pass * T + cb) * 2, sc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *(d2*)(vrow + (cl0) * 16 + 2 * sp) = sum[0];
+        *(d2*)(vrow + (cl0 + 64) * 16 + 2 * sp) = sum[1];
+    }
     d2 qq = {0.0, 0.0};
     if (cb * 128 + cl0 < N) { qq.x += sum[0].x * sum[0].x; qq.y += sum[0].y * sum[0].y; }
     if (cb * 128 + cl0 + 64 < N) { qq.x += sum[1].x * sum[1].x; qq.y += sum[1].y * sum[1].y; }
@@ -378,7 +427,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV s
         st_agent(sv.qpart + ((int64_t)pass * T + cb) * 16 + tid, s);
     }
     SM_MARK(sc, 0, 7);
-    if (!sv.finish) return;                 // (gradient call: k_small_u's last workgroup finishes the posterior)
+    if (sc.vflag) {       // fused form: the q record is out -> the block's second flag (the U pass's last workgroup waits for all of them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sc.vflag + ((int64_t)pass * T + cb) * 2 + 1, sc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!sv.finish) return;                 // (gradient call: the U pass's last workgroup finishes the posterior)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) flag = atomicAdd(&sc.cnt[gridDim.y * T + pass], 1u) == (unsigned)(T - 1);
@@ -409,6 +463,12 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV s
     SM_MARK(sc, 0, 10);
     if (tid == 0) { sv.best_out->val = idx >= 0 ? f_best : -INFINITY; sv.best_out->idx = idx >= 0 ? idx + sv.idx_off : -1; }
 }
+template <int DT, int G>
+__global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV sv, KernelHyper hp) {
+    if (sc.go && *sc.go == 0u) return;
+    SMALL_LDS_DECL(DT, L);
+    small_v_body<DT, G>(sc, sv, hp, blockIdx.x, L);
+}
 
 // ---- U pass ---------------------------------------------------------------------------------------------------------------------------
 // U' = V' W (A = W, contraction k >= c), then the gradient (k_grad_finish's formulas: reference src/acquisition.jl:11-17 wrap_gradient's
@@ -417,21 +477,19 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV s
 // into a record; the finisher of the last block adds the records in block order and applies the chain rule.
 struct SmallVPair { d2 a, b; };
 template <int DT, int G>
-__global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU su, KernelHyper hp) {
-    if (sc.go && *sc.go == 0u) return;
-    __shared__ __attribute__((aligned(16))) double lbuf[3 * 2048];
+__device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU& su, const KernelHyper& hp, int tile, const SmallLds<DT>& L) {
+    double* const lbuf = L.lbuf;
     double* const rt2 = lbuf;
     double* const red = lbuf + 4096;
-    __shared__ double xs_l[16 * DT];
-    __shared__ double xc_l[128 * DT];     // the column block's 128 observations and their alpha: fetched at the START of the kernel by every
-    __shared__ double al_l[128];          // tile (8 KB at d = 8), so that the block's finisher finds them in LDS instead of behind four round trips
-    __shared__ __attribute__((aligned(16))) double ks_l[128 * 16];   // K*' of the block's observations (from k_small_v)
-    __shared__ double post_l[32];
-    __shared__ int flag;
+    double* const xs_l = L.xs_l;
+    double* const xc_l = L.xc_l;          // the column block's 128 observations and their alpha: fetched at the START of the kernel by every
+    double* const al_l = L.al_l;          // tile (8 KB at d = 8), so that the block's finisher finds them in LDS instead of behind four round trips
+    double* const post_l = L.small;
+    int& flag = *L.flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pass = blockIdx.y, d = hp.d, N = sc.N, T = sc.T;
     SM_MARK(sc, 1, 0);
     int cb, kc0, kc1, t0, nseg;
-    small_tile<1>(blockIdx.x, T, sc.m, cb, kc0, kc1, t0, nseg);
+    small_tile<1>(tile, T, sc.m, cb, kc0, kc1, t0, nseg);
     const double* vsrc = su.v16 + (int64_t)pass * T * 128 * 16;
     auto setup_load = [&]() { return 0; };
     auto setup_store = [&](int) {
@@ -444,14 +502,14 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU s
         const int64_t e0 = (int64_t)cb * 128 * d, e1 = min((int64_t)N * d, e0 + 128 * d);
         for (int t = tid; t < 128 * d; t += SP_THREADS) xc_l[t] = e0 + t < e1 ? sc.X[e0 + t] : 0.0;
         if (tid < 128) al_l[tid] = cb * 128 + tid < N ? sc.alpha[cb * 128 + tid] : 0.0;
-        const double* ksrc = su.sv.ks16 + ((int64_t)pass * T * 128 + cb * 128) * 16 + 4 * tid;
-        *(d2*)(ks_l + 4 * tid) = *(const d2*)ksrc;
-        *(d2*)(ks_l + 4 * tid + 2) = *(const d2*)(ksrc + 2);
     };
-    auto pre = [&](int kc) {                    // V' of the chunk (slot layout, written by k_small_v), rows beyond N as zeros
+    auto pre = [&](int kc) {                    // V' of the chunk (slot layout, written by the V pass), rows beyond N as zeros
         SmallVPair v{{0.0, 0.0}, {0.0, 0.0}};
-        if (kc * 128 + (tid >> 2) < N) {
-            const double* src = vsrc + (int64_t)kc * 2048 + 4 * tid;
+        const double* src = vsrc + (int64_t)kc * 2048 + 4 * tid;
+        if (sc.vflag) {     // fused form: the block's V' is written INSIDE this launch: wait for its flag, then agent-scope loads
+            small_wait_flag(sc, sc.vflag + ((int64_t)pass * T + kc) * 2);
+            if (kc * 128 + (tid >> 2) < N) { v.a.x = ld_agent(src); v.a.y = ld_agent(src + 1); v.b.x = ld_agent(src + 2); v.b.y = ld_agent(src + 3); }
+        } else if (kc * 128 + (tid >> 2) < N) {
             v.a = *(const d2*)src;
             v.b = *(const d2*)(src + 2);
         }
@@ -463,13 +521,20 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU s
     };
     d2 sum[2];
     double acc[2][4];
-    small_contract<1, G>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
+    small_contract<1, G, false>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
     // the block's finisher, while the partial tiles are on their way: everything of the gradient sums that does not need u -- the
     // kernel factor of each of its four observations and the alpha-weighted sums
     const int slot = tid & 15, cg = tid >> 4, r = small_slot_to_r(slot);
     const bool active = pass * 16 + r < sc.P;
     double gm[DT], gv[DT], fac[4];
     auto meanwhile = [&]() {
+        // K*' of the thread's four observations (the V pass's own values: for the SE kernels d k*_j / d x = -k*_j (x - X_j) / l^2, no second
+        // exponential here).  The column block's first segment contracted chunk cb, i.e. it waited for / ran behind the V pass's block cb:
+        // the record is complete.  Requested first, used last.
+        double ksv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ksv[i] = ld_agent(su.sv.ks16 + ((int64_t)pass * T * 128 + cb * 128 + cg * 4 + i) * 16 + slot);
 #pragma unroll
         for (int k = 0; k < DT; ++k) { gm[k] = 0.0; gv[k] = 0.0; }
 #pragma unroll
@@ -488,7 +553,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU s
                     const double s = sqrt(5.0) * sqrt(rr);
                     fac[i] = -(5.0 / 3.0) * hp.sigma2 * (1.0 + s) * exp(-s);
                 } else {
-                    fac[i] = -ks_l[cl * 16 + slot];      // = -(sigma2 exp(-rr / 2)): k_small_v's own value of it, same expression on the same rr
+                    fac[i] = -ksv[i];                    // = -(sigma2 exp(-rr / 2)): the V pass's own value of it, same expression on the same rr
                 }
                 const double a = al_l[cl];
 #pragma unroll
@@ -497,7 +562,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU s
             }
         }
     };
-    if (!small_publish_combine<1>(sc, pass, red, &flag, cb, t0, nseg, acc, sum, meanwhile)) return;
+    if (!small_publish_combine<1>(sc, pass, tile, red, &flag, cb, t0, nseg, acc, sum, meanwhile)) return;
     // ---- the column block's finisher: u of its 128 observations -> LDS, then the u-weighted gradient sums of those observations
     double* const ul = lbuf;                   // (the right-hand-side tiles are done with)
     {
@@ -556,6 +621,10 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU s
     // same bits) and the gradient records in block order, both fetched in ONE round trip; then the chain rule through the reference's
     // acquisition formulas.  (slot, dimension) pairs; the block records of a pair are fetched by `nparts` threads at once and the parts added
     // in part order: the order depends on (T, d) only
+    if (sc.vflag) {     // fused form: every column block's q record of the V pass must be out (normally long since)
+        for (int b = tid; b < T; b += SP_THREADS) small_wait_flag(sc, sc.vflag + ((int64_t)pass * T + b) * 2 + 1);
+        __syncthreads();
+    }
     const double* gp = su.gpart + ((int64_t)pass * T * 16) * (2 * DT);
     const int npairs = 16 * d, nparts = max(1, min(8, SP_THREADS / npairs)), bpp = (T + nparts - 1) / nparts;
     double* gfin = lbuf;                                 // [nparts][npairs][2]  (<= 8 * 64 * 2 or 2 * 256 * 2 doubles) -- behind small_posterior_final's use of lbuf
@@ -623,7 +692,32 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU s
         // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
         su.grad[(int64_t)rr * d + k] = dmu * a + (v > 0.0 ? ds2 * (-2.0 * b) : 0.0);
     }
+    if (sc.vflag && __hip_atomic_load(sc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sc.epoch) {
+        // a wait of this launch timed out: whatever was computed behind it is garbage -- the call returns NaN (loud), not numbers
+        __syncthreads();
+        for (int e = tid; e < 16 * d; e += SP_THREADS) {
+            const int rr = pass * 16 + small_slot_to_r(e / d);
+            if (rr < sc.P) { su.grad[(int64_t)rr * d + e % d] = NAN; if (e % d == 0 && su.sv.score_out) su.sv.score_out[rr] = NAN; }
+        }
+    }
     SM_MARK(sc, 1, 11);
+}
+template <int DT, int G>
+__global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU su, KernelHyper hp) {
+    if (sc.go && *sc.go == 0u) return;
+    SMALL_LDS_DECL(DT, L);
+    small_u_body<DT, G>(sc, su, hp, blockIdx.x, L);
+}
+// The fused form: the V tiles (blocks [0, ntiles)) and the U tiles (blocks [ntiles, 2 ntiles)) of a pass in ONE launch.  A U tile requests
+// its part of W at once, then waits for the V' blocks it contracts (flags) -- its stream and its prologue run under the V pass's tail, and
+// one launch boundary is gone.  Blocks are dispatched in index order: whatever a U tile waits for was dispatched before it and waits for
+// nothing itself.
+template <int DT, int G>
+__global__ __launch_bounds__(SP_THREADS) void k_small_vu(SmallCommon scv, SmallCommon scu, SmallV sv, SmallU su, KernelHyper hp) {
+    if (scv.go && *scv.go == 0u) return;
+    SMALL_LDS_DECL(DT, L);
+    if ((int)blockIdx.x < scv.ntiles) small_v_body<DT, G>(scv, sv, hp, blockIdx.x, L);
+    else small_u_body<DT, G>(scu, su, hp, (int)blockIdx.x - scv.ntiles, L);
 }
 
 }  // namespace bohip
