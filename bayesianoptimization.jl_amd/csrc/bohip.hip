@@ -128,7 +128,6 @@ struct bohip_gp {
     size_t sm_bytes = 0;
     unsigned* dsm_cnt = nullptr;
     int sm_cnt_T = 0;
-    unsigned sm_epoch = 0;       // launches of the fused form so far (the value its flags carry)
     // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
     // 2-3 device-to-host copies of a call cost more than its kernels (each ~8 us of API + DMA set-up)
     double* hpin = nullptr;      // [score 32 | mu 32 | var 32 | best 2 | grad 32 DMAX]
@@ -297,7 +296,6 @@ static int g_asc_wg_nmax = 256;  // BOHIP_ASC_WG_NMAX: models up to this many ob
 static int g_asc_lockstep = 0;   // BOHIP_ASC_LOCKSTEP=1: the lock-step driver of the device ascent (five launches + a stream synchronisation per
                                  // evaluation pass) instead of the free-running one (k_asc_step)
 static int g_small_mfma = 1;   // BOHIP_SMALL_MFMA: the small-batch pass as two MFMA kernels (kernels_small.hip); 0 = round 4's five kernels
-static int g_small_fuse = 1;   // BOHIP_SMALL_FUSE: V and U tiles of a value + gradient pass in ONE launch (k_small_vu); 0 = two launches
 static int g_small_m = 0;      // BOHIP_SMALL_M: 128-chunks of the contraction index per tile of those kernels; 0 = by size
 static int g_small_r = -1;  // batches up to this size (<= 256) take the row-wise path; -1: min(256, 90 + 300000 / N), the measured
                             // break-even with the MFMA path (N=500: > 256, N=3000: ~190, N=10000: ~110); BOHIP_SMALL_R overrides: below that
@@ -414,7 +412,6 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_MAX, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SMALL_MFMA")) g_small_mfma = atoi(e);
     if (const char* e = getenv("BOHIP_SMALL_M")) g_small_m = std::max(0, atoi(e));
-    if (const char* e = getenv("BOHIP_SMALL_FUSE")) g_small_fuse = atoi(e);
     done = true;
     return 0;
 }
@@ -1923,10 +1920,6 @@ extern "C" int bohip_debug_small_trace_read(unsigned long long* out) {   // meas
 template <int DT, int G>
 static void launch_small_pass(bohip_gp* g, const SmallCommon& sc, const SmallCommon& scu, const SmallV& sv, const SmallU* su, const KernelHyper& hp,
                               int npass) {
-    if (su && sc.vflag) {
-        hipLaunchKernelGGL((k_small_vu<DT, G>), dim3((unsigned)(2 * sc.ntiles), (unsigned)npass), dim3(SP_THREADS), 0, g->stream, sc, scu, sv, *su, hp);
-        return;
-    }
     hipLaunchKernelGGL((k_small_v<DT, G>), dim3((unsigned)sc.ntiles, (unsigned)npass), dim3(SP_THREADS), 0, g->stream, sc, sv, hp);
     if (su) hipLaunchKernelGGL((k_small_u<DT, G>), dim3((unsigned)sc.ntiles, (unsigned)npass), dim3(SP_THREADS), 0, g->stream, scu, *su, hp);
 }
@@ -1951,8 +1944,8 @@ static int small_pass_mfma(bohip_gp* g, const double* dXs, int64_t R, const AcqP
     if (m <= 0) { const int cus = std::max(device_cus(), 1); for (m = 1; m < T && small_ntiles(T, m) > cus; ++m) {} }
     const int ntiles = small_ntiles(T, m);
     const size_t n_part = (size_t)npass * ntiles * 2048, n_v16 = (size_t)npass * T * 128 * 16, n_rec = (size_t)npass * T * 16,
-                 n_g = (size_t)npass * T * 16 * 2 * DTm;
-    const size_t need = (2 * n_part + 2 * n_v16 + 2 * n_rec + (size_t)npass * 32 + SMALL_MAX + n_g) * 8;
+                 n_g = (size_t)npass * ntiles * 16 * DTm, n_gm = (size_t)npass * T * 16 * DTm;
+    const size_t need = (n_part + 2 * n_v16 + 2 * n_rec + (size_t)npass * 32 + SMALL_MAX + n_g + n_gm) * 8;
     if (need > g->sm_bytes) {
         if (g->dsm) { HIPCHK(hipStreamSynchronize(g->stream)); HIPCHK(hipFree(g->dsm)); g->dsm = nullptr; g->sm_bytes = 0; }
         HIPCHK(hipMalloc(&g->dsm, need + need / 4));
@@ -1961,8 +1954,8 @@ static int small_pass_mfma(bohip_gp* g, const double* dXs, int64_t R, const AcqP
     if (!g->dsm_cnt || T > g->sm_cnt_T) {
         if (g->dsm_cnt) { HIPCHK(hipStreamSynchronize(g->stream)); HIPCHK(hipFree(g->dsm_cnt)); g->dsm_cnt = nullptr; }
         const int Tc = T + 16;
-        // [V counters | U counters | flags (2 per pass and block) | error word]
-        const size_t words = 2 * ((size_t)(SMALL_MAX / 16) * (Tc + 1) + 1) + 2 * (size_t)(SMALL_MAX / 16) * Tc + 1;
+        // [V counters | U counters]
+        const size_t words = 2 * ((size_t)(SMALL_MAX / 16) * (Tc + 1) + 1);
         HIPCHK(hipMalloc(&g->dsm_cnt, words * sizeof(unsigned)));
         HIPCHK(hipMemsetAsync(g->dsm_cnt, 0, words * sizeof(unsigned), g->stream));
         g->sm_cnt_T = Tc;
@@ -1971,34 +1964,24 @@ static int small_pass_mfma(bohip_gp* g, const double* dXs, int64_t R, const AcqP
     SmallCommon sc{};
     sc.A = g->dWT; sc.ld = g->ld; sc.N = N; sc.T = T; sc.m = m; sc.P = P; sc.part = g->dsm; sc.ntiles = ntiles; sc.cnt = g->dsm_cnt;
     sc.X = g->dX; sc.Xs = dXs; sc.alpha = g->dalpha; sc.go = (const unsigned*)g->asc_go;
-    const size_t cnt_block = (size_t)(SMALL_MAX / 16) * (g->sm_cnt_T + 1) + 1;
-    sc.vflag = nullptr; sc.epoch = 0; sc.err = g->dsm_cnt + 2 * cnt_block + 2 * (size_t)(SMALL_MAX / 16) * g->sm_cnt_T;
-    sc.spin_ticks = g_chol_spin_ticks;
-    if (d_grad && g_small_fuse) {     // the fused form: flags carry the number of this launch
-        sc.vflag = g->dsm_cnt + 2 * cnt_block;
-        sc.epoch = ++g->sm_epoch;
-        if (g->sm_epoch == 0x7fffffffu) {     // (the comparison is a signed difference: start over long before it wraps)
-            HIPCHK(hipMemsetAsync(sc.vflag, 0, 2 * (size_t)(SMALL_MAX / 16) * g->sm_cnt_T * sizeof(unsigned), g->stream));
-            g->sm_epoch = 0; sc.epoch = ++g->sm_epoch;
-        }
-    }
 #ifdef BOHIP_SMALL_TRACE
     if (!g_small_trace) { HIPCHK(hipMalloc(&g_small_trace, 8192 * 16 * 8)); }
     HIPCHK(hipMemsetAsync(g_small_trace, 0, 8192 * 16 * 8, g->stream));
     sc.trace = g_small_trace;
 #endif
+    const size_t cnt_block = (size_t)(SMALL_MAX / 16) * (g->sm_cnt_T + 1) + 1;
     SmallV sv{};
-    sv.v16 = g->dsm + 2 * n_part; sv.qpart = sv.v16 + n_v16; sv.mupart = sv.qpart + n_rec;
+    sv.v16 = g->dsm + n_part; sv.qpart = sv.v16 + n_v16; sv.mupart = sv.qpart + n_rec;
     sv.fstash = sv.mupart + n_rec + (size_t)npass * 32;
     sv.sigma2 = std::exp(2.0 * g->logsig); sv.beta = g->beta; sv.ap = ap;
     sv.mu_out = d_mu; sv.var_out = d_var; sv.score_out = d_score; sv.best_out = d_best; sv.idx_off = (long long)best_off;
     sv.finish = d_grad ? 0 : 1;
     SmallU su{};
     sv.ks16 = sv.fstash + SMALL_MAX;
-    su.v16 = sv.v16; su.sv = sv; su.gpart = sv.ks16 + n_v16; su.grad = d_grad;
+    su.v16 = sv.v16; su.sv = sv; su.gpart = sv.ks16 + n_v16; su.gmpart = su.gpart + n_g; su.grad = d_grad;
     const SmallU* sup = d_grad ? &su : nullptr;
     SmallCommon scu = sc;       // the U pass: W itself (contraction k >= c), its own partial planes and counters
-    scu.A = g->dW; scu.part = g->dsm + n_part; scu.cnt = g->dsm_cnt + cnt_block;
+    scu.A = g->dW; scu.cnt = g->dsm_cnt + cnt_block;
     const int G = (std::min(P, 16) + 3) / 4;
     t_begin(g, d_grad ? "small_V+U" : "small_V");
     switch (DTm) {

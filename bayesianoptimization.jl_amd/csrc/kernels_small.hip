@@ -40,12 +40,6 @@ struct SmallCommon {
     const double* Xs;       // [P][d] candidates
     const double* alpha;
     const unsigned* go;     // not null: return at once when the word is 0 (free-running ascent)
-    // fused form (k_small_vu: V tiles and U tiles in ONE launch): [pass][T][2] words -- [0] = epoch when V' of the column block is out (and
-    // K*' of its diagonal chunk, and its mu record), [1] = epoch when its q record is out too; null in the two-launch form
-    unsigned* vflag;
-    unsigned epoch;
-    unsigned* err;          // receives the epoch of a launch in which a wait ran into its time-out (that call then returns NaN: loud, never a hang)
-    unsigned long long spin_ticks;
 #ifdef BOHIP_SMALL_TRACE
     unsigned long long* trace;   // [2][workgroup][16] wall-clock marks (tools/small_pass_trace.py; measurement build only)
 #endif
@@ -73,11 +67,28 @@ struct SmallV {
 struct SmallU {
     const double* v16;
     SmallV sv;              // the posterior finish rides in this kernel's last workgroup (same device function as the value-only call: same bits)
-    double* gpart;          // [pass][T][16][2 DT]
+    double* gpart;          // [pass][ntiles][16][DT]  the tiles' u-weighted gradient sums
+    double* gmpart;         // [pass][T][16][DT]       the column blocks' alpha-weighted gradient sums
     double* grad;           // [P][d]
 };
 
 __device__ __forceinline__ int small_slot_to_r(int slot) { return 4 * (slot & 3) + (slot >> 2); }
+// sum over the 16 lanes of a DPP row by four rotate-and-add levels (row_ror 8, 4, 2, 1: VALU moves, no trip through the LDS crossbar);
+// every lane ends with the sum of its row in its own association -- callers use ONE fixed lane's
+template <int N>
+__device__ __forceinline__ double dpp_row_ror(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x120 + N, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_row_ror<8>(v);
+    v += dpp_row_ror<4>(v);
+    v += dpp_row_ror<2>(v);
+    v += dpp_row_ror<1>(v);
+    return v;
+}
 
 // which tile is workgroup b: column blocks heaviest first (lower: T-1 ... 0, upper: 0 ... T-1), a block's segments in contraction order
 template <int UPPER>
@@ -225,17 +236,6 @@ __device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int
     return true;
 }
 
-// Fused form: wait until a flag word carries this launch's epoch (every wave polls for itself; bounded by wall clock; a time-out marks the
-// call as failed).  The waiting workgroup's block index is HIGHER than that of every workgroup it waits for: those were dispatched before it
-// and never wait themselves, so they are running or done -- no dead-lock whatever the residency.
-__device__ __forceinline__ void small_wait_flag(const SmallCommon& sc, const unsigned* f) {
-    const unsigned long long t0 = wall_clock64();
-    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sc.epoch) < 0) {
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > sc.spin_ticks) { __hip_atomic_store(sc.err, sc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-    }
-}
-
 // The posterior finish of one pass of 16 candidates (k_small_finish's formulas): q = sum of the column blocks' records in block order,
 // mu - beta likewise, sigma^2 = max(s_f^2 - q, 0), the acquisition value.  The records are fetched by all threads at once (one round
 // trip), then added by one thread per slot from LDS.  buf: >= 4096 doubles of LDS.  Thread `slot` (< 16) returns (f, candidate index).
@@ -379,9 +379,8 @@ __device__ __forceinline__ void small_v_body(const SmallCommon& sc, const SmallV
         const double* rt = rt2 + ((kc1 - 1 - kc0) & 1) * 2048;
         if (!sv.finish) {     // (gradient call) K*' of the chunk for the U pass's finisher
             double* kd = sv.ks16 + ((int64_t)pass * T * 128 + cb * 128) * 16 + 4 * tid;
-            const d2 k0 = *(const d2*)(rt + 4 * tid), k1 = *(const d2*)(rt + 4 * tid + 2);
-            if (sc.vflag) { st_agent2(kd, k0.x, k0.y); st_agent2(kd + 2, k1.x, k1.y); }    // (fused form: read inside this launch; acknowledged before the tile counts itself in)
-            else { *(d2*)kd = k0; *(d2*)(kd + 2) = k1; }
+            *(d2*)kd = *(const d2*)(rt + 4 * tid);
+            *(d2*)(kd + 2) = *(const d2*)(rt + 4 * tid + 2);
         }
         if (tid < 256) {
             const int slot = tid & 15, pt = tid >> 4;
@@ -405,16 +404,8 @@ __device__ __forceinline__ void small_v_body(const SmallCommon& sc, const SmallV
     // ---- the column block's finisher: V' of its 128 columns, q record
     const int sp = tid & 7, cl0 = tid >> 3;                 // pieces (cl0, sp) and (cl0 + 64, sp)
     double* vrow = sv.v16 + ((int64_t)pass * T * 128 + cb * 128) * 16;
-    if (sc.vflag) {       // fused form: the U tiles of THIS launch read it -- write-through stores, then the block's first flag
-        st_agent2(vrow + (cl0) * 16 + 2 * sp, sum[0].x, sum[0].y);
-        st_agent2(vrow + (cl0 + 64) * 16 + 2 * sp, sum[1].x, sum[1].y);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(sc.vflag + ((int64_t)pass * T + cb) * 2, sc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        *(d2*)(vrow + (cl0) * 16 + 2 * sp) = sum[0];
-        *(d2*)(vrow + (cl0 + 64) * 16 + 2 * sp) = sum[1];
-    }
+    *(d2*)(vrow + (cl0) * 16 + 2 * sp) = sum[0];          // (plain stores: the next KERNEL reads them)
+    *(d2*)(vrow + (cl0 + 64) * 16 + 2 * sp) = sum[1];
     d2 qq = {0.0, 0.0};
     if (cb * 128 + cl0 < N) { qq.x += sum[0].x * sum[0].x; qq.y += sum[0].y * sum[0].y; }
     if (cb * 128 + cl0 + 64 < N) { qq.x += sum[1].x * sum[1].x; qq.y += sum[1].y * sum[1].y; }
@@ -427,11 +418,6 @@ __device__ __forceinline__ void small_v_body(const SmallCommon& sc, const SmallV
         st_agent(sv.qpart + ((int64_t)pass * T + cb) * 16 + tid, s);
     }
     SM_MARK(sc, 0, 7);
-    if (sc.vflag) {       // fused form: the q record is out -> the block's second flag (the U pass's last workgroup waits for all of them)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(sc.vflag + ((int64_t)pass * T + cb) * 2 + 1, sc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (!sv.finish) return;                 // (gradient call: the U pass's last workgroup finishes the posterior)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -471,30 +457,36 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV s
 }
 
 // ---- U pass ---------------------------------------------------------------------------------------------------------------------------
-// U' = V' W (A = W, contraction k >= c), then the gradient (k_grad_finish's formulas: reference src/acquisition.jl:11-17 wrap_gradient's
-// role, analytic): the finisher of column block cb holds u_j for its 128 observations j and all slots, adds
-//   gm[k] = sum_j dk*_j/dx_k alpha_j,  gv[k] = sum_j dk*_j/dx_k u_j      over its observations in a fixed order
-// into a record; the finisher of the last block adds the records in block order and applies the chain rule.
+// The gradient (k_grad_finish's formulas: reference src/acquisition.jl:11-17 wrap_gradient's role, analytic) needs u = W'(W k*) only inside
+//   gv[k] = sum_j (d k*_j / d x_k) u_j ,        u_j = sum_{i >= j} W[i][j] v_i
+// which is LINEAR in u: a tile's share of u (its 128 columns j, its segment of rows i) is contracted with d k*_j / d x_k inside the tile,
+// and what leaves the tile is one record of 16 slots x 2 d sums (gv, and -- from the tile of the block's first segment -- the alpha-weighted
+// gm[k] = sum_j (d k*_j / d x_k) alpha_j of those 128 observations).  No partial tiles of u, no column-block combine, ONE counter per pass:
+// the LAST tile adds the records in tile order and applies the chain rule.  (Until this form the U pass published 16-KiB partial tiles like
+// the V pass, a block's last arriver combined them and added the gradient sums of its 128 observations alone: 22 us of serial tail behind a
+// 10 us contraction, profiles/r05_small_pass_trace_*.txt.)  For the SE kernels d k*_j / d x_k = -k*_j (x_k - X_jk) / l_k^2 with k*_j taken
+// from the V pass's own K*' record (no second exponential).
 struct SmallVPair { d2 a, b; };
 template <int DT, int G>
 __device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU& su, const KernelHyper& hp, int tile, const SmallLds<DT>& L) {
     double* const lbuf = L.lbuf;
     double* const rt2 = lbuf;
-    double* const red = lbuf + 4096;
     double* const xs_l = L.xs_l;
-    double* const xc_l = L.xc_l;          // the column block's 128 observations and their alpha: fetched at the START of the kernel by every
-    double* const al_l = L.al_l;          // tile (8 KB at d = 8), so that the block's finisher finds them in LDS instead of behind four round trips
+    double* const xc_l = L.xc_l;          // the column block's 128 observations and their alpha (fetched behind the matrix loads)
+    double* const al_l = L.al_l;
     double* const post_l = L.small;
     int& flag = *L.flag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, pass = blockIdx.y, d = hp.d, N = sc.N, T = sc.T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), pass = blockIdx.y, d = hp.d, N = sc.N, T = sc.T;
+    const int kh = wave >> 2, wc = wave & 3, q = lane >> 4, p = lane & 15;
     SM_MARK(sc, 1, 0);
     int cb, kc0, kc1, t0, nseg;
     small_tile<1>(tile, T, sc.m, cb, kc0, kc1, t0, nseg);
     const double* vsrc = su.v16 + (int64_t)pass * T * 128 * 16;
+    d2 kv[2][2];                                 // K*' of this lane's two columns, slots 4 q ... 4 q + 3 (from the V pass)
     auto setup_load = [&]() { return 0; };
     auto setup_store = [&](int) {
-        // candidates, the block's observations and alpha: requested BEHIND the matrix loads (nothing waits for them before the tile is
-        // published), no barrier (read many barriers from here)
+        // candidates, the block's observations, alpha and K*': requested BEHIND the matrix loads (nothing needs them before the contraction is
+        // done); no barrier here (read behind the contraction's barriers)
         for (int t = tid; t < 16 * DT; t += SP_THREADS) {
             const int r = t / DT, k = t % DT, rr = pass * 16 + r;
             xs_l[t] = (rr < sc.P && k < d) ? sc.Xs[(int64_t)rr * d + k] : 0.0;
@@ -502,14 +494,17 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU
         const int64_t e0 = (int64_t)cb * 128 * d, e1 = min((int64_t)N * d, e0 + 128 * d);
         for (int t = tid; t < 128 * d; t += SP_THREADS) xc_l[t] = e0 + t < e1 ? sc.X[e0 + t] : 0.0;
         if (tid < 128) al_l[tid] = cb * 128 + tid < N ? sc.alpha[cb * 128 + tid] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const double* ks = su.sv.ks16 + ((int64_t)pass * T * 128 + cb * 128 + wc * 32 + 2 * p + e) * 16 + 4 * q;
+            kv[e][0] = *(const d2*)ks;
+            kv[e][1] = *(const d2*)(ks + 2);
+        }
     };
     auto pre = [&](int kc) {                    // V' of the chunk (slot layout, written by the V pass), rows beyond N as zeros
         SmallVPair v{{0.0, 0.0}, {0.0, 0.0}};
-        const double* src = vsrc + (int64_t)kc * 2048 + 4 * tid;
-        if (sc.vflag) {     // fused form: the block's V' is written INSIDE this launch: wait for its flag, then agent-scope loads
-            small_wait_flag(sc, sc.vflag + ((int64_t)pass * T + kc) * 2);
-            if (kc * 128 + (tid >> 2) < N) { v.a.x = ld_agent(src); v.a.y = ld_agent(src + 1); v.b.x = ld_agent(src + 2); v.b.y = ld_agent(src + 3); }
-        } else if (kc * 128 + (tid >> 2) < N) {
+        if (kc * 128 + (tid >> 2) < N) {
+            const double* src = vsrc + (int64_t)kc * 2048 + 4 * tid;
             v.a = *(const d2*)src;
             v.b = *(const d2*)(src + 2);
         }
@@ -519,186 +514,179 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU
         *(d2*)(rt_ + 4 * tid) = v.a;
         *(d2*)(rt_ + 4 * tid + 2) = v.b;
     };
-    d2 sum[2];
     double acc[2][4];
-    small_contract<1, G, false>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
-    // the block's finisher, while the partial tiles are on their way: everything of the gradient sums that does not need u -- the
-    // kernel factor of each of its four observations and the alpha-weighted sums
-    const int slot = tid & 15, cg = tid >> 4, r = small_slot_to_r(slot);
-    const bool active = pass * 16 + r < sc.P;
-    double gm[DT], gv[DT], fac[4];
-    auto meanwhile = [&]() {
-        // K*' of the thread's four observations (the V pass's own values: for the SE kernels d k*_j / d x = -k*_j (x - X_j) / l^2, no second
-        // exponential here).  The column block's first segment contracted chunk cb, i.e. it waited for / ran behind the V pass's block cb:
-        // the record is complete.  Requested first, used last.
-        double ksv[4];
+    small_contract<1, G, true>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
+    SM_MARK(sc, 1, 3);
+    // ---- the tile's share of the gradient sums: lane (q, p) of strip wc holds u's share for columns j_e = 128 cb + 32 wc + 2 p + e and the
+    // candidates r_g = 4 g + q; sum over e in the lane, over p by four DPP levels, over the eight waves in wave order through LDS
+    const bool first_seg = kc0 == cb && kh == 0;          // (the alpha-weighted sums of the block's observations: once per column block)
+    double fac[2][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            ksv[i] = ld_agent(su.sv.ks16 + ((int64_t)pass * T * 128 + cb * 128 + cg * 4 + i) * 16 + slot);
+    for (int e = 0; e < 2; ++e) {
+        const int cl = wc * 32 + 2 * p + e, j = cb * 128 + cl;
 #pragma unroll
-        for (int k = 0; k < DT; ++k) { gm[k] = 0.0; gv[k] = 0.0; }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int cl = cg * 4 + i, j = cb * 128 + cl;
-            fac[i] = 0.0;
-            if (j < N && active) {
-                double t[DT], rr = 0.0;
-#pragma unroll
-                for (int k = 0; k < DT; ++k)
-                    if (k < d) {
-                        t[k] = xs_l[r * DT + k] - xc_l[cl * d + k];
-                        rr += hp.il2[k] * (t[k] * t[k]);
-                    }
+        for (int g = 0; g < 4; ++g) {
+            fac[e][g] = 0.0;
+            if (g < G && j < N && pass * 16 + 4 * g + q < sc.P) {
                 if (hp.kern == KERN_MAT52ARD) {
-                    const double s = sqrt(5.0) * sqrt(rr);
-                    fac[i] = -(5.0 / 3.0) * hp.sigma2 * (1.0 + s) * exp(-s);
-                } else {
-                    fac[i] = -ksv[i];                    // = -(sigma2 exp(-rr / 2)): the V pass's own value of it, same expression on the same rr
-                }
-                const double a = al_l[cl];
+                    double rr = 0.0;
 #pragma unroll
-                for (int k = 0; k < DT; ++k)
-                    if (k < d) gm[k] += (fac[i] * t[k] * hp.il2[k]) * a;
+                    for (int k = 0; k < DT; ++k)
+                        if (k < d) { const double t = xs_l[(4 * g + q) * DT + k] - xc_l[cl * d + k]; rr += hp.il2[k] * (t * t); }
+                    const double s5 = sqrt(5.0) * sqrt(rr);
+                    fac[e][g] = -(5.0 / 3.0) * hp.sigma2 * (1.0 + s5) * exp(-s5);
+                } else {
+                    fac[e][g] = -(g < 2 ? (g == 0 ? kv[e][0].x : kv[e][0].y) : (g == 2 ? kv[e][1].x : kv[e][1].y));   // -(sigma2 exp(-rr / 2)): the V pass's own value
+                }
             }
         }
-    };
-    if (!small_publish_combine<1>(sc, pass, tile, red, &flag, cb, t0, nseg, acc, sum, meanwhile)) return;
-    // ---- the column block's finisher: u of its 128 observations -> LDS, then the u-weighted gradient sums of those observations
-    double* const ul = lbuf;                   // (the right-hand-side tiles are done with)
-    {
-        const int sp = tid & 7, cl0 = tid >> 3;
-        *(d2*)(ul + cl0 * 16 + 2 * sp) = sum[0];
-        *(d2*)(ul + (cl0 + 64) * 16 + 2 * sp) = sum[1];
     }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int cl = cg * 4 + i, j = cb * 128 + cl;
-        if (j < N && active) {
-            const double uj = ul[cl * 16 + slot];
-#pragma unroll
-            for (int k = 0; k < DT; ++k)
-                if (k < d) gv[k] += (fac[i] * (xs_l[r * DT + k] - xc_l[cl * d + k]) * hp.il2[k]) * uj;
-        }
-    }
-    SM_MARK(sc, 1, 7);
-    // the four lanes of a wave that share a slot (lane bits 4, 5), then the eight waves in wave order: rounds of 8 dimensions x {m, v}
-    double* grec = su.gpart + (((int64_t)pass * T + cb) * 16) * (2 * DT);
+    double* const red2 = lbuf;                   // [8 waves][4 q][4 g][16]: one round = 8 dimensions x {gm, gv}  (the right-hand-side tiles are done with)
+    double* gvrec = su.gpart + (((int64_t)pass * sc.ntiles + tile) * 16) * DT;            // this tile's u-weighted sums [slot][DT]
+    double* gmrec = su.gmpart + (((int64_t)pass * T + cb) * 16) * DT;                   // the block's alpha-weighted sums (first segment's tile)
 #pragma unroll
     for (int kb = 0; kb < DT; kb += 8) {
         if (kb >= d) break;
-        double val[16];
+        // the round's operands from LDS into registers first (the stores into red2 below would keep the compiler from hoisting them)
+        double xcv[2][8], xsv[4][8], alv[2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            double a = kb + k < DT ? gm[kb + k] : 0.0, b = kb + k < DT ? gv[kb + k] : 0.0;
-            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-            val[2 * k] = a; val[2 * k + 1] = b;
+        for (int e = 0; e < 2; ++e) {
+            const int cl = wc * 32 + 2 * p + e;
+            alv[e] = al_l[cl];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) xcv[e][k8] = (kb + k8 < DT && kb + k8 < d) ? xc_l[cl * d + kb + k8] : 0.0;
         }
-        if (kb > 0) __syncthreads();         // (red: the previous round's readers are done; round 0: red was last read before the block's counter)
-        if (lane < 16) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) red[(wave * 16 + lane) * 16 + k] = val[k];
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) xsv[g][k8] = (g < G && kb + k8 < DT) ? xs_l[(4 * g + q) * DT + kb + k8] : 0.0;
+        d2 out[4][8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const int k = kb + k8;
+                double sm = 0.0, sv_ = 0.0;
+                if (g < G && k < DT && k < d) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const double dk = fac[e][g] * (xsv[g][k8] - xcv[e][k8]) * hp.il2[k];
+                        sv_ += dk * acc[e][g];
+                        if (first_seg) sm += dk * alv[e];
+                    }
+                    sv_ = row16_sum(sv_);
+                    if (kc0 == cb) sm = row16_sum(sm);
+                }
+                out[g][k8] = d2{sm, sv_};
+            }
+        }
+        if (kb > 0) __syncthreads();             // (the previous round's readers are done)
+        if (p == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g >= G) break;
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) *(d2*)(red2 + (((wave * 4 + q) * 4 + g) * 8 + k8) * 2) = out[g][k8];
+            }
         }
         __syncthreads();
-        if (tid < 256) {
-            const int sl = tid & 15, vi = tid >> 4;
-            double s = 0.0;
+        if (tid < 64) {                           // (slot, dimension pair): the eight waves in wave order
+            const int slot = tid >> 2, k8 = 2 * (tid & 3), qq = slot >> 2, gg = slot & 3;
+            d2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};       // (gm, gv) of dimensions kb + k8, kb + k8 + 1
+            if (gg < G) {
 #pragma unroll
-            for (int w8 = 0; w8 < 8; ++w8) s += red[(w8 * 16 + sl) * 16 + vi];
-            if (2 * kb + vi < 2 * DT) st_agent(grec + sl * (2 * DT) + 2 * kb + vi, s);
+                for (int w8 = 0; w8 < 8; ++w8) {
+                    s0 += *(const d2*)(red2 + (((w8 * 4 + qq) * 4 + gg) * 8 + k8) * 2);
+                    s1 += *(const d2*)(red2 + (((w8 * 4 + qq) * 4 + gg) * 8 + k8 + 1) * 2);
+                }
+            }
+            if (kb + k8 < DT) {
+                st_agent2(gvrec + slot * DT + kb + k8, s0.y, s1.y);
+                if (kc0 == cb) st_agent2(gmrec + slot * DT + kb + k8, s0.x, s1.x);
+            }
         }
     }
-    SM_MARK(sc, 1, 8);
+    SM_MARK(sc, 1, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) flag = atomicAdd(&sc.cnt[gridDim.y * T + pass], 1u) == (unsigned)(T - 1);
+    if (tid == 0) flag = atomicAdd(&sc.cnt[pass], 1u) == (unsigned)(sc.ntiles - 1);
     __syncthreads();
+    SM_MARK(sc, 1, 5);
     if (!flag) return;
+    if (tid == 0) sc.cnt[pass] = 0u;
     SM_MARK(sc, 1, 9);
-    if (tid == 0) sc.cnt[gridDim.y * T + pass] = 0u;
     // ---- the pass's finisher: the posterior of the pass's candidates (what k_small_v's finisher does in a value-only call: same function,
-    // same bits) and the gradient records in block order, both fetched in ONE round trip; then the chain rule through the reference's
-    // acquisition formulas.  (slot, dimension) pairs; the block records of a pair are fetched by `nparts` threads at once and the parts added
-    // in part order: the order depends on (T, d) only
-    if (sc.vflag) {     // fused form: every column block's q record of the V pass must be out (normally long since)
-        for (int b = tid; b < T; b += SP_THREADS) small_wait_flag(sc, sc.vflag + ((int64_t)pass * T + b) * 2 + 1);
-        __syncthreads();
-    }
-    const double* gp = su.gpart + ((int64_t)pass * T * 16) * (2 * DT);
-    const int npairs = 16 * d, nparts = max(1, min(8, SP_THREADS / npairs)), bpp = (T + nparts - 1) / nparts;
-    double* gfin = lbuf;                                 // [nparts][npairs][2]  (<= 8 * 64 * 2 or 2 * 256 * 2 doubles) -- behind small_posterior_final's use of lbuf
-    const bool fast = nparts > 1 && bpp <= 8;            // one round trip for everything (T <= 8 nparts)
-    double ga = 0.0, gb = 0.0;
-    const int pair = tid % npairs, part = tid / npairs;
+    // same bits) and the tiles' records in tile order; then the chain rule through the reference's acquisition formulas.  (slot, dimension)
+    // pairs; the records of a pair are fetched by `nparts` threads, each a contiguous range of tiles, twenty 16-byte loads in flight, and the
+    // parts added in part order: the order depends on (T, m, d) only
+    // pairs = (candidate, two dimensions); a pair's tile records are fetched by `nparts` threads, each a contiguous range of tiles (and of
+    // column blocks for the alpha-weighted sums), all of them in flight at once together with the posterior's records; the parts are added in
+    // part order: the order depends on (T, m, d) only
+    const double* gp = su.gpart + ((int64_t)pass * sc.ntiles * 16) * DT;
+    const double* gmp = su.gmpart + ((int64_t)pass * T * 16) * DT;
+    const int pcand = min(16, sc.P - pass * 16), dh = (d + 1) / 2;      // candidates of this pass, dimension pairs
+    const int npairs = pcand * dh;                                       // <= 16 * 32 = SP_THREADS
+    int nparts = max(1, min(16, SP_THREADS / npairs));
+    while (nparts < 16 && (sc.ntiles + nparts - 1) / nparts > 24 && (nparts + 1) * npairs <= SP_THREADS) ++nparts;
+    const int bpp = (sc.ntiles + nparts - 1) / nparts, bpm = (T + nparts - 1) / nparts;
+    double* gfin = lbuf + 4096;                          // [nparts][npairs][4]  (behind small_posterior_final's two LDS planes)
+    const int pr = tid % npairs, pt = tid / npairs;
+    const bool mine = tid < npairs * nparts;
+    const int ri = pr / dh, k2 = pr % dh, sl = 4 * (ri & 3) + (ri >> 2);       // candidate ri of the pass lives in slot 4 (ri % 4) + ri / 4
+    d2 ga = {0.0, 0.0}, gb = {0.0, 0.0};                 // (gm, gv) of dimensions 2 k2, 2 k2 + 1
     auto fetch = [&]() {
-        if (!fast || tid >= npairs * nparts) return;
-        const double* src = gp + (int64_t)(pair / d) * (2 * DT) + 2 * (pair % d);
-        const int bl0 = part * bpp, bl1 = min(T, bl0 + bpp);
-        double va[8], vb[8];
+        if (!mine) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
+        const double* src = gp + (int64_t)sl * DT + 2 * k2;
+        const double* srm = gmp + (int64_t)sl * DT + 2 * k2;
+        for (int b0 = 0; b0 < bpp; b0 += 24) {           // (one trip up to 24 tiles per part: 384 tiles with 16 parts)
+            const int bl0 = pt * bpp + b0, bl1 = min(sc.ntiles, pt * bpp + min(bpp, b0 + 24));
+            const int ml0 = pt * bpm, ml1 = b0 == 0 ? min(T, ml0 + min(bpm, 4)) : ml0;
+            d2 v[24], vm[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double* s2 = src + (int64_t)min(bl0 + j, T - 1) * 16 * (2 * DT);
-            va[j] = ld_agent(s2); vb[j] = ld_agent(s2 + 1);
+            for (int j = 0; j < 24; ++j) ld_agent_x2_issue(src + (int64_t)max(0, min(bl0 + j, bl1 - 1)) * 16 * DT, v[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ld_agent_x2_issue(srm + (int64_t)max(0, min(ml0 + j, ml1 - 1)) * 16 * DT, vm[j]);
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                           "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]),
+                           "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]), "+v"(vm[0]), "+v"(vm[1]), "+v"(vm[2]), "+v"(vm[3])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int j = 0; j < 24; ++j)
+                if (bl0 + j < bl1) gb += v[j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ml0 + j < ml1) ga += vm[j];
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (bl0 + j < bl1) { ga += va[j]; gb += vb[j]; }
+        for (int b = pt * bpm + 4; b < min(T, (pt + 1) * bpm); ++b) {        // (more than four column blocks per part: T > 64)
+            d2 vmx;
+            ld_agent_x2_issue(srm + (int64_t)b * 16 * DT, vmx);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vmx) : : "memory");
+            ga += vmx;
+        }
     };
     {
         double f, mu_, s2_;
         long long idx;
         small_posterior_final(su.sv, pass, T, sc.P, lbuf, f, idx, mu_, s2_, fetch);
         if (tid < 16) { post_l[2 * tid] = mu_; post_l[2 * tid + 1] = s2_; }
-        __syncthreads();
     }
+    if (mine) { *(d2*)(gfin + (pt * npairs + pr) * 4) = ga; *(d2*)(gfin + (pt * npairs + pr) * 4 + 2) = gb; }
+    __syncthreads();
     SM_MARK(sc, 1, 10);
-    for (int e0 = 0; e0 < npairs; e0 += SP_THREADS) {    // (one trip unless d > 32)
-        const int e = e0 + tid, pr = nparts > 1 ? pair : e, pt = nparts > 1 ? part : 0;
-        const bool mine = nparts > 1 ? tid < npairs * nparts : e < npairs;
-        const int sl = pr / d, k = pr % d;
-        double a = ga, b = gb;
-        if (mine && !fast) {
-            const double* src = gp + (int64_t)sl * (2 * DT) + 2 * k;
-            const int bl0 = pt * bpp, bl1 = min(T, bl0 + bpp);
-            for (int b0 = bl0; b0 < bl1; b0 += 8) {          // eight records in flight, added in block order
-                double va[8], vb[8];
+    if (tid < npairs) {
+        d2 a = {0.0, 0.0}, b = {0.0, 0.0};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const double* s2 = src + (int64_t)min(b0 + j, bl1 - 1) * 16 * (2 * DT);
-                    va[j] = ld_agent(s2); vb[j] = ld_agent(s2 + 1);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (b0 + j < bl1) { a += va[j]; b += vb[j]; }
-            }
-        }
-        if (nparts > 1) {
-            if (mine) { gfin[(pt * npairs + pr) * 2] = a; gfin[(pt * npairs + pr) * 2 + 1] = b; }
-            __syncthreads();
-            if (tid >= npairs) continue;
-            a = 0.0; b = 0.0;
-#pragma unroll
-            for (int pp = 0; pp < 8; ++pp)
-                if (pp < nparts) { a += gfin[(pp * npairs + tid) * 2]; b += gfin[(pp * npairs + tid) * 2 + 1]; }
-        } else if (!mine) {
-            continue;
-        }
-        const int rr = pass * 16 + small_slot_to_r(sl);
-        if (rr >= sc.P) continue;
+        for (int pp = 0; pp < 16; ++pp)
+            if (pp < nparts) { a += *(const d2*)(gfin + (pp * npairs + tid) * 4); b += *(const d2*)(gfin + (pp * npairs + tid) * 4 + 2); }
+        const int rr = pass * 16 + ri;
         const double m = post_l[2 * sl], v = post_l[2 * sl + 1];
         double dmu, ds2;
         acq_partials(su.sv.ap, m, v, dmu, ds2);
         // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
-        su.grad[(int64_t)rr * d + k] = dmu * a + (v > 0.0 ? ds2 * (-2.0 * b) : 0.0);
-    }
-    if (sc.vflag && __hip_atomic_load(sc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == sc.epoch) {
-        // a wait of this launch timed out: whatever was computed behind it is garbage -- the call returns NaN (loud), not numbers
-        __syncthreads();
-        for (int e = tid; e < 16 * d; e += SP_THREADS) {
-            const int rr = pass * 16 + small_slot_to_r(e / d);
-            if (rr < sc.P) { su.grad[(int64_t)rr * d + e % d] = NAN; if (e % d == 0 && su.sv.score_out) su.sv.score_out[rr] = NAN; }
-        }
+        su.grad[(int64_t)rr * d + 2 * k2] = dmu * a.x + (v > 0.0 ? ds2 * (-2.0 * b.x) : 0.0);
+        if (2 * k2 + 1 < d) su.grad[(int64_t)rr * d + 2 * k2 + 1] = dmu * a.y + (v > 0.0 ? ds2 * (-2.0 * b.y) : 0.0);
     }
     SM_MARK(sc, 1, 11);
 }
@@ -707,17 +695,6 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU s
     if (sc.go && *sc.go == 0u) return;
     SMALL_LDS_DECL(DT, L);
     small_u_body<DT, G>(sc, su, hp, blockIdx.x, L);
-}
-// The fused form: the V tiles (blocks [0, ntiles)) and the U tiles (blocks [ntiles, 2 ntiles)) of a pass in ONE launch.  A U tile requests
-// its part of W at once, then waits for the V' blocks it contracts (flags) -- its stream and its prologue run under the V pass's tail, and
-// one launch boundary is gone.  Blocks are dispatched in index order: whatever a U tile waits for was dispatched before it and waits for
-// nothing itself.
-template <int DT, int G>
-__global__ __launch_bounds__(SP_THREADS) void k_small_vu(SmallCommon scv, SmallCommon scu, SmallV sv, SmallU su, KernelHyper hp) {
-    if (scv.go && *scv.go == 0u) return;
-    SMALL_LDS_DECL(DT, L);
-    if ((int)blockIdx.x < scv.ntiles) small_v_body<DT, G>(scv, sv, hp, blockIdx.x, L);
-    else small_u_body<DT, G>(scu, su, hp, (int)blockIdx.x - scv.ntiles, L);
 }
 
 }  // namespace bohip

@@ -15,8 +15,8 @@ Xs = np.asfortranarray(rng.random((d, R)))
 lib = _lib.load()
 names = {0: ["start", "tile known", "first rhs tile in LDS", "contraction done", "tile published (stores acked)", "counted in", "combined (last arriver)",
              "block record out", "pass counted", "posterior final", "arg-max", ""],
-         1: ["start", "tile known", "first rhs tile in LDS", "contraction done", "tile published (stores acked)", "counted in", "combined (last arriver)",
-             "gradient sums of the block", "record out", "pass counted", "posterior final", "gradient out"]}
+         1: ["start", "tile known", "first rhs tile in LDS", "contraction done", "tile's gradient record out", "counted in", "", "", "",
+             "last tile of the pass", "posterior final", "gradient out"]}
 for what in ("score_grad", "score"):
     for _ in range(20):
         (m.score_grad if what == "score_grad" else m.score)("EI", [y.max()], Xs)
