@@ -1904,7 +1904,8 @@ static int64_t small_limit(const bohip_gp* g) {
     // form applies it wins earlier (N=1500: ~150, N=3000: ~95, N=10000: ~55)
     // (round 4, k_trimv_stream: the row-wise products take 16 right-hand sides per pass over W, so the break-even moves in steps of 16:
     // N = 1000: ~240, N = 3000: 80, N = 10^4: 32 -- tools/small_limit_sweep.py, profiles/r04_small_limit_sweep.txt)
-    if (split_applicable(g)) return std::min<int64_t>(SMALL_MAX, std::max<int64_t>(16, (20 + 220000 / std::max<int64_t>(g->n, 1)) / 16 * 16));
+    // (round 5, kernels_small.hip: 256 at N = 1000, 96 at N = 3000, 32 at N = 10^4 -- profiles/r05_small_limit_sweep.txt)
+    if (split_applicable(g)) return std::min<int64_t>(SMALL_MAX, std::max<int64_t>(16, (20 + 260000 / std::max<int64_t>(g->n, 1)) / 16 * 16));
     return std::min<int64_t>(SMALL_MAX, 90 + 300000 / std::max<int64_t>(g->n, 1));
 }
 // the batch size the path decision is based on (see bohip_gp_set_batch_hint)

@@ -5,7 +5,7 @@ What round 4's verdict listed as sampling holes, closed here inside the driver-r
     GaussianProcesses.jl's update, reference src/models/gp.jl:11-18 -- itself pinned against the C oracle's own factorisation at a
     size both afford), the WHOLE device factor against it, ALL 640 candidates scored by the oracle on that factor, arg-max asserted;
   * the stress variant (kappa ~ 5e10) on all 4096 candidates, arg-max over the full set;
-  * the small-batch path (k_trimv_stream x2 + k_grad_finish) at the bench's `default_usage` sizes against the oracle's analytic
+  * the small-batch path (round 5: k_small_v + k_small_u, kernels_small.hip) at the bench's `default_usage` sizes against the oracle's analytic
     value + gradient, and bohip_gp_acquire_max at that shape against SciPy's L-BFGS-B on the oracle (reference
     src/acquisition.jl:54-68);
   * one seed each of the randomised sweeps tools/fuzz_parity.py / tools/fuzz_large.py.
@@ -93,7 +93,7 @@ def test_c4_whole_factor_and_all_640_candidates_on_an_independent_factor(bohip, 
 
 
 def test_c4_small_batch_pass_vs_oracle(bohip, orc):
-    """The small-batch pass at N = 10^4, d = 16, R = 10 (bench.py's `small_batch_c4`; k_trimv_stream with 40 column chunks):
+    """The small-batch pass at N = 10^4, d = 16, R = 10 (bench.py's `small_batch_c4`):
     value + analytic gradient against the oracle on the LAPACK factor."""
     N, d = 10000, 16
     X, y, Xs = synth(N, d, 10, seed=4)
@@ -125,10 +125,10 @@ def headline(bohip, orc):
     return m, X, y, ll, L, alpha
 
 
-@pytest.mark.parametrize("R", [1, 10, 16, 17, 80, 190])
+@pytest.mark.parametrize("R", [1, 10, 16, 17, 96, 190])
 def test_small_batch_pass_at_the_headline_model_vs_oracle(bohip, orc, headline, R):
     """score_grad at N = 3000, d = 8 for the batch sizes of the reference's defaults (R = 10: `default_usage`; 1; one and two passes
-    of 16 right-hand sides; the last row-wise size, 80; 190 = the split-K schedule): every value and gradient against the oracle,
+    of 16 right-hand sides; the last small-batch size, 96; 190 = the split-K schedule): every value and gradient against the oracle,
     value path == gradient path and batch == single bit for bit, arg-max = the oracle's."""
     m, X, y, ll, L, alpha = headline
     Xs = np.random.default_rng(100 + R).random((R, 8))
@@ -148,7 +148,7 @@ def test_small_batch_pass_at_the_headline_model_vs_oracle(bohip, orc, headline, 
         if R == 1 or top[1] - top[0] > 2 * fl.max() + 1e-6 * abs(top[1]):
             assert bi == int(np.argmax(sc_o))
         assert bv == sv[bi] and bi == int(np.argmax(sv))
-        if R <= 80:
+        if R <= 96:
             j = R // 2
             assert m.score(acq, p, Xs[j:j + 1].T)[0][0] == sv[j]
 
