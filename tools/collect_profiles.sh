@@ -1,6 +1,6 @@
 #!/bin/bash
 # everything copied to profiles/r04_* in one GPU call (tag = $1, default r04)
-TAG=${1:-r04}
+TAG=${1:-r05}
 out=gpurun_out/$TAG; mkdir -p $out
 bash tools/prof.sh $TAG > $out/prof_stdout.txt 2>&1
 cp gpurun_out/prof_$TAG/summary.txt $out/rocprof_bench_summary.txt 2>/dev/null
@@ -23,3 +23,12 @@ python tools/small_batch_bench.py 2>&1 | grep -v amdgpu > $out/small_batch_bench
 python tools/power_probe.py 4096 2>&1 | grep -v amdgpu > $out/power_probe.txt
 make -C bayesianoptimization.jl_amd/csrc abl/libbohip_trace.so > /dev/null 2>&1
 python tools/trace_trigemm.py 2>&1 | grep -v amdgpu > $out/trigemm_workgroup_timeline.txt
+# round 5: the small-batch pass (kernels_small.hip): kernel trace statistics and the in-kernel timeline; the full GPU test suite's log
+{
+bash tools/small_pass_prof.sh "3000 8" "500 2" "1000 4" "10000 16"
+echo "# the same with round 4's five-kernel pass (BOHIP_SMALL_MFMA=0)"
+BOHIP_SMALL_MFMA=0 bash tools/small_pass_prof.sh "3000 8" "10000 16"
+} > $out/small_pass_kernel_stats.txt 2>&1
+make -C bayesianoptimization.jl_amd/csrc abl/libbohip_smalltrace.so > /dev/null 2>&1
+{ timeout 100 python tools/small_pass_trace.py 3000 8; timeout 100 python tools/small_pass_trace.py 500 2; timeout 100 python tools/small_pass_trace.py 10000 16; } 2>&1 | grep -v amdgpu > $out/small_pass_trace.txt
+timeout 1500 python -m pytest tests -m gpu -q -s --durations=15 2>&1 | grep -v amdgpu > $out/pytest_gpu.txt
