@@ -153,6 +153,33 @@ def test_small_batch_pass_at_the_headline_model_vs_oracle(bohip, orc, headline, 
             assert m.score(acq, p, Xs[j:j + 1].T)[0][0] == sv[j]
 
 
+@pytest.mark.parametrize("N,d,R,kern", [(600, 40, 5, "SEArd"), (900, 64, 20, "SEArd"), (700, 33, 33, "Mat52Ard"), (300, 1, 7, "SEIso"), (1300, 3, 50, "SEArd")])
+def test_small_batch_pass_wide_and_odd_dimensions(bohip, orc, N, d, R, kern):
+    """The small-batch kernels are instantiated per dimension class (2, 4, 8, 16, 32, 64) and fetch their gradient records two dimensions at
+    a time: odd d, d > 32 (one trip of the final's loop per 32 dimensions), Mat52 (its own gradient factor), several passes of 16 candidates."""
+    X, y, Xs = synth(N, d, R, seed=N + d)
+    nl = 1 if kern == "SEIso" else d
+    ll = np.linspace(0.2, 0.6, nl) if d > 16 else np.linspace(-0.8, -0.4, nl)
+    llp = ll if nl > 1 else float(ll[0])
+    lsig, lnoise, beta = 0.15, -1.8, 0.1
+    L, alpha = orc.fit(X, y, llp, lsig, lnoise, beta, kern=kern)
+    m = make_model(bohip, X, y, llp, lsig, lnoise, beta, kern=kern)
+    s2f = math.exp(2 * lsig)
+    for acq, p in [("EI", [float(np.median(y))]), ("UCB", [2.0])]:
+        sc, g = m.score_grad(acq, p, Xs.T)
+        sc_o, g_o = orc.score_grad(X, llp, lsig, beta, L, alpha, acq, p, Xs, kern=kern)
+        _, var_o = orc.predict(X, llp, lsig, beta, L, alpha, Xs, kern=kern, nthreads=8)
+        vt0 = var_tol(var_o, N, s2f, rel=0)
+        fl = mu_floor(alpha, s2f) + (2.0 * np.sqrt(vt0) if acq == "UCB" else vt0) + 1e-13
+        assert np.all(np.abs(sc - sc_o) <= 1e-6 * np.abs(sc_o) + fl), (acq, np.abs(sc - sc_o).max())
+        good = var_o > 1e3 * var_tol(var_o, N, s2f)
+        np.testing.assert_allclose(g.T[good], g_o[good], rtol=1e-6, atol=1e-8 * np.abs(g_o).max(), err_msg=f"{acq} d={d}")
+        sv, bv, bi = m.score(acq, p, Xs.T)
+        np.testing.assert_array_equal(sv, sc)
+        assert bi == int(np.argmax(sv)) and bv == sv[bi]
+        assert m.score(acq, p, Xs[R // 2:R // 2 + 1].T)[0][0] == sv[R // 2]
+
+
 def test_default_usage_acquire_max_vs_scipy_on_the_oracle(bohip, orc, headline):
     """bench.py's `default_usage` (the reference's defaults: 10 Latin-hypercube starts, :LD_LBFGS with the box bounds, UCB at
     BrochuBetaScaling's beta_t, reference src/acquisition.jl:4-6,54-68) on the headline model: per start the device's end point is

@@ -5,6 +5,7 @@ out=gpurun_out/$TAG; mkdir -p $out
 bash tools/prof.sh $TAG > $out/prof_stdout.txt 2>&1
 cp gpurun_out/prof_$TAG/summary.txt $out/rocprof_bench_summary.txt 2>/dev/null
 cp gpurun_out/prof_$TAG/traffic_trigemm_sq.json $out/traffic_trigemm_sq.json 2>/dev/null
+rm -rf gpurun_out/prof_$TAG/kt gpurun_out/prof_$TAG/pmc_*   # (raw traces: tens of MB; gpurun merges at most 64 MiB back)
 python bench.py > $out/bench_line_default.json 2> $out/bench.err
 python bench.py --strong --no-cpu-baseline --no-c4 > $out/bench_line_strong_1gpu.json 2>> $out/bench.err
 BOHIP_LOGICAL_SHARDS=1 python bench.py --gpus 8 --no-cpu-baseline > $out/bench_line_8_logical_shards_1gpu.json 2>> $out/bench.err
@@ -32,3 +33,12 @@ BOHIP_SMALL_MFMA=0 bash tools/small_pass_prof.sh "3000 8" "10000 16"
 make -C bayesianoptimization.jl_amd/csrc abl/libbohip_smalltrace.so > /dev/null 2>&1
 { timeout 100 python tools/small_pass_trace.py 3000 8; timeout 100 python tools/small_pass_trace.py 500 2; timeout 100 python tools/small_pass_trace.py 10000 16; } 2>&1 | grep -v amdgpu > $out/small_pass_trace.txt
 timeout 1500 python -m pytest tests -m gpu -q -s --durations=15 2>&1 | grep -v amdgpu > $out/pytest_gpu.txt
+# soak of the dataflow forms (12 fresh processes x 8 refits) and W under 8 concurrent refits (the cross-process lock is non-blocking since round 5)
+{
+echo "tools/chol_soak.py N 12 8 (12 fresh processes x 8 refits each): the last process's stage times and the count of processes that saw a time-out"
+for N in 10000 7000 3000 1000; do echo "== N=$N"; timeout 600 python tools/chol_soak.py $N 12 8 2>&1 | grep -v amdgpu | tail -1; timeout 600 python tools/chol_soak.py $N 12 8 2>&1 | grep -c "fall-backs 0" | sed 's/$/ of 12 processes without a time-out/'; done
+echo "== two processes refitting at once on one device (the non-blocking file lock), N=3000, 8 refits each"
+(timeout 300 python tools/chol_soak.py 3000 4 8 2>&1 | grep -v amdgpu | sed 's/^/A: /' &) ; timeout 300 python tools/chol_soak.py 3000 4 8 2>&1 | grep -v amdgpu | sed 's/^/B: /'; wait
+echo "== tools/w_stress.py 3000 8 8"
+timeout 600 python tools/w_stress.py 3000 8 8 2>&1 | grep -v amdgpu
+} > $out/soak.txt 2>&1
