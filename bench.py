@@ -506,7 +506,7 @@ def default_usage(model, tau):
                         ":LD_LBFGS (the reference's defaultoptions)",
             "acquire_max_ms": t * 1e3, "evaluations": int(ev), "us_per_evaluation": t / max(ev, 1) * 1e6,
             "score_grad_call_us": float(np.median(sg)) * 1e6, "best": {"value": float(bf), "index": int(bi)},
-            "note": "an evaluation = value + gradient of all 10 starts in one pass (kstar, two row-wise triangular products, finish); "
+            "note": "an evaluation = value + gradient of all 10 starts in one pass (round 5: two kernels, K*' + V' + posterior and U' + gradient, kernels_small.hip); "
                     "compare with 10 / cpu_baseline.with_gradient.value seconds per such pass on one CPU core",
             "small_model": default_usage_small()}
 
