@@ -182,9 +182,9 @@ __device__ __forceinline__ void small_contract(const SmallCommon& sc, double* rt
 }
 // Publication of the tile + the column block's combine.  Returns true in the LAST ARRIVER of the column block, with the combined sums of
 // pieces (tid, tid + 512) in sum[0..1]: piece e = c_local * 8 + sp  <->  out[cb * 128 + c_local][slots 2 sp, 2 sp + 1].
-// meanwhile(): what the last arriver does while the partial tiles are on their way (one round trip to the memory side: ~2 us).  The
-// loads are plain compiler-tracked 8-byte agent-scope loads, so code between their issue and their use is safe (running it in EVERY
-// workgroup under the stores' acknowledgement was measured: 2.5 us on the critical path of every tile instead of one).
+// meanwhile(): a hook behind the first round of loads (unused since the U pass stopped publishing partial tiles; the V pass passes nothing).
+// The partial tiles come as 16-byte agent-scope loads issued and waited for in ONE asm sequence (8-byte atomic loads read handed-off data at
+// 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md: 196 KB per finisher at N = 3000).
 template <int UPPER, class Meanwhile>
 __device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int pass, int tile, double* red, int* flag, int cb, int t0, int nseg,
                                                       const double (&acc)[2][4], d2 (&sum)[2], Meanwhile&& meanwhile) {
@@ -220,17 +220,24 @@ __device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int
     const double* p0 = sc.part + ((int64_t)pass * sc.ntiles + t0) * 2048 + 2 * tid;
     sum[0] = d2{0.0, 0.0};
     sum[1] = d2{0.0, 0.0};
-    for (int s0 = 0; s0 < nseg; s0 += 12) {         // twelve segments in flight per piece (one round trip to the memory side, ~2 us), added in segment order
-        double v[12][4];
+    for (int s0 = 0; s0 < nseg; s0 += 12) {         // twelve segments in flight per piece as 16-byte loads (one round trip to the memory side), added in segment order
+        d2 v[2][12];
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            const double* src = p0 + (int64_t)min(s0 + j, nseg - 1) * 2048;
-            v[j][0] = ld_agent(src); v[j][1] = ld_agent(src + 1); v[j][2] = ld_agent(src + 1024); v[j][3] = ld_agent(src + 1025);
+            const int si = min(s0 + j, nseg - 1);
+            ld_agent_x2_issue(p0 + (int64_t)si * 2048, v[0][j]);
+            ld_agent_x2_issue(p0 + (int64_t)si * 2048 + 1024, v[1][j]);
         }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[0][4]), "+v"(v[0][5]), "+v"(v[0][6]), "+v"(v[0][7]),
+                       "+v"(v[0][8]), "+v"(v[0][9]), "+v"(v[0][10]), "+v"(v[0][11]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]),
+                       "+v"(v[1][4]), "+v"(v[1][5]), "+v"(v[1][6]), "+v"(v[1][7]), "+v"(v[1][8]), "+v"(v[1][9]), "+v"(v[1][10]), "+v"(v[1][11])
+                     :
+                     : "memory");
         if (s0 == 0) meanwhile();
 #pragma unroll
         for (int j = 0; j < 12; ++j)
-            if (s0 + j < nseg) { sum[0].x += v[j][0]; sum[0].y += v[j][1]; sum[1].x += v[j][2]; sum[1].y += v[j][3]; }
+            if (s0 + j < nseg) { sum[0] += v[0][j]; sum[1] += v[1][j]; }
     }
     SM_MARK(sc, UPPER, 6);
     return true;
@@ -238,7 +245,8 @@ __device__ __forceinline__ bool small_publish_combine(const SmallCommon& sc, int
 
 // The posterior finish of one pass of 16 candidates (k_small_finish's formulas): q = sum of the column blocks' records in block order,
 // mu - beta likewise, sigma^2 = max(s_f^2 - q, 0), the acquisition value.  The records are fetched by all threads at once (one round
-// trip), then added by one thread per slot from LDS.  buf: >= 4096 doubles of LDS.  Thread `slot` (< 16) returns (f, candidate index).
+// trip), then added by one thread per slot from LDS.  buf: >= 4096 doubles of LDS.  Thread `slot` (< 16) returns (f, candidate index) and
+// (mu, sigma^2); threads 64 + slot return (mu, sigma^2) too.
 template <class Meanwhile>
 __device__ __forceinline__ void small_posterior_final(const SmallV& sv, int pass, int T, int P, double* buf, double& f_out, long long& idx_out,
                                                       double& mu_o, double& s2_o, Meanwhile&& meanwhile) {
@@ -261,11 +269,12 @@ __device__ __forceinline__ void small_posterior_final(const SmallV& sv, int pass
             if (e < nb * 16) { buf[e] = qv[i]; buf[2048 + e] = mv[i]; }
         }
         __syncthreads();
-        if (tid < 16) {      // (eight LDS reads in flight per step: a rolled loop pays one LDS latency per addend)
+        if (tid < 128 && (tid & 63) < 16) {      // slot = lane, in waves 0 and 1 (the second copy: see mu_o / s2_o below); eight LDS reads in flight per step
+            const int sl_ = tid & 63;
             for (int b = 0; b < nb; b += 8) {
                 double tq[8], tm[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { tq[j] = buf[min(b + j, nb - 1) * 16 + tid]; tm[j] = buf[2048 + min(b + j, nb - 1) * 16 + tid]; }
+                for (int j = 0; j < 8; ++j) { tq[j] = buf[min(b + j, nb - 1) * 16 + sl_]; tm[j] = buf[2048 + min(b + j, nb - 1) * 16 + sl_]; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (b + j < nb) qs += tq[j];
 #pragma unroll
@@ -276,6 +285,9 @@ __device__ __forceinline__ void small_posterior_final(const SmallV& sv, int pass
     f_out = -INFINITY;
     idx_out = -1;
     mu_o = 0.0; s2_o = 0.0;
+    if (tid >= 64 && tid < 80) {     // wave 1's copy of (mu, sigma^2) of slot tid - 64: the caller may run the chain rule's partials there, beside wave 0's acquisition value
+        if (pass * 16 + small_slot_to_r(tid - 64) < P) posterior_like_small_finish(sv.sigma2, sv.beta, qs, mr, mu_o, s2_o);
+    }
     if (tid < 16) {
         const int rr = pass * 16 + small_slot_to_r(tid);
         if (rr < P) {
@@ -619,74 +631,133 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU
     // same bits) and the tiles' records in tile order; then the chain rule through the reference's acquisition formulas.  (slot, dimension)
     // pairs; the records of a pair are fetched by `nparts` threads, each a contiguous range of tiles, twenty 16-byte loads in flight, and the
     // parts added in part order: the order depends on (T, m, d) only
-    // pairs = (candidate, two dimensions); a pair's tile records are fetched by `nparts` threads, each a contiguous range of tiles (and of
-    // column blocks for the alpha-weighted sums), all of them in flight at once together with the posterior's records; the parts are added in
-    // part order: the order depends on (T, m, d) only
+    // Two things run side by side in this workgroup.  WAVES 0 AND 1, lanes 0..15 (slot = lane): the posterior of the pass's candidates -- each
+    // lane fetches its slot's T q records and T mu records itself (all in flight at once) and adds them in block order, exactly the sums of
+    // small_posterior_final (the value-only call's finisher): same numbers, same order, same bits; wave 0 then evaluates the acquisition,
+    // wave 1 the chain rule's partials (erf / exp in both).  WAVES 2..7: pairs = (candidate, two dimensions); a pair's tile records are
+    // fetched by `nparts` threads, each a contiguous range of tiles (and of column blocks for the alpha-weighted sums), all of them in
+    // flight at once; the parts are added in part order: the order depends on (T, m, d) only.
     const double* gp = su.gpart + ((int64_t)pass * sc.ntiles * 16) * DT;
     const double* gmp = su.gmpart + ((int64_t)pass * T * 16) * DT;
     const int pcand = min(16, sc.P - pass * 16), dh = (d + 1) / 2;      // candidates of this pass, dimension pairs
-    const int npairs = pcand * dh;                                       // <= 16 * 32 = SP_THREADS
-    int nparts = max(1, min(16, SP_THREADS / npairs));
-    while (nparts < 16 && (sc.ntiles + nparts - 1) / nparts > 24 && (nparts + 1) * npairs <= SP_THREADS) ++nparts;
-    const int bpp = (sc.ntiles + nparts - 1) / nparts, bpm = (T + nparts - 1) / nparts;
-    double* gfin = lbuf + 4096;                          // [nparts][npairs][4]  (behind small_posterior_final's two LDS planes)
-    const int pr = tid % npairs, pt = tid / npairs;
-    const bool mine = tid < npairs * nparts;
-    const int ri = pr / dh, k2 = pr % dh, sl = 4 * (ri & 3) + (ri >> 2);       // candidate ri of the pass lives in slot 4 (ri % 4) + ri / 4
-    d2 ga = {0.0, 0.0}, gb = {0.0, 0.0};                 // (gm, gv) of dimensions 2 k2, 2 k2 + 1
-    auto fetch = [&]() {
-        if (!mine) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); return; }
-        const double* src = gp + (int64_t)sl * DT + 2 * k2;
-        const double* srm = gmp + (int64_t)sl * DT + 2 * k2;
-        for (int b0 = 0; b0 < bpp; b0 += 24) {           // (one trip up to 24 tiles per part: 384 tiles with 16 parts)
-            const int bl0 = pt * bpp + b0, bl1 = min(sc.ntiles, pt * bpp + min(bpp, b0 + 24));
-            const int ml0 = pt * bpm, ml1 = b0 == 0 ? min(T, ml0 + min(bpm, 4)) : ml0;
-            d2 v[24], vm[4];
+    const int npairs = pcand * dh;                                       // <= 16 * 32
+    constexpr int FT = SP_THREADS - 128;                                 // fetching threads
+    double* gfin = lbuf;                                                 // [nparts][npairs][4]
+    if (tid < 128) {
+        const int slot_ = tid & 63;
+        if (slot_ < 16 && pass * 16 + small_slot_to_r(slot_) < sc.P) {
+            const double* qsrc = su.sv.qpart + (int64_t)pass * T * 16 + slot_;
+            const double* msrc = su.sv.mupart + (int64_t)pass * T * 16 + slot_;
+            double qs = 0.0, mr = 0.0;
+            for (int b0 = 0; b0 < T; b0 += 16) {
+                double tq[16], tm[16];
 #pragma unroll
-            for (int j = 0; j < 24; ++j) ld_agent_x2_issue(src + (int64_t)max(0, min(bl0 + j, bl1 - 1)) * 16 * DT, v[j]);
+                for (int j = 0; j < 16; ++j) { tq[j] = ld_agent(qsrc + (int64_t)min(b0 + j, T - 1) * 16); tm[j] = ld_agent(msrc + (int64_t)min(b0 + j, T - 1) * 16); }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ld_agent_x2_issue(srm + (int64_t)max(0, min(ml0 + j, ml1 - 1)) * 16 * DT, vm[j]);
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
-                           "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]),
-                           "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]), "+v"(vm[0]), "+v"(vm[1]), "+v"(vm[2]), "+v"(vm[3])
-                         :
-                         : "memory");
+                for (int j = 0; j < 16; ++j) if (b0 + j < T) qs += tq[j];
 #pragma unroll
-            for (int j = 0; j < 24; ++j)
-                if (bl0 + j < bl1) gb += v[j];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (ml0 + j < ml1) ga += vm[j];
+                for (int j = 0; j < 16; ++j) if (b0 + j < T) mr += tm[j];
+            }
+            double mu, s2;
+            posterior_like_small_finish(su.sv.sigma2, su.sv.beta, qs, mr, mu, s2);
+            if (tid < 64) {
+                const int rr = pass * 16 + small_slot_to_r(slot_);
+                if (su.sv.mu_out) su.sv.mu_out[rr] = mu;
+                if (su.sv.var_out) su.sv.var_out[rr] = s2;
+                if (su.sv.score_out) su.sv.score_out[rr] = acq_eval(su.sv.ap, mu, s2);
+            } else {
+                double dmu, ds2;
+                acq_partials(su.sv.ap, mu, s2, dmu, ds2);
+                post_l[2 * slot_] = dmu;
+                post_l[2 * slot_ + 1] = ds2;
+                post_l[32 + slot_] = s2;
+            }
         }
-        for (int b = pt * bpm + 4; b < min(T, (pt + 1) * bpm); ++b) {        // (more than four column blocks per part: T > 64)
-            d2 vmx;
-            ld_agent_x2_issue(srm + (int64_t)b * 16 * DT, vmx);
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vmx) : : "memory");
-            ga += vmx;
-        }
-    };
-    {
-        double f, mu_, s2_;
-        long long idx;
-        small_posterior_final(su.sv, pass, T, sc.P, lbuf, f, idx, mu_, s2_, fetch);
-        if (tid < 16) { post_l[2 * tid] = mu_; post_l[2 * tid + 1] = s2_; }
+        SM_MARK(sc, 1, 7);
     }
-    if (mine) { *(d2*)(gfin + (pt * npairs + pr) * 4) = ga; *(d2*)(gfin + (pt * npairs + pr) * 4 + 2) = gb; }
-    __syncthreads();
-    SM_MARK(sc, 1, 10);
-    if (tid < npairs) {
-        d2 a = {0.0, 0.0}, b = {0.0, 0.0};
+    const int ft = tid - 128;
+    if (npairs <= FT) {
+        int nparts = max(1, min(16, FT / npairs));
+        const int bpp = (sc.ntiles + nparts - 1) / nparts, bpm = (T + nparts - 1) / nparts;
+        const int pr = ft >= 0 ? ft % npairs : 0, pt = ft >= 0 ? ft / npairs : 0;
+        const bool mine = ft >= 0 && ft < npairs * nparts;
+        const int ri = pr / dh, k2 = pr % dh, sl = 4 * (ri & 3) + (ri >> 2);       // candidate ri of the pass lives in slot 4 (ri % 4) + ri / 4
+        if (mine) {
+            d2 ga = {0.0, 0.0}, gb = {0.0, 0.0};                 // (gm, gv) of dimensions 2 k2, 2 k2 + 1
+            const double* src = gp + (int64_t)sl * DT + 2 * k2;
+            const double* srm = gmp + (int64_t)sl * DT + 2 * k2;
+            for (int b0 = 0; b0 < bpp; b0 += 24) {
+                const int bl0 = pt * bpp + b0, bl1 = min(sc.ntiles, pt * bpp + min(bpp, b0 + 24));
+                const int ml0 = pt * bpm, ml1 = b0 == 0 ? min(T, ml0 + min(bpm, 4)) : ml0;
+                d2 v[24], vm[4];
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp)
-            if (pp < nparts) { a += *(const d2*)(gfin + (pp * npairs + tid) * 4); b += *(const d2*)(gfin + (pp * npairs + tid) * 4 + 2); }
-        const int rr = pass * 16 + ri;
-        const double m = post_l[2 * sl], v = post_l[2 * sl + 1];
-        double dmu, ds2;
-        acq_partials(su.sv.ap, m, v, dmu, ds2);
-        // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
-        su.grad[(int64_t)rr * d + 2 * k2] = dmu * a.x + (v > 0.0 ? ds2 * (-2.0 * b.x) : 0.0);
-        if (2 * k2 + 1 < d) su.grad[(int64_t)rr * d + 2 * k2 + 1] = dmu * a.y + (v > 0.0 ? ds2 * (-2.0 * b.y) : 0.0);
+                for (int j = 0; j < 24; ++j) ld_agent_x2_issue(src + (int64_t)max(0, min(bl0 + j, bl1 - 1)) * 16 * DT, v[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ld_agent_x2_issue(srm + (int64_t)max(0, min(ml0 + j, ml1 - 1)) * 16 * DT, vm[j]);
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                               "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]),
+                               "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]), "+v"(vm[0]), "+v"(vm[1]), "+v"(vm[2]), "+v"(vm[3])
+                             :
+                             : "memory");
+#pragma unroll
+                for (int j = 0; j < 24; ++j)
+                    if (bl0 + j < bl1) gb += v[j];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ml0 + j < ml1) ga += vm[j];
+            }
+            for (int b = pt * bpm + 4; b < min(T, (pt + 1) * bpm); ++b) {        // (more than four column blocks per part: T > 64)
+                d2 vmx;
+                ld_agent_x2_issue(srm + (int64_t)b * 16 * DT, vmx);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(vmx) : : "memory");
+                ga += vmx;
+            }
+            *(d2*)(gfin + (pt * npairs + pr) * 4) = ga;
+            *(d2*)(gfin + (pt * npairs + pr) * 4 + 2) = gb;
+            if (ft == 0) SM_MARK(sc, 1, 6);
+        }
+        __syncthreads();
+        SM_MARK(sc, 1, 10);
+        if (tid < npairs) {
+            const int ri2 = tid / dh, k22 = tid % dh, sl2 = 4 * (ri2 & 3) + (ri2 >> 2);
+            d2 a = {0.0, 0.0}, b = {0.0, 0.0};
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp)
+                if (pp < nparts) { a += *(const d2*)(gfin + (pp * npairs + tid) * 4); b += *(const d2*)(gfin + (pp * npairs + tid) * 4 + 2); }
+            const int rr = pass * 16 + ri2;
+            const double dmu = post_l[2 * sl2], ds2 = post_l[2 * sl2 + 1], v = post_l[32 + sl2];
+            // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
+            su.grad[(int64_t)rr * d + 2 * k22] = dmu * a.x + (v > 0.0 ? ds2 * (-2.0 * b.x) : 0.0);
+            if (2 * k22 + 1 < d) su.grad[(int64_t)rr * d + 2 * k22 + 1] = dmu * a.y + (v > 0.0 ? ds2 * (-2.0 * b.y) : 0.0);
+        }
+    } else {
+        // (more pairs than fetching threads: d > 48 with a full pass -- every thread of the workgroup takes pairs in turn, one record at a time)
+        __syncthreads();
+        for (int e = tid; e < npairs; e += SP_THREADS) {
+            const int ri2 = e / dh, k22 = e % dh, sl2 = 4 * (ri2 & 3) + (ri2 >> 2);
+            d2 a = {0.0, 0.0}, b = {0.0, 0.0};
+            for (int t0 = 0; t0 < sc.ntiles; t0 += 8) {          // eight records in flight, added in tile order
+                d2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ld_agent_x2_issue(gp + ((int64_t)min(t0 + j, sc.ntiles - 1) * 16 + sl2) * DT + 2 * k22, v[j]);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (t0 + j < sc.ntiles) b += v[j];
+            }
+            for (int t0 = 0; t0 < T; t0 += 8) {
+                d2 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ld_agent_x2_issue(gmp + ((int64_t)min(t0 + j, T - 1) * 16 + sl2) * DT + 2 * k22, v[j]);
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (t0 + j < T) a += v[j];
+            }
+            const int rr = pass * 16 + ri2;
+            const double dmu = post_l[2 * sl2], ds2 = post_l[2 * sl2 + 1], v = post_l[32 + sl2];
+            su.grad[(int64_t)rr * d + 2 * k22] = dmu * a.x + (v > 0.0 ? ds2 * (-2.0 * b.x) : 0.0);
+            if (2 * k22 + 1 < d) su.grad[(int64_t)rr * d + 2 * k22 + 1] = dmu * a.y + (v > 0.0 ? ds2 * (-2.0 * b.y) : 0.0);
+        }
     }
     SM_MARK(sc, 1, 11);
 }

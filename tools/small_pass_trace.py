@@ -15,7 +15,7 @@ Xs = np.asfortranarray(rng.random((d, R)))
 lib = _lib.load()
 names = {0: ["start", "tile known", "first rhs tile in LDS", "contraction done", "tile published (stores acked)", "counted in", "combined (last arriver)",
              "block record out", "pass counted", "posterior final", "arg-max", ""],
-         1: ["start", "tile known", "first rhs tile in LDS", "contraction done", "tile's gradient record out", "counted in", "", "", "",
+         1: ["start", "tile known", "first rhs tile in LDS", "contraction done", "tile's gradient record out", "counted in", "records fetched (last tile)", "posterior + value done (thread 0)", "",
              "last tile of the pass", "posterior final", "gradient out"]}
 for what in ("score_grad", "score"):
     for _ in range(20):
