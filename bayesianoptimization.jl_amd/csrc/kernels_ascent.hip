@@ -272,6 +272,32 @@ __global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R,
 // after pass and reads, two passes behind, how many start points were still active (a pinned word written by the last
 // workgroup of a pass).  Lock-step: five launches + a stream synchronisation per pass, 94-117 us at N = 3000 with 10 starts.
 // (one wave: lane k = coordinate k of start point r; ring_slot < 0: no pass bookkeeping -- the one-workgroup-per-start kernel)
+// slot order -> age order of the curvature pairs (see asc_step_one); NEWEST = slot of the pair made in this step (taken from registers)
+template <int NEWEST>
+__device__ __forceinline__ void asc_age_order_t(const double (&sv)[ASC_M], const double (&yv)[ASC_M], double s_new, double y_new,
+                                                double (&ps)[ASC_M], double (&py)[ASC_M]) {
+    ps[0] = s_new;
+    py[0] = y_new;
+#pragma unroll
+    for (int i = 1; i < ASC_M; ++i) {
+        ps[i] = sv[(NEWEST - i + ASC_M) % ASC_M];
+        py[i] = yv[(NEWEST - i + ASC_M) % ASC_M];
+    }
+}
+__device__ __forceinline__ void asc_age_order(int newest, const double (&sv)[ASC_M], const double (&yv)[ASC_M], double s_new, double y_new,
+                                              double (&ps)[ASC_M], double (&py)[ASC_M]) {
+    static_assert(ASC_M == 8, "eight arms");
+    switch (__builtin_amdgcn_readfirstlane(newest)) {     // (one start point per wave: uniform)
+        case 0: asc_age_order_t<0>(sv, yv, s_new, y_new, ps, py); break;
+        case 1: asc_age_order_t<1>(sv, yv, s_new, y_new, ps, py); break;
+        case 2: asc_age_order_t<2>(sv, yv, s_new, y_new, ps, py); break;
+        case 3: asc_age_order_t<3>(sv, yv, s_new, y_new, ps, py); break;
+        case 4: asc_age_order_t<4>(sv, yv, s_new, y_new, ps, py); break;
+        case 5: asc_age_order_t<5>(sv, yv, s_new, y_new, ps, py); break;
+        case 6: asc_age_order_t<6>(sv, yv, s_new, y_new, ps, py); break;
+        default: asc_age_order_t<7>(sv, yv, s_new, y_new, ps, py); break;
+    }
+}
 __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k, int d, int R, const double* __restrict__ lb,
                                              const double* __restrict__ ub, double ftol_rel, double xtol_abs, int ring_slot) {
     const bool on = k < d;
@@ -327,20 +353,13 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
                 // ---- the next direction (k_asc_direction at x = xn, g = gn; the newest pair is the one just written: taken
                 // from registers, the older ones were loaded up front by slot -- every lane reads only elements it wrote itself)
                 const int nh = it + 1 < ASC_M ? it + 1 : ASC_M, newest = slot;
-                auto pair_s = [&](int i) {   // i-th newest pair (i = 0: the one just made)
-                    const int sl = (newest - i + ASC_M) % ASC_M;
-                    double v = 0.0;
-#pragma unroll
-                    for (int t = 0; t < ASC_M; ++t) v = t == sl ? sv[t] : v;
-                    return i == 0 ? s_new : v;
-                };
-                auto pair_y = [&](int i) {
-                    const int sl = (newest - i + ASC_M) % ASC_M;
-                    double v = 0.0;
-#pragma unroll
-                    for (int t = 0; t < ASC_M; ++t) v = t == sl ? yv[t] : v;
-                    return i == 0 ? y_new : v;
-                };
+                // The pairs in AGE order (i = 0: the one just made, i = 1: the newest loaded one, ...).  The registers hold them by SLOT; the
+                // rotation is resolved by ONE wave-uniform switch on `newest` whose eight arms are register renames (28 moves) -- until
+                // round 5 every use selected its pair out of all eight slots (16 v_cndmask per pair and use: the step grew by 0.6 us per pair).
+                double ps_age[ASC_M], py_age[ASC_M];
+                asc_age_order(newest, sv, yv, s_new, y_new, ps_age, py_age);
+                auto pair_s = [&](int i) { return ps_age[i]; };
+                auto pair_y = [&](int i) { return py_age[i]; };
                 // (the free subspace of asc_direction_one: coordinates on a bound with the gradient pushing outward stay out)
                 const bool fr = on && !((xn <= lo && gn < 0.0) || (xn >= hi && gn > 0.0));
                 double q = fr ? gn : 0.0;
