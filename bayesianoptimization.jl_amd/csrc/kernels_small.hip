@@ -530,8 +530,7 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU
     small_contract<1, G, true>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
     SM_MARK(sc, 1, 3);
     // ---- the tile's share of the gradient sums: lane (q, p) of strip wc holds u's share for columns j_e = 128 cb + 32 wc + 2 p + e and the
-    // candidates r_g = 4 g + q; sum over e in the lane, over p by four DPP levels, over the eight waves in wave order through LDS
-    const bool first_seg = kc0 == cb && kh == 0;          // (the alpha-weighted sums of the block's observations: once per column block)
+    // candidates r_g = 4 g + q
     double fac[2][4];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
@@ -553,68 +552,73 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU
             }
         }
     }
-    double* const red2 = lbuf;                   // [8 waves][4 q][4 g][16]: one round = 8 dimensions x {gm, gv}  (the right-hand-side tiles are done with)
-    double* gvrec = su.gpart + (((int64_t)pass * sc.ntiles + tile) * 16) * DT;            // this tile's u-weighted sums [slot][DT]
-    double* gmrec = su.gmpart + (((int64_t)pass * T + cb) * 16) * DT;                   // the block's alpha-weighted sums (first segment's tile)
+    // z[c][slot] = (u's share, both contraction halves) x (kernel factor) for the tile's 128 columns -> LDS (slot layout); then
+    //   gv[slot][k] = sum_c z[c][slot] (x*_k - X_ck) / l_k^2
+    // by threads (slot, k, group of 32 columns) walking their columns, four groups added in group order -- 64 LDS reads and 32 FMAs per thread and
+    // round of 8 dimensions.  (Until this form every lane multiplied its own 2 x G values by d k*/dx and 24 sixteen-lane DPP sums per lane followed:
+    // 5 us per tile; lane sums are what a latency-bound tail should not be made of.)  The alpha-weighted sums of the block's first tile the same
+    // way from the factors themselves.
+    double* const zt = lbuf;                     // [128][16]  (the right-hand-side tiles are done with)
+    double* const fat = lbuf + 2048;             // [128][16]  factors x alpha, first tile of the block only
+    double* const redh = lbuf + 4096;            // [4][64][8] hand-over of the contraction halves, then [4 groups][16 slots][8][2] partial sums
+    if (kh == 1) {
+        double* dst = redh + (wc * 64 + lane) * 8;
 #pragma unroll
-    for (int kb = 0; kb < DT; kb += 8) {
-        if (kb >= d) break;
-        // the round's operands from LDS into registers first (the stores into red2 below would keep the compiler from hoisting them)
-        double xcv[2][8], xsv[4][8], alv[2];
+        for (int e = 0; e < 2; ++e) { *(d2*)(dst + 4 * e) = d2{acc[e][0], acc[e][1]}; *(d2*)(dst + 4 * e + 2) = d2{acc[e][2], acc[e][3]}; }
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const double* src = redh + (wc * 64 + lane) * 8;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int cl = wc * 32 + 2 * p + e;
-            alv[e] = al_l[cl];
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) xcv[e][k8] = (kb + k8 < DT && kb + k8 < d) ? xc_l[cl * d + kb + k8] : 0.0;
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) xsv[g][k8] = (g < G && kb + k8 < DT) ? xs_l[(4 * g + q) * DT + kb + k8] : 0.0;
-        d2 out[4][8];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) {
-                const int k = kb + k8;
-                double sm = 0.0, sv_ = 0.0;
-                if (g < G && k < DT && k < d) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const double dk = fac[e][g] * (xsv[g][k8] - xcv[e][k8]) * hp.il2[k];
-                        sv_ += dk * acc[e][g];
-                        if (first_seg) sm += dk * alv[e];
-                    }
-                    sv_ = row16_sum(sv_);
-                    if (kc0 == cb) sm = row16_sum(sm);
-                }
-                out[g][k8] = d2{sm, sv_};
+            const d2 r01 = *(const d2*)(src + 4 * e), r23 = *(const d2*)(src + 4 * e + 2);
+            *(d2*)(zt + cl * 16 + 4 * q) = d2{(acc[e][0] + r01.x) * fac[e][0], (acc[e][1] + r01.y) * fac[e][1]};
+            *(d2*)(zt + cl * 16 + 4 * q + 2) = d2{(acc[e][2] + r23.x) * fac[e][2], (acc[e][3] + r23.y) * fac[e][3]};
+            if (kc0 == cb) {
+                const double a_ = al_l[cl];
+                *(d2*)(fat + cl * 16 + 4 * q) = d2{fac[e][0] * a_, fac[e][1] * a_};
+                *(d2*)(fat + cl * 16 + 4 * q + 2) = d2{fac[e][2] * a_, fac[e][3] * a_};
             }
         }
-        if (kb > 0) __syncthreads();             // (the previous round's readers are done)
-        if (p == 0) {
+    }
+    __syncthreads();
+    double* gvrec = su.gpart + (((int64_t)pass * sc.ntiles + tile) * 16) * DT;            // this tile's u-weighted sums [slot][DT]
+    double* gmrec = su.gmpart + (((int64_t)pass * T + cb) * 16) * DT;                   // the block's alpha-weighted sums (first segment's tile)
+    {
+        const int slot = tid & 15, k8 = (tid >> 4) & 7, cg = tid >> 7, rs = small_slot_to_r(slot);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g >= G) break;
-#pragma unroll
-                for (int k8 = 0; k8 < 8; ++k8) *(d2*)(red2 + (((wave * 4 + q) * 4 + g) * 8 + k8) * 2) = out[g][k8];
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {                           // (slot, dimension pair): the eight waves in wave order
-            const int slot = tid >> 2, k8 = 2 * (tid & 3), qq = slot >> 2, gg = slot & 3;
-            d2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};       // (gm, gv) of dimensions kb + k8, kb + k8 + 1
-            if (gg < G) {
-#pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) {
-                    s0 += *(const d2*)(red2 + (((w8 * 4 + qq) * 4 + gg) * 8 + k8) * 2);
-                    s1 += *(const d2*)(red2 + (((w8 * 4 + qq) * 4 + gg) * 8 + k8 + 1) * 2);
+        for (int kb = 0; kb < DT; kb += 8) {
+            if (kb >= d) break;
+            const int k = kb + k8;
+            double sv_ = 0.0, sm = 0.0;
+            if (k < DT && k < d) {
+                const double xk = xs_l[rs * DT + k], w = hp.il2[k];
+                const double* zc = zt + (32 * cg) * 16 + slot;
+                const double* fc = fat + (32 * cg) * 16 + slot;
+                const double* xc = xc_l + (32 * cg) * d + k;
+#pragma unroll 8
+                for (int c = 0; c < 32; ++c) {
+                    const double t = (xk - xc[c * d]) * w;
+                    sv_ += zc[c * 16] * t;
+                    if (kc0 == cb) sm += fc[c * 16] * t;
                 }
             }
-            if (kb + k8 < DT) {
-                st_agent2(gvrec + slot * DT + kb + k8, s0.y, s1.y);
-                if (kc0 == cb) st_agent2(gmrec + slot * DT + kb + k8, s0.x, s1.x);
+            if (kb > 0) __syncthreads();         // (the previous round's readers are done; round 0: redh was last read before the barrier above)
+            *(d2*)(redh + ((cg * 16 + slot) * 8 + k8) * 2) = d2{sm, sv_};
+            __syncthreads();
+            if (tid < 64) {                       // (slot, dimension pair): the four column groups in group order
+                const int sl = tid >> 2, kk = 2 * (tid & 3);
+                d2 s0 = {0.0, 0.0}, s1 = {0.0, 0.0};       // (gm, gv) of dimensions kb + kk, kb + kk + 1
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    s0 += *(const d2*)(redh + ((g4 * 16 + sl) * 8 + kk) * 2);
+                    s1 += *(const d2*)(redh + ((g4 * 16 + sl) * 8 + kk + 1) * 2);
+                }
+                if (kb + kk < DT) {
+                    st_agent2(gvrec + sl * DT + kb + kk, s0.y, s1.y);
+                    if (kc0 == cb) st_agent2(gmrec + sl * DT + kb + kk, s0.x, s1.x);
+                }
             }
         }
     }
