@@ -126,8 +126,8 @@ static int small_ntiles(int T, int m) {
 // chunk kc + 1 writes the tile that chunk kc - 1 used, and every wave has left chunk kc - 1 when it passes chunk kc's barrier.
 // On return rt2 + ((kc1 - 1 - kc0) & 1) * 2048 holds the tile of chunk kc1 - 1.
 template <int UPPER, int G, bool PRE_FIRST, class SetupL, class SetupS, class Pre, class Fill>
-__device__ __forceinline__ void small_contract(const SmallCommon& sc, double* rt2, int cb, int kc0, int kc1, SetupL&& setup_load, SetupS&& setup_store, Pre&& pre, Fill&& fill,
-                                               double (&acc)[2][4]) {
+__device__ __forceinline__ bool small_contract(const SmallCommon& sc, unsigned gow, double* rt2, int cb, int kc0, int kc1, SetupL&& setup_load, SetupS&& setup_store, Pre&& pre,
+                                               Fill&& fill, double (&acc)[2][4]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 2, wc = wave & 3, q = lane >> 4, p = lane & 15;
     const int N = sc.N;
@@ -145,6 +145,10 @@ __device__ __forceinline__ void small_contract(const SmallCommon& sc, double* rt
     for (int s = 0; s < 16; ++s) w[s] = *(const d2*)(ap + (int64_t)(4 * s) * ld);
     SM_MARK(sc, UPPER, 1);
     setup_store(sregs);
+    // gow: the free-running ascent's "anybody still active?" word, requested as the kernel's FIRST load and looked at only here, with every
+    // input of the first chunk on its way (as the kernel's first statement the word's round trip stood in front of all of them; nothing up to
+    // here has a side effect outside the CU)
+    if (gow == 0u) return false;
     if (!PRE_FIRST) regs = pre(kc0);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -179,6 +183,7 @@ __device__ __forceinline__ void small_contract(const SmallCommon& sc, double* rt
             if (G > 3) { acc[0][3] = mfma444(a23.y, wv.x, acc[0][3]); acc[1][3] = mfma444(a23.y, wv.y, acc[1][3]); }
         }
     }
+    return true;
 }
 // Publication of the tile + the column block's combine.  Returns true in the LAST ARRIVER of the column block, with the combined sums of
 // pieces (tid, tid + 512) in sum[0..1]: piece e = c_local * 8 + sp  <->  out[cb * 128 + c_local][slots 2 sp, 2 sp + 1].
@@ -329,7 +334,7 @@ struct SmallLds {
     SmallLds<DT_> L_{sl_lbuf_, sl_xs_, sl_xc_, sl_al_, sl_small_, sl_shb_, &sl_flag_}
 
 template <int DT, int G>
-__device__ __forceinline__ void small_v_body(const SmallCommon& sc, const SmallV& sv, const KernelHyper& hp, int tile, const SmallLds<DT>& L) {
+__device__ __forceinline__ void small_v_body(const SmallCommon& sc, unsigned gow, const SmallV& sv, const KernelHyper& hp, int tile, const SmallLds<DT>& L) {
     double* const lbuf = L.lbuf;
     double* const rt2 = lbuf;             // 2 x [128][16] right-hand-side tiles
     double* const red = lbuf + 4096;      // [4][64][8] hand-over of the contraction halves, later the finishers' scratch
@@ -384,7 +389,7 @@ __device__ __forceinline__ void small_v_body(const SmallCommon& sc, const SmallV
     };
     d2 sum[2];
     double acc[2][4];
-    small_contract<0, G, true>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
+    if (!small_contract<0, G, true>(sc, gow, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc)) return;
     // mu - beta = alpha' k*: the tile that holds the DIAGONAL chunk of its column block (the last chunk of the block's last segment) adds that
     // chunk's share in a fixed order from the K*' tile still in LDS, and publishes the record BEFORE it counts itself in
     if (kc1 - 1 == cb) {
@@ -463,9 +468,9 @@ __device__ __forceinline__ void small_v_body(const SmallCommon& sc, const SmallV
 }
 template <int DT, int G>
 __global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV sv, KernelHyper hp) {
-    if (sc.go && *sc.go == 0u) return;
+    const unsigned gow = sc.go ? *sc.go : 1u;
     SMALL_LDS_DECL(DT, L);
-    small_v_body<DT, G>(sc, sv, hp, blockIdx.x, L);
+    small_v_body<DT, G>(sc, gow, sv, hp, blockIdx.x, L);
 }
 
 // ---- U pass ---------------------------------------------------------------------------------------------------------------------------
@@ -480,7 +485,7 @@ __global__ __launch_bounds__(SP_THREADS) void k_small_v(SmallCommon sc, SmallV s
 // from the V pass's own K*' record (no second exponential).
 struct SmallVPair { d2 a, b; };
 template <int DT, int G>
-__device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU& su, const KernelHyper& hp, int tile, const SmallLds<DT>& L) {
+__device__ __forceinline__ void small_u_body(const SmallCommon& sc, unsigned gow, const SmallU& su, const KernelHyper& hp, int tile, const SmallLds<DT>& L) {
     double* const lbuf = L.lbuf;
     double* const rt2 = lbuf;
     double* const xs_l = L.xs_l;
@@ -527,7 +532,7 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU
         *(d2*)(rt_ + 4 * tid + 2) = v.b;
     };
     double acc[2][4];
-    small_contract<1, G, true>(sc, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc);
+    if (!small_contract<1, G, true>(sc, gow, rt2, cb, kc0, kc1, setup_load, setup_store, pre, fill, acc)) return;
     SM_MARK(sc, 1, 3);
     // ---- the tile's share of the gradient sums: lane (q, p) of strip wc holds u's share for columns j_e = 128 cb + 32 wc + 2 p + e and the
     // candidates r_g = 4 g + q
@@ -767,9 +772,9 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, const SmallU
 }
 template <int DT, int G>
 __global__ __launch_bounds__(SP_THREADS) void k_small_u(SmallCommon sc, SmallU su, KernelHyper hp) {
-    if (sc.go && *sc.go == 0u) return;
+    const unsigned gow = sc.go ? *sc.go : 1u;
     SMALL_LDS_DECL(DT, L);
-    small_u_body<DT, G>(sc, su, hp, blockIdx.x, L);
+    small_u_body<DT, G>(sc, gow, su, hp, blockIdx.x, L);
 }
 
 }  // namespace bohip
