@@ -140,9 +140,18 @@ __device__ __forceinline__ bool small_contract(const SmallCommon& sc, unsigned g
     decltype(pre(kc0)) regs;
     if (PRE_FIRST) regs = pre(kc0);
     auto sregs = setup_load();
-    d2 w[16];
+    // DEPTH loads of 16 bytes per lane in flight (8 = half a chunk ahead, 64 KB per CU).  A whole chunk ahead (16: 128 KB per CU, 32 MB on the
+    // chip) is past what the memory side takes at full rate -- tools/ubench_readbw shows the same for a bare read of 400 MB (32 KB per CU in
+    // flight: 6.4 TB/s, 128 KB: 4.7) -- and costs 32 registers: value + gradient of ten candidates, 16 / 12 / 8 / 6 / 4 in flight:
+    // N = 4500 76.6 / 75.9 / 75.3 / 75.5 / 74.4 us, N = 6000 99.6 / 98.5 / 97.0 / 102.5 / 95.8, N = 10^4 226.5 / 222.9 / 221.9 / 237 / 229,
+    // N = 14000 397 / 390 / 386 / 426 / 408 (profiles/r05_small_pass_prefetch_depth.txt); N = 3000 (W in the Infinity Cache): within 1 %.
+#ifndef SMALL_DEPTH
+#define SMALL_DEPTH 8
+#endif
+    constexpr int DEPTH = SMALL_DEPTH;
+    d2 w[DEPTH];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) w[s] = *(const d2*)(ap + (int64_t)(4 * s) * ld);
+    for (int s = 0; s < DEPTH; ++s) w[s] = *(const d2*)(ap + (int64_t)(4 * s) * ld);
     SM_MARK(sc, UPPER, 1);
     setup_store(sregs);
     // gow: the free-running ascent's "anybody still active?" word, requested as the kernel's FIRST load and looked at only here, with every
@@ -168,8 +177,9 @@ __device__ __forceinline__ bool small_contract(const SmallCommon& sc, unsigned g
             const d2 a01 = *(const d2*)(ra + s * 64);
             d2 a23 = {0.0, 0.0};
             if (G > 2) a23 = *(const d2*)(ra + s * 64 + 2);
-            d2 wv = w[s];
-            if (more) w[s] = *(const d2*)(apn + (int64_t)(4 * s) * ld);
+            d2 wv = w[s % DEPTH];
+            if (s + DEPTH < 16) w[s % DEPTH] = *(const d2*)(apn - (int64_t)128 * ld + (int64_t)(4 * (s + DEPTH)) * ld);
+            else if (more) w[s % DEPTH] = *(const d2*)(apn + (int64_t)(4 * (s + DEPTH - 16)) * ld);
             if (edge) {
                 const int k = kc * 128 + 64 * kh + 4 * s + q, c = c0 + 2 * p;
                 const bool okx = k < N && (UPPER ? k >= c : k <= c), oky = k < N && (UPPER ? k >= c + 1 : k <= c + 1);
