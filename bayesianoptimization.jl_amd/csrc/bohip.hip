@@ -340,6 +340,7 @@ static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue
 static int g_chol_exec_pairs = -1; // early sums and bulk updates are claimed two records (= both halves of a tile) at a time (BOHIP_CHOL_EXEC_PAIRS=1; 0: one); p >= 2: the bulk 2 p
                                     // records (p tiles) per claim.  -1: 1, and 2 from 72 row tiles on (N = 10^4 14.05 -> 13.8 ms, N = 12000 23.1 -> 22.6; N = 8000 the same, N = 6000 4.0 -> 4.25)
 static int g_chol_exec_wgs = -1;  // executor workgroups (BOHIP_CHOL_EXEC_WGS); -1: by size -- ONE per free CU up to 32 row tiles, two from 45 on (see cholesky_exec)
+static int g_append_alpha_inc = 1;   // incremental alpha on append (BOHIP_APPEND_ALPHA_INC=0: recomputed as W'(W r))
 static int g_fuse_finish = 1;  // sigma^2 + acquisition + arg-max in k_trigemm_sq's epilogue (BOHIP_FUSE_FINISH=0: k_score + k_argmax_final)
 static int64_t g_chunk_rows_forced = 0;   // BOHIP_CHUNK_ROWS: candidates per K*' chunk (tools: chunk-size sweeps), 0 = the rule in chunk_rows
 static int g_halve_lo = -1, g_halve_hi = -1;   // BOHIP_TRIGEMM_HALVE (see trigemm_pieces)
@@ -404,6 +405,7 @@ static int one_time_kernel_setup() {
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= a) { g_halve_lo = a; g_halve_hi = b; }
     }
     if (const char* e = getenv("BOHIP_FUSE_FINISH")) g_fuse_finish = atoi(e);
+    if (const char* e = getenv("BOHIP_APPEND_ALPHA_INC")) g_append_alpha_inc = atoi(e);
     if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
     if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
@@ -1661,7 +1663,9 @@ static int launch_rows_trimv(bohip_gp* g, const double* W, int64_t N0, const dou
 }
 
 // ---- A2': incremental extension by p new observations (already in dX/dy and the host mirror) ----------
-static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
+// defer_info != nullptr: the pivot word is copied there (pinned) behind the kernels and looked at by the caller after ITS synchronisation
+// (one host round trip less per append)
+static int append_incremental(bohip_gp* g, int64_t N0, int64_t p, int* defer_info = nullptr) {
     CHK(one_time_kernel_setup());
     const int64_t N1 = N0 + p, Npad1 = round_up(N1 + 1, TILE), ld = g->ld;
     const KernelHyper hp = make_hyper(g);
@@ -1689,9 +1693,16 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p) {
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "alpha");
-    CHK(compute_alpha(g));
+    if (g_append_alpha_inc) {      // alpha_new = [alpha_old + W21' u2; W22' u2] (kernels_linalg.hip k_alpha_append_*); BOHIP_APPEND_ALPHA_INC=0: the full product
+        hipLaunchKernelGGL(k_alpha_append_u, dim3(1), dim3(1024), 0, g->stream, g->dW, ld, N0, (int)p, g->dy, g->beta, g->dr, g->dt);
+        hipLaunchKernelGGL(k_alpha_append_apply, dim3((unsigned)((N1 + 255) / 256)), dim3(256), 0, g->stream, g->dW, ld, N0, (int)p, g->dt, g->dalpha);
+        HIPCHK(hipGetLastError());
+    } else {
+        CHK(compute_alpha(g));
+    }
     t_end(g);
-    CHK(check_info(g));
+    if (defer_info) HIPCHK(hipMemcpyAsync(defer_info, g->dinfo, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    else CHK(check_info(g));
     g->n_factored = N1;
     g->appends++;
     return 0;
@@ -2423,17 +2434,45 @@ int bohip_gp_append(bohip_gp* g, const double* X, const double* y, int64_t p) {
                 return arc;
             }
         } else {
-            // the mirrors and n advance only after the device holds the new rows: a failed copy leaves the handle unchanged
-            HIPCHK(hipMemcpyAsync(g->dX + n_old * g->d, X, (size_t)p * g->d * 8, hipMemcpyHostToDevice, g->stream));
-            HIPCHK(hipMemcpyAsync(g->dy + n_old, y, (size_t)p * 8, hipMemcpyHostToDevice, g->stream));
-            HIPCHK(hipStreamSynchronize(g->stream));  // caller's buffers are only valid during the call
+            // A few rows (what a BO iteration appends) go through the pinned block: the copies are then plain DMA commands in front of the
+            // update's kernels, the pivot word comes back the same way, and the call synchronises ONCE (three times before: behind the
+            // pageable copies, for the pivot word, at the end -- ~60 us of a 0.19 ms append).  Otherwise: the mirrors and n advance only
+            // after the device holds the new rows, a failed copy leaves the handle unchanged.
+            const bool staged = g->hpin && p <= SMALL_R && (size_t)p * g->d <= (size_t)SMALL_R * DMAX;
+            int* pinfo = nullptr;
+            if (staged) {
+                double* sx = g->hpin + 3 * SMALL_R + 2;   // (the gradient area and the score area of the result block: idle during an append)
+                double* sy = g->hpin;
+                std::memcpy(sx, X, (size_t)p * g->d * 8);
+                std::memcpy(sy, y, (size_t)p * 8);
+                HIPCHK(hipMemcpyAsync(g->dX + n_old * g->d, sx, (size_t)p * g->d * 8, hipMemcpyHostToDevice, g->stream));
+                HIPCHK(hipMemcpyAsync(g->dy + n_old, sy, (size_t)p * 8, hipMemcpyHostToDevice, g->stream));
+                pinfo = reinterpret_cast<int*>(g->hpin + 3 * SMALL_R);
+                *pinfo = 0;
+            } else {
+                HIPCHK(hipMemcpyAsync(g->dX + n_old * g->d, X, (size_t)p * g->d * 8, hipMemcpyHostToDevice, g->stream));
+                HIPCHK(hipMemcpyAsync(g->dy + n_old, y, (size_t)p * 8, hipMemcpyHostToDevice, g->stream));
+                HIPCHK(hipStreamSynchronize(g->stream));  // caller's buffers are only valid during the call
+            }
             g->hX.insert(g->hX.end(), X, X + p * g->d);
             g->hy.insert(g->hy.end(), y, y + p);
             g->n = n_new;
             if (!g->stale && g->n_factored == n_old && n_old > 0 && p <= APPEND_PMAX) {
-                rc = append_incremental(g, n_old, p);
+                rc = append_incremental(g, n_old, p, pinfo);
                 if (rc != 0) g->stale = true;
                 done = true;
+                if (rc == 0 && pinfo) {
+                    const hipError_t e = hipStreamSynchronize(g->stream);
+                    if (e != hipSuccess) { g->stale = true; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
+                    t_collect(g);
+                    if (*pinfo != 0) {
+                        g->pivot = *pinfo;
+                        g->stale = true;
+                        return fail(BOHIP_E_NOTPD, "kernel matrix not positive definite at pivot " + std::to_string(*pinfo));
+                    }
+                    g->pivot = 0;
+                    return 0;
+                }
             }
         }
     }

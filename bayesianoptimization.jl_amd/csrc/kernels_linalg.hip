@@ -1252,6 +1252,63 @@ __global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, doubl
     }
 }
 
+// alpha after an append, incrementally.  With W_new = [W11 0; W21 W22] and the residual r = y - beta (old entries unchanged):
+//     u = W_new r = [u_old; u2],   u2 = W21 r1 + W22 r2            (u_old = W11 r1 is what compute_alpha left in dt)
+//     alpha_new = W_new' u = [alpha_old + W21' u2; W22' u2]
+// O(N p) instead of the two passes over W that the full product takes (N = 3000: 36 of an append's 107 us, N = 10^4: 175 of 450).
+// Fixed summation orders (one workgroup for u2: thread-strided partial sums, waves by butterfly, waves in order; alpha: r ascending).
+// k_alpha_append_u: r2 -> dr, u2 -> dt.   k_alpha_append_apply: alpha (and its copy in W's padding row N1).
+__global__ __launch_bounds__(1024) void k_alpha_append_u(const double* __restrict__ W, int64_t ld, int64_t N0, int p,
+                                                         const double* __restrict__ y, double beta, double* __restrict__ r,
+                                                         double* __restrict__ t) {
+    __shared__ double red[16][4];
+    __shared__ double r2[APPEND_PMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < p) { const double v = y[N0 + tid] - beta; r2[tid] = v; r[N0 + tid] = v; }
+    __syncthreads();
+    for (int r0 = 0; r0 < p; r0 += 4) {
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int64_t c = tid; c < N0; c += 1024) {
+            const double rc = r[c];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (r0 + i < p) a[i] += W[(N0 + r0 + i) * ld + c] * rc;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = a[i];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) red[wave][i] = v;
+        }
+        __syncthreads();
+        if (tid < 4 && r0 + tid < p) {
+            const int rr = r0 + tid;
+            double v = 0.0;
+            for (int w = 0; w < 16; ++w) v += red[w][tid];
+            for (int s2 = 0; s2 <= rr; ++s2) v += W[(N0 + rr) * ld + N0 + s2] * r2[s2];
+            t[N0 + rr] = v;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_alpha_append_apply(double* __restrict__ W, int64_t ld, int64_t N0, int p,
+                                                            const double* __restrict__ t, double* __restrict__ alpha) {
+    const int64_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N0 + p) return;
+    double a;
+    if (c < N0) {
+        a = alpha[c];
+        for (int rr = 0; rr < p; ++rr) a += W[(N0 + rr) * ld + c] * t[N0 + rr];
+    } else {
+        const int s2 = (int)(c - N0);
+        a = 0.0;
+        for (int rr = s2; rr < p; ++rr) a += W[(N0 + rr) * ld + N0 + s2] * t[N0 + rr];
+    }
+    alpha[c] = a;
+    W[(N0 + p) * ld + c] = a;     // alpha' in the first padding row of W (compute_alpha's copy)
+}
+
 // ---- small-batch posterior (chunks of SMALL_R, up to ~100 candidates): the default use of the reference (10 L-BFGS
 // restarts) scores a handful of candidates per call.  A 128 x 64 MFMA tile would be almost empty and its single job per
 // row tile latency-bound by the longest K loop; instead V' = K*' W' is computed row-wise like the incremental append

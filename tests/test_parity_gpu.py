@@ -269,6 +269,32 @@ def test_incremental_append_is_used_and_matches_refit(bohip, orc):
     assert bi_i == bi_f
 
 
+def test_alpha_after_a_long_run_of_appends(bohip, orc):
+    """A2' / A3: since round 5 an append updates alpha incrementally (alpha_new = [alpha_old + W21' u2; W22' u2], O(N p)) instead of
+    recomputing W'(W r).  600 observations appended one by one, then in blocks of 3 and 32, to a model of 300 -- what a BO loop does
+    between two hyper-parameter updates -- without a refit: alpha, the factor and the posterior still match the oracle's from-scratch
+    fit, and a full refit of the same handle moves alpha by rounding only."""
+    X, y, Xs = synth(1100, 5, 80, seed=77)
+    ll = np.linspace(-0.7, -0.3, 5)
+    m = bohip.ElasticGPE(5, kernel=bohip.SEArd(ll, 0.2), logNoise=-1.8, mean=bohip.MeanConst(0.1), capacity=1200)
+    m.append_(X[:300].T, y[:300])
+    refits0 = m.info(2)
+    n = 300
+    for p_ in [1] * 600 + [3] * 24 + [32] * 4:
+        m.append_(X[n:n + p_].T, y[n:n + p_]); n += p_
+    assert n == 1100 and m.info(2) == refits0
+    L, alpha = orc.fit(X, y, ll, 0.2, -1.8, 0.1)
+    np.testing.assert_allclose(m.factor(), L, rtol=1e-8, atol=1e-11)
+    a_inc = m.alpha().copy()
+    np.testing.assert_allclose(a_inc, alpha, rtol=1e-7, atol=1e-10 * np.abs(alpha).max())
+    mu_o, var_o = orc.predict(X, ll, 0.2, 0.1, L, alpha, Xs)
+    mu, var = m.predict_f(Xs.T)
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-6, atol=mu_floor(alpha, math.exp(0.4)))
+    assert np.all(np.abs(var - var_o) <= var_tol(var_o, 1100, math.exp(0.4)))
+    m.fit_()                                                  # the same data factored from scratch on the device
+    np.testing.assert_allclose(a_inc, m.alpha(), rtol=1e-8, atol=1e-11 * np.abs(alpha).max())
+
+
 @pytest.mark.parametrize("kern,N,d,R", [("SEArd", 200, 3, 40), ("SEArd", 1000, 8, 300), ("Mat52Ard", 300, 6, 130), ("SEIso", 130, 2, 5)])
 def test_score_grad_vs_oracle(bohip, orc, kern, N, d, R):
     """A8: analytic d(score)/dx through the reference's formulas, against the oracle's analytic gradient."""
