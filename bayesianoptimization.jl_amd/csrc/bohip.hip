@@ -131,6 +131,7 @@ struct bohip_gp {
     // pinned, device-visible host block the kernels of a small batch (R <= SMALL_R) write their results into: the
     // 2-3 device-to-host copies of a call cost more than its kernels (each ~8 us of API + DMA set-up)
     double* hpin = nullptr;      // [score 32 | mu 32 | var 32 | best 2 | grad 32 DMAX]
+    double* dschur = nullptr;    // [APPEND_PMAX][APPEND_PMAX] Schur complement of an append of >= 3 rows (k_schur_dots)
     // lock-step L-BFGS ascent of acquire_max (kernels_ascent.hip)
     AscentState asc{};
     double* asc_block = nullptr;   // one allocation behind all double arrays of asc
@@ -1683,7 +1684,13 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p, int* defer_inf
     HIPCHK(hipMemcpy2DAsync(g->dL + N0 * ld, ld * 8, g->dApp, ld * 8, N0 * 8, p, hipMemcpyDeviceToDevice, g->stream));
     t_end(g);
     t_begin(g, "append_schur_chol");
-    hipLaunchKernelGGL(k_schur_chol, dim3(1), dim3(256), 0, g->stream, g->dL, g->dW, g->dWT, ld, N0, (int)p, g->dinfo);
+    const double* schur_in = nullptr;
+    if (p >= 3) {      // the Schur complement's inner products, one workgroup each (same bits as k_schur_chol's own loop, which p <= 2 keeps: one launch less)
+        if (!g->dschur) HIPCHK(hipMalloc(&g->dschur, (size_t)APPEND_PMAX * APPEND_PMAX * 8));
+        hipLaunchKernelGGL(k_schur_dots, dim3((unsigned)(p * (p + 1) / 2)), dim3(256), 0, g->stream, g->dL, ld, N0, (int)p, g->dschur);
+        schur_in = g->dschur;
+    }
+    hipLaunchKernelGGL(k_schur_chol, dim3(1), dim3(256), 0, g->stream, g->dL, g->dW, g->dWT, ld, N0, (int)p, g->dinfo, schur_in);
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "append_W21");
@@ -1694,7 +1701,7 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p, int* defer_inf
     t_end(g);
     t_begin(g, "alpha");
     if (g_append_alpha_inc) {      // alpha_new = [alpha_old + W21' u2; W22' u2] (kernels_linalg.hip k_alpha_append_*); BOHIP_APPEND_ALPHA_INC=0: the full product
-        hipLaunchKernelGGL(k_alpha_append_u, dim3(1), dim3(1024), 0, g->stream, g->dW, ld, N0, (int)p, g->dy, g->beta, g->dr, g->dt);
+        hipLaunchKernelGGL(k_alpha_append_u, dim3((unsigned)p), dim3(1024), 0, g->stream, g->dW, ld, N0, (int)p, g->dy, g->beta, g->dr, g->dt);
         hipLaunchKernelGGL(k_alpha_append_apply, dim3((unsigned)((N1 + 255) / 256)), dim3(256), 0, g->stream, g->dW, ld, N0, (int)p, g->dt, g->dalpha);
         HIPCHK(hipGetLastError());
     } else {
@@ -2369,6 +2376,7 @@ void bohip_gp_destroy(bohip_gp* g) {
     if (g->dsm) hipFree(g->dsm);
     if (g->dsm_cnt) hipFree(g->dsm_cnt);
     if (g->hpin) hipHostFree(g->hpin);
+    if (g->dschur) hipFree(g->dschur);
     if (g->asc_block) hipFree(g->asc_block);
     if (g->asc_ints) hipFree(g->asc_ints);
     if (g->asc_hints) hipHostFree(g->asc_hints);

@@ -1185,13 +1185,41 @@ __global__ __launch_bounds__(TRIMV_THREADS) void k_trimv_stream(const double* __
 
 // One workgroup: S = K22 - L21 L21' (p x p), L22 = chol(S), W22 = L22^-1.
 // K22 sits in L[N0+r][N0+s]; L21 in L[N0+r][0..N0).  Results overwrite L22 in place and go to W22.
+// The p (p + 1) / 2 inner products of the Schur complement, ONE WORKGROUP EACH (k_schur_chol's own loop takes them one after the other,
+// a block reduction and ~2.7 us apiece: 44 us at p = 5, 375 us at p = 16 -- the README's `repetitions = 5` appends five rows per
+// iteration).  Same threads, same strides, same reduction tree as there: the same bits.  Sout[r][s], row stride APPEND_PMAX.
+__global__ __launch_bounds__(256) void k_schur_dots(const double* __restrict__ L, int64_t ld, int64_t N0, int p, double* __restrict__ Sout) {
+    __shared__ double red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = blockIdx.x;
+    int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;
+    while (r * (r + 1) / 2 > e) --r;
+    const int sidx = e - r * (r + 1) / 2;
+    const double* a = L + (N0 + r) * ld;
+    const double* b = L + (N0 + sidx) * ld;
+    double acc = 0.0;
+    for (int64_t k = tid; k < N0; k += 256) acc += a[k] * b[k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) Sout[r * APPEND_PMAX + sidx] = a[N0 + sidx] - ((red[0] + red[1]) + (red[2] + red[3]));
+}
+// Sin != nullptr: the Schur complement comes from k_schur_dots.
 __global__ __launch_bounds__(256) void k_schur_chol(double* __restrict__ L, double* __restrict__ W, double* __restrict__ WT,
-                                                    int64_t ld, int64_t N0, int p, int* __restrict__ info) {
+                                                    int64_t ld, int64_t N0, int p, int* __restrict__ info, const double* __restrict__ Sin) {
     __shared__ double S[APPEND_PMAX][APPEND_PMAX + 1];
     __shared__ double Winv[APPEND_PMAX][APPEND_PMAX + 1];
     __shared__ double red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = 0; e < p * (p + 1) / 2; ++e) {  // (r, s), s <= r; every thread strides the dot product
+    if (Sin) {
+        for (int e = tid; e < p * p; e += 256) {
+            const int r = e / p, c = e % p;
+            if (c <= r) S[r][c] = Sin[r * APPEND_PMAX + c];
+        }
+        __syncthreads();
+    }
+    for (int e = 0; e < (Sin ? 0 : p * (p + 1) / 2); ++e) {  // (r, s), s <= r; every thread strides the dot product
         int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
         while ((r + 1) * (r + 2) / 2 <= e) ++r;
         while (r * (r + 1) / 2 > e) --r;
@@ -1206,26 +1234,33 @@ __global__ __launch_bounds__(256) void k_schur_chol(double* __restrict__ L, doub
         if (tid == 0) S[r][sidx] = a[N0 + sidx] - ((red[0] + red[1]) + (red[2] + red[3]));
         __syncthreads();
     }
-    if (tid == 0) {  // p <= 32: sequential Cholesky + inverse is a few microseconds
-        for (int j = 0; j < p; ++j) {
+    // Cholesky of the p x p block, column by column: the diagonal on thread 0, the column's entries one thread per row; then the inverse, one
+    // thread per column.  Every entry is computed by the expression, in the order, the one-thread version used (same bits) -- that one took
+    // p^3 / 3 dependent LDS round trips (89 us at p = 16), this takes ~p^2.
+    for (int j = 0; j < p; ++j) {
+        if (tid == 0) {
             double ajj = S[j][j];
             for (int k = 0; k < j; ++k) ajj -= S[j][k] * S[j][k];
             if (!(ajj > 0.0)) { atomicCAS(info, 0, (int)(N0 + j + 1)); ajj = 1.0; }
-            const double dd = sqrt(ajj);
-            S[j][j] = dd;
-            for (int i = j + 1; i < p; ++i) {
-                double v = S[i][j];
-                for (int k = 0; k < j; ++k) v -= S[i][k] * S[j][k];
-                S[i][j] = v / dd;
-            }
+            S[j][j] = sqrt(ajj);
         }
-        for (int c = 0; c < p; ++c) {
-            Winv[c][c] = 1.0 / S[c][c];
-            for (int i = c + 1; i < p; ++i) {
-                double v = 0.0;
-                for (int k = c; k < i; ++k) v += S[i][k] * Winv[k][c];
-                Winv[i][c] = -v / S[i][i];
-            }
+        __syncthreads();
+        if (tid > j && tid < p) {
+            const int i = tid;
+            const double dd = S[j][j];
+            double v = S[i][j];
+            for (int k = 0; k < j; ++k) v -= S[i][k] * S[j][k];
+            S[i][j] = v / dd;
+        }
+        __syncthreads();
+    }
+    if (tid < p) {
+        const int c = tid;
+        Winv[c][c] = 1.0 / S[c][c];
+        for (int i = c + 1; i < p; ++i) {
+            double v = 0.0;
+            for (int k = c; k < i; ++k) v += S[i][k] * Winv[k][c];
+            Winv[i][c] = -v / S[i][i];
         }
     }
     __syncthreads();
@@ -1240,13 +1275,16 @@ __global__ __launch_bounds__(256) void k_schur_chol(double* __restrict__ L, doub
 // W21[r][c] = -sum_{s<=r} W22[r][s] * T[s][c]   with T = L21 W11 (rows of T at Tm, row stride ldt); W21' goes to W' too.
 __global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, double* __restrict__ WT, int64_t ld, int64_t N0, int p,
                                                    const double* __restrict__ Tm, int64_t ldt) {
+    __shared__ double w22[APPEND_PMAX * APPEND_PMAX];    // (read p (p + 1) / 2 times by every thread: from LDS, not through the vector cache)
+    for (int e = threadIdx.x; e < p * p; e += 256) w22[e] = W[(N0 + e / p) * ld + N0 + e % p];
+    __syncthreads();
     const int64_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N0) return;
     double T[APPEND_PMAX];
     for (int s = 0; s < p; ++s) T[s] = Tm[(int64_t)s * ldt + c];
     for (int r = 0; r < p; ++r) {
         double v = 0.0;
-        for (int s = 0; s <= r; ++s) v += W[(N0 + r) * ld + N0 + s] * T[s];
+        for (int s = 0; s <= r; ++s) v += w22[r * p + s] * T[s];
         W[(N0 + r) * ld + c] = -v;
         WT[c * ld + N0 + r] = -v;
     }
@@ -1256,40 +1294,26 @@ __global__ __launch_bounds__(256) void k_apply_w22(double* __restrict__ W, doubl
 //     u = W_new r = [u_old; u2],   u2 = W21 r1 + W22 r2            (u_old = W11 r1 is what compute_alpha left in dt)
 //     alpha_new = W_new' u = [alpha_old + W21' u2; W22' u2]
 // O(N p) instead of the two passes over W that the full product takes (N = 3000: 36 of an append's 107 us, N = 10^4: 175 of 450).
-// Fixed summation orders (one workgroup for u2: thread-strided partial sums, waves by butterfly, waves in order; alpha: r ascending).
+// Fixed summation orders (u2: one workgroup per new row, thread-strided partial sums, waves by butterfly, waves in order; alpha: r ascending).
 // k_alpha_append_u: r2 -> dr, u2 -> dt.   k_alpha_append_apply: alpha (and its copy in W's padding row N1).
 __global__ __launch_bounds__(1024) void k_alpha_append_u(const double* __restrict__ W, int64_t ld, int64_t N0, int p,
                                                          const double* __restrict__ y, double beta, double* __restrict__ r,
                                                          double* __restrict__ t) {
-    __shared__ double red[16][4];
-    __shared__ double r2[APPEND_PMAX];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < p) { const double v = y[N0 + tid] - beta; r2[tid] = v; r[N0 + tid] = v; }
+    // workgroup rr: u2[rr] (one new row each: p rows in parallel)
+    __shared__ double red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, rr = blockIdx.x;
+    double a = 0.0;
+    for (int64_t c = tid; c < N0; c += 1024) a += W[(N0 + rr) * ld + c] * r[c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off);
+    if (lane == 0) red[wave] = a;
     __syncthreads();
-    for (int r0 = 0; r0 < p; r0 += 4) {
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int64_t c = tid; c < N0; c += 1024) {
-            const double rc = r[c];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (r0 + i < p) a[i] += W[(N0 + r0 + i) * ld + c] * rc;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double v = a[i];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0) red[wave][i] = v;
-        }
-        __syncthreads();
-        if (tid < 4 && r0 + tid < p) {
-            const int rr = r0 + tid;
-            double v = 0.0;
-            for (int w = 0; w < 16; ++w) v += red[w][tid];
-            for (int s2 = 0; s2 <= rr; ++s2) v += W[(N0 + rr) * ld + N0 + s2] * r2[s2];
-            t[N0 + rr] = v;
-        }
-        __syncthreads();
+    if (tid == 0) {
+        double v = 0.0;
+        for (int w = 0; w < 16; ++w) v += red[w];
+        for (int s2 = 0; s2 <= rr; ++s2) v += W[(N0 + rr) * ld + N0 + s2] * (y[N0 + s2] - beta);
+        t[N0 + rr] = v;
+        r[N0 + rr] = y[N0 + rr] - beta;      // (nobody reads the new residuals in this kernel: the old ones end at N0)
     }
 }
 __global__ __launch_bounds__(256) void k_alpha_append_apply(double* __restrict__ W, int64_t ld, int64_t N0, int p,
