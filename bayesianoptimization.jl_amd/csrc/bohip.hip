@@ -436,8 +436,15 @@ static int compute_alpha(bohip_gp* g) {
 
 static int check_info(bohip_gp* g) {
     int info = 0;
-    HIPCHK(hipMemcpyAsync(&info, g->dinfo, sizeof(int), hipMemcpyDeviceToHost, g->stream));
-    HIPCHK(hipStreamSynchronize(g->stream));
+    if (g->hpin) {     // through the pinned block: a plain DMA command (a pageable destination is staged by the runtime)
+        int* pw = reinterpret_cast<int*>(g->hpin + 3 * SMALL_R) + 1;
+        HIPCHK(hipMemcpyAsync(pw, g->dinfo, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        info = *pw;
+    } else {
+        HIPCHK(hipMemcpyAsync(&info, g->dinfo, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+    }
     if (info != 0) {
         g->pivot = info;
         g->stale = true;
@@ -1483,9 +1490,17 @@ static int refit_once(bohip_gp* g, double jitter) {
         t_begin(g, "alpha");
         CHK(compute_alpha(g));
         t_end(g);
-        HIPCHK(hipStreamSynchronize(g->stream));
+        // the abort word and the pivot word come back through the pinned block behind the kernels: ONE host round trip per refit (three before:
+        // this synchronisation, a blocking copy of the abort word, check_info's copy + synchronisation -- ~25 us of a 1.5 ms refit)
         unsigned aborted = 0;
-        HIPCHK(hipMemcpy(&aborted, g->dchol_flags + chol_abort_word(T), sizeof(unsigned), hipMemcpyDeviceToHost));
+        int* const pwords = g->hpin ? reinterpret_cast<int*>(g->hpin + 3 * SMALL_R) : nullptr;
+        if (pwords) {
+            HIPCHK(hipMemcpyAsync(pwords, g->dchol_flags + chol_abort_word(T), sizeof(unsigned), hipMemcpyDeviceToHost, g->stream));
+            HIPCHK(hipMemcpyAsync(pwords + 1, g->dinfo, sizeof(int), hipMemcpyDeviceToHost, g->stream));
+        }
+        HIPCHK(hipStreamSynchronize(g->stream));
+        if (pwords) aborted = (unsigned)pwords[0];
+        else HIPCHK(hipMemcpy(&aborted, g->dchol_flags + chol_abort_word(T), sizeof(unsigned), hipMemcpyDeviceToHost));
         df_file.release();
         df_lock.unlock();
         if (aborted) {
@@ -1515,7 +1530,16 @@ static int refit_once(bohip_gp* g, double jitter) {
             g->stale = true;
             return refit_once(g, jitter);
         }
-        CHK(check_info(g));
+        if (pwords) {
+            if (pwords[1] != 0) {
+                g->pivot = pwords[1];
+                g->stale = true;
+                return fail(BOHIP_E_NOTPD, "kernel matrix not positive definite at pivot " + std::to_string(pwords[1]));
+            }
+            g->pivot = 0;
+        } else {
+            CHK(check_info(g));
+        }
         g->stale = false;
         g->n_factored = N;
         g->refits++;
@@ -2527,8 +2551,10 @@ int bohip_gp_mll(bohip_gp* g, double* mll) {
     CHK(ensure_fresh(g));
     hipLaunchKernelGGL(k_mll, dim3(1), dim3(256), 0, g->stream, g->dL, g->ld, g->n, g->dr, g->dalpha, g->dmll);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(mll, g->dmll, 8, hipMemcpyDeviceToHost, g->stream));
+    double* const pm = g->hpin ? g->hpin : mll;     // (through the pinned block: a plain DMA command)
+    HIPCHK(hipMemcpyAsync(pm, g->dmll, 8, hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
+    *mll = *pm;
     return 0;
 }
 
@@ -2575,7 +2601,8 @@ int bohip_gp_mll_grad(bohip_gp* g, double* mll, double* d_lognoise, double* d_me
     hipLaunchKernelGGL(k_dmll_final, dim3(nout), dim3(256), 0, g->stream, g->ddmll_parts, nblocks, NP, g->d, iso, g->dmll + 1);
     HIPCHK(hipGetLastError());
     t_end(g);
-    double h[DMAX + 4];
+    double hbuf[DMAX + 4];
+    double* const h = g->hpin ? g->hpin + 3 * SMALL_R + 2 : hbuf;     // (the pinned block's gradient area: a plain DMA command)
     HIPCHK(hipMemcpyAsync(h, g->dmll, 8 * (size_t)(nout + 1), hipMemcpyDeviceToHost, g->stream));
     HIPCHK(hipStreamSynchronize(g->stream));
     *mll = h[0]; *d_lognoise = h[1]; *d_mean = h[2];
