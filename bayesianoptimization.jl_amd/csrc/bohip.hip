@@ -525,6 +525,7 @@ static CholFlags chol_flags_layout_at(unsigned* base, double* idl, int T) {
     fl.xp3 = base + chol_xp3_word(T);
     fl.pre3 = fl.xp3 + (size_t)T * CH_PANELS;
     fl.w16_g = idl;
+    fl.resident = fl.abort + 7;   // (the word between the executor's six queue cursors and the inverse queues' counters)
     fl.spin_ticks = g_chol_spin_ticks;
     fl.crit_want = 16u;   // the row-(k+2) update: 4 workgroups x 4 storing waves
     fl.panel_want = 3u;   // three publishing waves per panel
@@ -547,6 +548,10 @@ static int cholesky_dataflow(bohip_gp* g, int T) {
         HIPCHK(hipStreamWaitEvent(g->inv_stream, g->ev_panels, 0));
         hipLaunchKernelGGL(k_chol_rows, dim3(T - 3), dim3(CH_THREADS), WK_LDS_DOUBLES * 8, g->col_stream, g->dL, ld, g->dS, T, fl);
         hipLaunchKernelGGL(k_chol_cols, dim3(2 * (T - 3)), dim3(GEMM_THREADS), 0, g->side_stream, g->dL, ld, g->dS, T, fl);
+        HIPCHK(hipGetLastError());
+    }
+    if (T > 3) {   // the flagged launches below stay behind the persistent workgroups (k_chol_gate)
+        hipLaunchKernelGGL(k_chol_gate, dim3(1), dim3(64), 0, g->inv_stream, fl.resident, 8u + 3u * (unsigned)(T - 3), fl.abort, fl.spin_ticks);
         HIPCHK(hipGetLastError());
     }
     for (int k = 0; k + 3 < T; ++k) {
@@ -1520,6 +1525,27 @@ static int refit_once(bohip_gp* g, double jitter) {
                 }
                 fprintf(stderr, "libbohip: dataflow factorisation (form %d, %d row tiles) timed out on a dependency (%s); using the launch-chained form for a while\n",
                         g->chol_form_last, T, which);
+            }
+            if (getenv("BOHIP_CHOL_DF_DUMP")) {   // diagnosis: which flags of the dataflow form never arrived
+                std::vector<unsigned> hf(chol_flag_words(T));
+                hipMemcpy(hf.data(), g->dchol_flags, hf.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+                const CholFlags fl = chol_flags_layout(g, T);
+                auto at = [&](const unsigned* p) { return hf[(size_t)(p - g->dchol_flags)]; };
+                fprintf(stderr, "  abort word 0x%x, words behind it:", aborted);
+                for (int w_ = 1; w_ < 8; ++w_) fprintf(stderr, " %u", hf[chol_abort_word(T) + w_]);
+                fprintf(stderr, "\n");
+                for (int k = 0; k < T; ++k) {
+                    fprintf(stderr, "  block %2d: panel", k);
+                    for (int p = 0; p < CH_PANELS; ++p) fprintf(stderr, " %u", at(fl.panel + k * CH_PANELS + p));
+                    fprintf(stderr, " | crit %u rest %u col %u farall %u colall %u | rows with xp[7] unset:", at(fl.crit + k), at(fl.rest + k), at(fl.col + k), at(fl.farall + k), at(fl.colall + k));
+                    for (int i = k + 1; i < T; ++i) {
+                        const unsigned* x = fl.xp + ((size_t)k * T + i) * CH_PANELS;
+                        if (at(x + CH_PANELS - 1) == 0u) { int p0 = 0; while (p0 < CH_PANELS && at(x + p0) != 0u) ++p0; fprintf(stderr, " %d(p%d)", i, p0); }
+                    }
+                    fprintf(stderr, " | colr<8:");
+                    for (int i = k + 2; i < T; ++i) if (at(fl.colr + (size_t)k * T + i) < 8u) fprintf(stderr, " %d(%u)", i, at(fl.colr + (size_t)k * T + i));
+                    fprintf(stderr, "\n");
+                }
             }
             if (getenv("BOHIP_CHOL_DF_STRICT")) return fail(BOHIP_E_HIP, "dataflow factorisation timed out on a dependency (BOHIP_CHOL_DF_STRICT)");
             {

@@ -41,13 +41,30 @@
 
 namespace bohip {
 
+#ifndef BOHIP_PIVOT_W16GROW
+#define BOHIP_PIVOT_W16GROW 1   // 1 (round 6): W16 grown inside the pivot block's factorisation, the rows below solved as a PRODUCT with it on the matrix pipe; 0: round 5's substitutions
+#endif
 constexpr int CH_THREADS = 512;
+// Row stride of the owner's LDS image of the diagonal tile.  k_potf2_inv's 129 makes a thread-per-row walk conflict-free; the chain's pivot
+// block no longer has one: its operand fetches are MFMA fragments (8 rows x 4 consecutive entries per 32 lanes), which want
+// stride = 4 (mod 32): 132.  (With 129 the row-solve phase took 1.2 us of LDS conflicts per panel instead of 0.3.)
+constexpr int CH_LD = BOHIP_PIVOT_W16GROW ? TILE + 4 : PF_LD;
+constexpr int CH_WLS = BOHIP_PIVOT_W16GROW ? 20 : 16;   // row stride of the pivot block's inverse in LDS (20: see WK_S)
 constexpr int CH_PANELS = TILE / 16;          // 8 panels of 16 columns per 128-block
 constexpr int WK_LPS = 16;                    // worker LDS: published panel LP[128][16]
 constexpr int WK_XS = 18;                     //             solved rows   XB[128][18]: rows 16-byte aligned (two entries per ds_read_b128), 16 consecutive rows on 16 different bank quads
+#ifndef BOHIP_FOLLOW_MFMA
+#define BOHIP_FOLLOW_MFMA 1   // 1 (round 6): the panel followers solve and update on the matrix pipe (follow_block below); 0: round 5's register-tiled VALU form
+#endif
+constexpr int WK_S = 20;                      // round 6, row stride of the follower's LDS arrays: 20 r + k (8-byte units) hits 32 different bank pairs for r < 8, k < 4 -- the
+                                              // footprint of one MFMA operand fetch -- and keeps 16-byte alignment
+#if BOHIP_FOLLOW_MFMA
+constexpr int WK_LDS_DOUBLES = 2 * TILE * WK_S + 16 * WK_S + 2;   // Lp[128][20] | X[128][20] | W16[16][20] | next-panel-ready word: 43.5 KB (round 5: 55.5 -- a CU must still hold a column updater and a flagged launch's workgroup beside a follower)
+#else
 constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + 2 * TILE * WK_XS + 256 + 2;   // LPt[16][130] | XB[128][18] | XS[128][18] | W16[16][16] | next-panel-ready word
+#endif
 constexpr int INV_LDS_DOUBLES = (TILE - 16) * TILE + 16 * (TILE - 16) + 16 * TILE + 256;   // the inverter workgroup's image (inverter_role)
-constexpr int CH_LDS_BYTES = (INV_LDS_DOUBLES > TILE * PF_LD + 2 * TILE + 256 ? INV_LDS_DOUBLES : TILE * PF_LD + 2 * TILE + 256) * 8;   // the potf2 image + dl + idl + W16 scratch (the worker arrays alias its start), or the inverter's
+constexpr int CH_LDS_BYTES = (INV_LDS_DOUBLES > TILE * CH_LD + 2 * TILE + 2 * 16 * CH_WLS ? INV_LDS_DOUBLES : TILE * CH_LD + 2 * TILE + 2 * 16 * CH_WLS) * 8;   // the potf2 image + dl + idl + W16 scratch (the worker arrays alias its start), or the inverter's
 static_assert(WK_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "worker arrays must fit inside the diagonal-block image");
 
 struct CholFlags {
@@ -73,6 +90,7 @@ struct CholFlags {
     int nsf;              // executor form: solve-follower workgroups of the chain kernel (rows k+3 .. k+2+nsf of block k)
     unsigned* xp3;        // [T * 8]   mode2 >= 200: panel p of S(k+3, k) is complete (solve follower 0): what the gated updates of row k+3 consume
     unsigned* pre3;       // [T * 4]   mode2 >= 200: tile (k+3, k+1+j) carries every block before k (executor: 16 per tile): pre3[4 k + j]
+    unsigned* resident;   // [1]       persistent workgroups that have started (form 1: what k_chol_gate holds the flagged launches back for)
 };
 
 // Bound of every in-kernel wait, in ticks of wall_clock64() (100 MHz constant clock): 200 ms by default.  The longest legitimate
@@ -151,6 +169,160 @@ __host__ __device__ constexpr int blk_bj(int idx) { return idx - blk_bi(idx) * (
 // took 10 us.  With an 8-row x 4-column register block per lane, a step of the update needs 8 + 4 operands for 32 FMAs.
 constexpr int WK_LS = TILE + 2;   // row stride of LPt (even: 16-B aligned rows; +2 spreads the staging writes over the banks)
 
+#if BOHIP_FOLLOW_MFMA
+// ---- round 6: the panel follower on the matrix pipe ------------------------------------------------------------------------------------
+// Round 5's follower (kept below, BOHIP_FOLLOW_MFMA=0) held 8 rows x 4 columns per lane and paid, per panel, 32 broadcast reads of 16 bytes
+// for the row solve (0.9 us of LDS time: an LDS read returns 64 lanes x its width whether or not the lanes share an address) and 96 per
+// updating wave for the rank-16 update (2.5 us with seven waves updating): 4.3-5 us per panel against a pivot that publishes one every
+// 4.3 us since the pivot block's own phases moved to the matrix pipe.  Here both are v_mfma_f64_4x4x4 products (2 x 2 blocks = 8 x 8 x 4 per
+// instruction, gemm_core.h): wave w owns columns 16w .. 16w+15 of tile (i, k) as 16 x 2 accumulator blocks (32 doubles per lane, as before),
+//     solve    X = R W16'            wave w: rows 16w .. 16w+15, 16 instructions, 16 operand fetches
+//     update   A -= X Lp'            wave w > p: 128 instructions, 64 + 8 operand fetches of 8 bytes (one lane = one element, no broadcasts)
+// The rate of the update is the CU's FP64 rate either way (MI355X: matrix = vector); what changes is the LDS traffic under it (3 x less)
+// and the solve.  LDS arrays, row stride WK_S = 20:  Lp[c][m] = L_kk[c][16p + m] (staged as it arrives: rows, not transposed), W16[c][m], and
+// X[r][m] = the panel's 16 columns -- handed over by the wave that holds them while the staging loads are in flight (one phase and one
+// barrier less per panel), then solved IN PLACE: every wave reads the 16 rows it solves and writes -x over them.
+__device__ __forceinline__ double lane_swap1(double v) {   // the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2])
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int H>
+__device__ __forceinline__ void d1_rank16(const double* XB, double (&d)[18]);
+template <bool WITH_D1, int H>
+__device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ S,
+                                             int i_tile, int k_blk, const CholFlags& fl, double* wk, double (&a)[32],
+                                             double (&d)[18], unsigned* xf) {
+    static_assert(!WITH_D1, "the owner keeps its own loop (chain_owner)");
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kq = lane >> 4, bb = (lane >> 2) & 3, t4 = lane & 3;
+    const int ar = 4 * (bb >> 1) + t4, bc = 4 * (bb & 1) + t4, dr = 4 * (bb >> 1) + kq, dc = bc;
+    double* Lp = wk;                          // [128][WK_S]
+    double* XB = Lp + TILE * WK_S;            // [128][WK_S]  before the solve: the panel's columns;  after it: -x
+    double* XS = XB;
+    double* W16s = XB + TILE * WK_S;          // [16][WK_S]
+    int* nready = reinterpret_cast<int*>(W16s + 16 * WK_S);
+    const double* Lkk = Lmat + (int64_t)k_blk * TILE * (ld + 1);
+    double pv0 = 0.0, pv1 = 0.0, pv2 = 0.0, pv3 = 0.0, pw = 0.0;
+    bool have = false;
+    auto hand_over = [&]() {   // this wave's 16 columns, final for the panel that comes next, to XB
+#pragma unroll
+        for (int rb = 0; rb < 16; ++rb) {
+            XB[(8 * rb + dr) * WK_S + dc] = a[2 * rb];
+            XB[(8 * rb + dr) * WK_S + 8 + dc] = a[2 * rb + 1];
+        }
+    };
+    for (int p = 0; p < CH_PANELS; ++p) {
+        if (t == 0) {
+            if (!have) flag_wait_ge(fl.panel + k_blk * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
+            *nready = (p + 1 < CH_PANELS && __hip_atomic_load(fl.panel + k_blk * CH_PANELS + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= fl.panel_want) ? 1 : 0;
+        }
+        __syncthreads();
+        const bool nxt = *nready != 0;
+        {   // stage the published panel: rows 16p..127 of L_kk, columns 16p..16p+15 (4 threads per 128-B row segment), and W16;
+            // the wave that holds the panel's columns hands them over under the loads
+            const int i = t >> 2, mq = t & 3;
+            const bool ldp = !have && i >= 16 * p, ldw = !have && t < 128;
+            d2 u0, u1, uw;
+            u0.x = pv0; u0.y = pv1; u1.x = pv2; u1.y = pv3; uw.x = uw.y = 0.0;
+            if (ldp) {
+                const double* src = Lkk + (int64_t)i * ld + 16 * p + 4 * mq;
+                ld_agent_x2_issue(src, u0);
+                ld_agent_x2_issue(src + 2, u1);
+            }
+            if (ldw) ld_agent_x2_issue(fl.w16_g + ((size_t)k_blk * CH_PANELS + p) * 256 + 2 * t, uw);
+            if (w == p) hand_over();
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(u0), "+v"(u1), "+v"(uw) : : "memory");
+            if (i >= 16 * p) {
+                *reinterpret_cast<d2*>(Lp + i * WK_S + 4 * mq) = u0;
+                *reinterpret_cast<d2*>(Lp + i * WK_S + 4 * mq + 2) = u1;
+            }
+            if (have) {
+                if (t < 256) W16s[(t >> 4) * WK_S + (t & 15)] = pw;
+            } else if (t < 128) {
+                *reinterpret_cast<d2*>(W16s + (t >> 3) * WK_S + 2 * (t & 7)) = uw;
+            }
+        }
+        if (nxt) {   // the next panel's staging loads: in flight during this panel's solve and update (a follower that is behind catches up)
+            const int i = t >> 2, mq = t & 3;
+            if (i >= 16 * (p + 1)) {
+                const double* src = Lkk + (int64_t)i * ld + 16 * (p + 1) + 4 * mq;
+                pv0 = ld_agent(src); pv1 = ld_agent(src + 1); pv2 = ld_agent(src + 2); pv3 = ld_agent(src + 3);
+            }
+            if (t < 256) pw = ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p + 1) * 256 + t);
+        }
+        have = nxt;
+        __syncthreads();
+        {   // solve: rows 16w .. 16w+15, X = R W16'
+            double x[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double b0 = W16s[bc * WK_S + 4 * ks + kq], b1 = W16s[(8 + bc) * WK_S + 4 * ks + kq];
+                const double a0 = XB[(16 * w + ar) * WK_S + 4 * ks + kq], a1 = XB[(16 * w + 8 + ar) * WK_S + 4 * ks + kq];
+                x[0][0] = mfma444(a0, b0, x[0][0]);
+                x[0][1] = mfma444(a0, b1, x[0][1]);
+                x[1][0] = mfma444(a1, b0, x[1][0]);
+                x[1][1] = mfma444(a1, b1, x[1][1]);
+            }
+            const bool odd = (lane & 1) != 0;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int row = 16 * w + 8 * rb + dr;
+                XS[row * WK_S + dc] = -x[rb][0];
+                XS[row * WK_S + 8 + dc] = -x[rb][1];
+                // neighbouring lanes hold neighbouring columns: the even lane stores both lanes' entries of the left column half, the odd
+                // lane both of the right one -- 16-byte agent-scope pieces
+                const double got = lane_swap1(odd ? x[rb][0] : x[rb][1]);
+                double* Srow = S + ((int64_t)i_tile * TILE + row) * ld + (int64_t)k_blk * TILE + 16 * p + (odd ? 8 + dc - 1 : dc);
+                st_agent2(Srow, odd ? got : x[rb][0], odd ? x[rb][1] : got);
+            }
+        }
+        __syncthreads();
+        if (w > p) {   // wave-uniform: this wave's columns lie beyond the panel
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double b0 = Lp[(16 * w + bc) * WK_S + 4 * ks + kq], b1 = Lp[(16 * w + 8 + bc) * WK_S + 4 * ks + kq];
+                double ax[16];
+#pragma unroll
+                for (int rb = 0; rb < 16; ++rb) ax[rb] = XS[(8 * rb + ar) * WK_S + 4 * ks + kq];
+#pragma unroll
+                for (int rb = 0; rb < 16; ++rb) {
+                    a[2 * rb] = mfma444(ax[rb], b0, a[2 * rb]);
+                    a[2 * rb + 1] = mfma444(ax[rb], b1, a[2 * rb + 1]);
+                }
+            }
+        }
+        if (xf) release_wg();   // the S stores of this panel were issued a phase ago: they have landed by now
+        __syncthreads();   // Lp / XS are rewritten by the next panel
+        if (xf && t == 0) { flag_set(xf + p, 1u); if (k_blk < 24 && i_tile - k_blk <= 2) CH_MARK(3648 + (k_blk * 2 + (i_tile - k_blk - 1)) * 9 + p); }
+    }
+}
+
+// tile (i, k) into the accumulator layout of follow_block: lane pairs fetch 16-byte pieces (even lane: its row's two entries of the left
+// column half, odd lane: of the right one) and swap one entry each
+__device__ __forceinline__ void load_row_piece(const double* __restrict__ Lmat, int64_t ld, int i_tile, int k_blk,
+                                               double (&a)[32]) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int kq = lane >> 4, bb = (lane >> 2) & 3, t4 = lane & 3, dr = 4 * (bb >> 1) + kq, dc = 4 * (bb & 1) + t4;
+    const bool odd = (lane & 1) != 0;
+    const double* base = Lmat + ((int64_t)i_tile * TILE + dr) * ld + (int64_t)k_blk * TILE + 16 * w + (odd ? 8 + dc - 1 : dc);
+    d2 v[16];
+#pragma unroll
+    for (int rb = 0; rb < 16; ++rb) ld_agent_x2_issue(base + (int64_t)8 * rb * ld, v[rb]);
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int rb = 0; rb < 16; ++rb) {
+        const double got = lane_swap1(odd ? v[rb].x : v[rb].y);
+        a[2 * rb] = odd ? got : v[rb].x;
+        a[2 * rb + 1] = odd ? v[rb].y : got;
+    }
+}
+#else
 // x L16' = r  <=>  x = r W16',  W16 = L16^-1 published by the pivot workgroup: 4 of the 16 entries per thread, all 512
 // threads, no dependent chain (the substitution by one thread per row -- 16 dependent steps behind two barriers -- took 4 us
 // of a 10 us panel).
@@ -302,6 +474,8 @@ __device__ __forceinline__ void load_row_piece(const double* __restrict__ Lmat, 
     }
 }
 
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------------
 // Pivot role: the Cholesky part of k_potf2_inv (same panels, same look-ahead of the next 16 x 16 pivot block beside the
 // trailing update) on the image `a` already in LDS, run by threads 0..255 of the 512-thread owner (the others only keep
@@ -318,12 +492,12 @@ __device__ __forceinline__ void publish_panel(double* __restrict__ Lblk, int64_t
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int c0 = P + 8 * h + c;
-            v[c] = (i > c0) ? a[c0 * PF_LD + i] : (i == c0 ? dl[i] : 0.0);
+            v[c] = (i > c0) ? a[c0 * CH_LD + i] : (i == c0 ? dl[i] : 0.0);
         }
 #pragma unroll
         for (int c = 0; c < 8; c += 2) st_agent2(dst + c, v[c], v[c + 1]);
     }
-    if (tid < 128) st_agent2(w16_out + 2 * tid, w16s[2 * tid], w16s[2 * tid + 1]);   // 256 entries, 16 bytes per store
+    if (tid < 128) st_agent2(w16_out + 2 * tid, w16s[(tid >> 3) * CH_WLS + 2 * (tid & 7)], w16s[(tid >> 3) * CH_WLS + 2 * (tid & 7) + 1]);   // 256 entries, 16 bytes per store
 }
 
 // ---- forward substitution against a 16 x 16 pivot block on LPR lanes per row (used by pivot_block) ----------------------------------
@@ -416,6 +590,108 @@ __device__ __forceinline__ void group_fsub_w16(const double* a, const double* id
     group_fsub_w16_steps(w16s, cc, p, sacc, L, std::make_integer_sequence<int, 16>{});
 }
 
+#if BOHIP_PIVOT_W16GROW
+// Round 6.  Per panel the critical path was  factor16 (2.7 us) -> [16-step substitution of the rows below the pivot block (1.6 us) beside the
+// 16-step inverse W16 on wave 4 (2.1 us)] -> update of the next pivot block (0.5 us) -> factor16 ...: 5.2 us, 41 us per 128-block.  W16 now
+// comes out of factor16w itself (kernels_linalg.hip: the inverse's partial sums live in the triangle the Schur complement has left and take
+// the same rank-1 update), so the rows below are solved the way the followers solve theirs -- x = r W16', 64 multiply-adds per thread on all
+// eight waves, no dependent chain -- and the phase shrinks to ~0.4 us.  W16 is double-buffered in LDS: the publishing waves read panel
+// jb's while wave 0 writes panel jb+1's.
+__device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, double* __restrict__ Lblk, int64_t ld,
+                                            int k_blk, const CholFlags& fl, int* info, int row0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool act = tid < PF_THREADS;
+    unsigned* pflag = fl.panel + k_blk * CH_PANELS;
+    double* w16b = idl + TILE;   // [2][16][CH_WLS] inverse of the pivot block: panel jb's in buffer jb & 1
+    if (wave == 0) factor16w<CH_LD, CH_WLS>(a, dl, idl, w16b, 0, lane, info, row0);
+    __syncthreads();
+    for (int jb = 0; jb < CH_PANELS; ++jb) {
+        const int P = 16 * jb;
+        const int base = P + 16, m = TILE - base;
+        const double* w16s = w16b + 16 * CH_WLS * (jb & 1);
+        if (m > 0) {
+            // Phase A: the rows below the pivot block, X = R W16' (m x 16 x 16), on the matrix pipe: 8-row blocks dealt to the eight waves,
+            // one v_mfma_f64_4x4x4 (2 x 2 blocks = 8 x 8 x 4, gemm_core.h) per column half and contraction step.  (As 64 multiply-adds per
+            // thread with W16 read as broadcasts it took 1.3 us: an LDS read returns 64 lanes x its width whether or not the lanes share an
+            // address -- 32 such 16-byte reads per thread, 0.9 us of LDS time per panel.)  Reads the lower triangle of the image (row i,
+            // columns P .. P+15), writes the mirror (column P + c of L, row i): disjoint.
+            const int kq = lane >> 4, bb = (lane >> 2) & 3, t4 = lane & 3;
+            const int ar = 4 * (bb >> 1) + t4, bc = 4 * (bb & 1) + t4, dr = 4 * (bb >> 1) + kq, dc = 4 * (bb & 1) + t4;
+            if (8 * wave < m) {
+                double bw[2][4];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) bw[cb][ks] = w16s[(8 * cb + bc) * CH_WLS + 4 * ks + kq];
+                for (int rb = wave; 8 * rb < m; rb += 8) {
+                    const double* rrow = a + (base + 8 * rb + ar) * CH_LD + P + kq;
+                    double av[4], x0 = 0.0, x1 = 0.0;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) av[ks] = rrow[4 * ks];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        x0 = mfma444(av[ks], bw[0][ks], x0);
+                        x1 = mfma444(av[ks], bw[1][ks], x1);
+                    }
+                    a[(P + dc) * CH_LD + base + 8 * rb + dr] = x0;
+                    a[(P + 8 + dc) * CH_LD + base + 8 * rb + dr] = x1;
+                }
+            }
+            if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 6);
+            __syncthreads();
+            if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 0);
+        }
+        // Phase C.  Who does what follows from where the waves sit: wave w runs on SIMD w % 4, so wave 4 shares its SIMD with wave 0.  The
+        // pivot chain (wave 0) gets the lightest neighbour: waves 4, 6, 7 publish (a few LDS reads and stores each, the wait for them to
+        // land, +1 each on the panel's flag: followers wait for 3), waves 1, 2, 3, 5 carry the trailing update.
+        if (wave == 4 || wave >= 6) {   // 192 threads walk the 256 publishing slots
+            const int pw = wave == 4 ? 0 : wave - 5;
+            for (int s_ = 64 * pw + lane; s_ < PF_THREADS; s_ += 192)
+                publish_panel(Lblk, ld, a, dl, w16s, fl.w16_g + ((size_t)k_blk * CH_PANELS + jb) * 256, P, s_);
+            if (lane == 0 && wave == 4 && k_blk == 1) CH_MARK(5904 + jb);   // wave 4 starts waiting for its stores
+            release_wg();   // s_waitcnt vmcnt(0): this wave's part of the panel has left the CU
+            if (lane == 0) {
+                atomicAdd(pflag + jb, 1u);
+                if (wave == 4) CH_MARK(k_blk * CH_PANELS + jb);
+                if (wave == 6 && k_blk == 1) CH_MARK(5888 + jb);
+                if (wave == 7 && k_blk == 1) CH_MARK(5896 + jb);
+            }
+        }
+        if (m == 0) break;
+        if (wave == 0) {
+            // the rank-16 update of the NEXT pivot block by this wave alone, D = Xn Xn' on the matrix pipe (its own phase on 256 threads and
+            // a barrier until round 6: 0.6 us of every panel), then straight into its factorisation (same wave: LDS is in order)
+            {
+                const int kq = lane >> 4, bb = (lane >> 2) & 3, t4 = lane & 3;
+                const int ar = 4 * (bb >> 1) + t4, bc = 4 * (bb & 1) + t4, dr = 4 * (bb >> 1) + kq, dc = 4 * (bb & 1) + t4;
+                double d00 = 0.0, d10 = 0.0, d11 = 0.0;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const double* xc = a + (P + 4 * ks + kq) * CH_LD + base;   // column 4 ks + kq of X: the next pivot block's 16 rows
+                    const double a0 = xc[ar], a1 = xc[8 + ar], b0 = xc[bc], b1 = xc[8 + bc];
+                    d00 = mfma444(a0, b0, d00);
+                    d10 = mfma444(a1, b0, d10);
+                    d11 = mfma444(a1, b1, d11);
+                }
+                if (dc <= dr) {
+                    a[(base + dr) * CH_LD + base + dc] -= d00;
+                    a[(base + 8 + dr) * CH_LD + base + 8 + dc] -= d11;
+                }
+                a[(base + 8 + dr) * CH_LD + base + dc] -= d10;
+                if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 1);
+            }
+            factor16w<CH_LD, CH_WLS>(a, dl, idl, w16b + 16 * CH_WLS * ((jb + 1) & 1), base, lane, info, row0);
+            if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 3);
+        } else if (wave <= 3 || wave == 5) {
+            const int u = 64 * (wave == 5 ? 3 : wave - 1) + lane;
+            trailing_dispatch<true, -1, CH_LD>(a, P, m >> 4, u >> 4, u & 15);
+            if (tid == 64 && k_blk == 1) CH_MARK(3584 + 8 * jb + 4);
+        }
+        __syncthreads();
+        if (tid == 0 && k_blk == 1) CH_MARK(3584 + 8 * jb + 2);
+    }
+}
+#else
 __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, double* __restrict__ Lblk, int64_t ld,
                                             int k_blk, const CholFlags& fl, int* info, int row0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -493,6 +769,7 @@ __device__ __forceinline__ void pivot_block(double* a, double* dl, double* idl, 
     }
 }
 
+#endif
 // diagonal tile (r, r): HBM -> registers (owner, follower role) / registers -> LDS image (owner, pivot role)
 template <int H>
 __device__ __forceinline__ void d1_load(const double* __restrict__ Lmat, int64_t ld, int r, double (&d)[18]) {
@@ -512,10 +789,10 @@ __device__ __forceinline__ void d1_to_image(double* a, const double (&d)[18]) {
         const int bi = blk_bi(2 * s + H), bj = blk_bj(2 * s + H);
         const int i = 16 * bi + ty, j = 16 * bj + tx;
         if (bi != bj) {
-            a[i * PF_LD + j] = d[s];
-            a[j * PF_LD + i] = 0.0;       // the strict upper triangle is workspace and starts at zero
+            a[i * CH_LD + j] = d[s];
+            a[j * CH_LD + i] = 0.0;       // the strict upper triangle is workspace and starts at zero
         } else {
-            a[i * PF_LD + j] = (j <= i) ? d[s] : 0.0;
+            a[i * CH_LD + j] = (j <= i) ? d[s] : 0.0;
         }
     }
 }
@@ -551,7 +828,7 @@ template <int H>
 __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t ld, double* __restrict__ S, int T,
                                             const CholFlags& fl, int* info, double* sm, int w) {
     double* a = sm;
-    double* dl = sm + TILE * PF_LD;
+    double* dl = sm + TILE * CH_LD;
     double* idl = dl + TILE;
     double* XB = sm;   // [128][18] while the image is not in use
     const int tid = threadIdx.x;
@@ -561,7 +838,7 @@ __device__ __forceinline__ void chain_owner(double* __restrict__ Lmat, int64_t l
             const double* Lblk = Lmat;
             for (int e = tid; e < TILE * TILE; e += CH_THREADS) {
                 const int i = e >> 7, j = e & 127;
-                a[i * PF_LD + j] = (j <= i) ? Lblk[(int64_t)i * ld + j] : 0.0;
+                a[i * CH_LD + j] = (j <= i) ? Lblk[(int64_t)i * ld + j] : 0.0;
             }
             __syncthreads();
         } else {
@@ -980,6 +1257,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_chain(double* __restrict
                                                            double* __restrict__ WT) {
     extern __shared__ double sm[];
     const int b = blockIdx.x;
+    if (threadIdx.x == 0) atomicAdd(fl.resident, 1u);
     if (b >= 9 + fl.nsf && fl.mode2 >= 200) {
         gated_worker3(Lmat, ld, S, T, fl, sm, b - 9 - fl.nsf);
     } else if (b >= 9) {
@@ -1005,6 +1283,7 @@ __global__ __launch_bounds__(CH_THREADS, 1) void k_chol_rows(const double* __res
                                                           int T, CholFlags fl) {
     extern __shared__ double sm[];
     const int i_tile = 3 + blockIdx.x;
+    if (threadIdx.x == 0) atomicAdd(fl.resident, 1u);
     double ar[32], d[18];
     for (int k = 0; k + 3 <= i_tile; ++k) {
         if (k >= 1) {   // tile (i, k) carries block k-1's update once its two column updaters have stored
@@ -1019,6 +1298,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_chol_cols(double* __restrict__
                                                          int T, CholFlags fl) {
     __shared__ __attribute__((aligned(16))) double sm[(TILE + CTILE) * GL_ROW];
     const int i_tile = 3 + (blockIdx.x >> 1), h = blockIdx.x & 1;
+    if (threadIdx.x == 0) atomicAdd(fl.resident, 1u);
     for (int k = 0; k + 3 <= i_tile; ++k) {   // tile (i, k+1), columns [64 h, 64 h + 64): -= L(i, k) L(k+1, k)'
         const double* A = S + (int64_t)i_tile * TILE * ld + (int64_t)k * TILE;
         const double* B = S + ((int64_t)(k + 1) * TILE + (int64_t)h * CTILE) * ld + (int64_t)k * TILE;
@@ -1028,6 +1308,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_chol_cols(double* __restrict__
                    xp_at(fl, k, k + 1), k >= 1 ? fl.farall + (k - 1) : nullptr, k >= 1 ? farcol_want(T, k - 1) : 0u,
                    fl.colr + (size_t)k * T + i_tile, fl, sm);
     }
+}
+
+// Form 1's flagged launches (k_gemm_nt, one per block, hundreds of workgroups that spin inside the kernel) must not reach the chip before
+// every PERSISTENT workgroup is resident: a panel follower holds 2 x 213 of a SIMD's 512 vector registers since round 6 (round 5: 2 x 160)
+// and no longer fits beside even one k_gemm_nt workgroup, so when the first flagged launch was dispatched between the persistent
+// kernels -- they sit on four streams released by one event -- some follower found no CU, the spinning workgroups waited for its rows,
+// and the factorisation ended in the 200 ms time-out (4 of 8 fresh processes at 24 row tiles, none at 16).  One wave on the flagged
+// launches' stream, in front of them, waits until the persistent workgroups have counted themselves in.
+__global__ __launch_bounds__(64) void k_chol_gate(const unsigned* word, unsigned want, unsigned* abort, unsigned long long spin_ticks) {
+    if (threadIdx.x == 0) flag_wait_ge(word, want, abort, spin_ticks);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

@@ -130,7 +130,7 @@ __device__ __forceinline__ bool ex_wait_task(const ExQueues& q, const ExTask* t,
         if (ex_ready_once(q, t, ntile, lane)) return true;
         if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
         if (wall_clock64() - t0 > q.spin_ticks) {
-            if (lane == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) atomicCAS(q.abort, 0u, 1u);
             return false;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -178,7 +178,7 @@ __device__ __forceinline__ int ex_pick(const ExQueues& q, int lane, bool& ready,
         if (!wait) return -3;
         if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return -1;
         if (wall_clock64() - t_idle > q.spin_ticks) {   // no runnable task for this long: something upstream never arrived
-            if (lane == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) atomicCAS(q.abort, 0u, 1u);
             return -1;
         }
         for (int s_ = 0; s_ < backoff; ++s_) __builtin_amdgcn_s_sleep(16);
@@ -221,7 +221,7 @@ __device__ __forceinline__ int ex_run(const ExTask& t, const ExQueues& q, double
                 for (int d = 0; d < 2; ++d)
                     if (t.dep2_idx[d] != EX_NONE && __hip_atomic_load(flags + t.dep2_idx[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t.dep2_want[d]) ok = false;
                 if (ok || __hip_atomic_load(abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-                if (wall_clock64() - t0 > spin_ticks) { __hip_atomic_store(abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                if (wall_clock64() - t0 > spin_ticks) { atomicCAS(abort, 0u, 1u); break; }
                 __builtin_amdgcn_s_sleep(2);
             }
         }
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(GEMM_THREADS_8, 4) void k_chol_exec(ExQueues q) {
                 }
                 if (__hip_atomic_load(q.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { run = -1; break; }
                 if (wall_clock64() - t_wait > q.spin_ticks) {
-                    if (pl == 0) __hip_atomic_store(q.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (pl == 0) atomicCAS(q.abort, 0u, 1u);
                     run = -1;
                     break;
                 }

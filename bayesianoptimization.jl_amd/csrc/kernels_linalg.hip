@@ -212,7 +212,7 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // operand NB times.)
 // (ty, tx): the element of every 16 x 16 sub-block this thread owns.  SKIP00: leave out sub-block (0, 0), the next
 // diagonal block, which the look-ahead updates and factors separately.
-template <int NB, bool SKIP00, int AMOD = -1>   // AMOD >= 0: only the sub-block rows ai with ai % 3 == AMOD
+template <int NB, bool SKIP00, int AMOD = -1, int LD = TILE + 1>   // AMOD >= 0: only the sub-block rows ai with ai % 3 == AMOD;  LD: row stride of the image
 __device__ __forceinline__ void trailing_update(double* a, int P, int ty, int tx) {
     const int base = P + 16;
     double acc[NB][NB];
@@ -222,7 +222,7 @@ __device__ __forceinline__ void trailing_update(double* a, int P, int ty, int tx
         for (int ki = 0; ki < NB; ++ki) acc[ai][ki] = 0.0;
 #pragma unroll 4
     for (int c = 0; c < 16; ++c) {
-        const double* col = a + (P + c) * PF_LD + base;
+        const double* col = a + (P + c) * LD + base;
         double li[NB], lk[NB];
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
@@ -243,19 +243,19 @@ __device__ __forceinline__ void trailing_update(double* a, int P, int ty, int tx
             if (AMOD >= 0 && ai % 3 != AMOD) continue;
             if (SKIP00 && ai == 0 && ki == 0) continue;
             const int i = base + ty + 16 * ai, k = base + tx + 16 * ki;
-            if (k <= i) a[i * PF_LD + k] -= acc[ai][ki];
+            if (k <= i) a[i * LD + k] -= acc[ai][ki];
         }
 }
-template <bool SKIP00, int AMOD>
+template <bool SKIP00, int AMOD, int LD = TILE + 1>
 __device__ __forceinline__ void trailing_dispatch(double* a, int P, int nb, int ty, int tx) {
     switch (nb) {  // tile size known at compile time per panel
-        case 7: trailing_update<7, SKIP00, AMOD>(a, P, ty, tx); break;
-        case 6: trailing_update<6, SKIP00, AMOD>(a, P, ty, tx); break;
-        case 5: trailing_update<5, SKIP00, AMOD>(a, P, ty, tx); break;
-        case 4: trailing_update<4, SKIP00, AMOD>(a, P, ty, tx); break;
-        case 3: trailing_update<3, SKIP00, AMOD>(a, P, ty, tx); break;
-        case 2: trailing_update<2, SKIP00, AMOD>(a, P, ty, tx); break;
-        case 1: trailing_update<1, SKIP00, AMOD>(a, P, ty, tx); break;
+        case 7: trailing_update<7, SKIP00, AMOD, LD>(a, P, ty, tx); break;
+        case 6: trailing_update<6, SKIP00, AMOD, LD>(a, P, ty, tx); break;
+        case 5: trailing_update<5, SKIP00, AMOD, LD>(a, P, ty, tx); break;
+        case 4: trailing_update<4, SKIP00, AMOD, LD>(a, P, ty, tx); break;
+        case 3: trailing_update<3, SKIP00, AMOD, LD>(a, P, ty, tx); break;
+        case 2: trailing_update<2, SKIP00, AMOD, LD>(a, P, ty, tx); break;
+        case 1: trailing_update<1, SKIP00, AMOD, LD>(a, P, ty, tx); break;
         default: break;
     }
 }
@@ -443,6 +443,85 @@ __device__ __forceinline__ void factor16(double* a, double* dl, double* idl, int
     for (int k = 0; k < 16; ++k)
         if (k < r) a[(P + k) * PF_LD + P + r] = v[k];     // finished columns to the mirror position
 #endif
+}
+
+// Round 6: the same 16 x 16 factorisation with W16 = L16^-1 GROWN INSIDE it (the chain's pivot_block, kernels_chol.hip).  Until now the
+// inverse of a pivot block was a second 16-step chain on another wave (group_fsub_w16, ~2 us) beside a 16-step substitution per row
+// below the block (~1.6 us), both BEHIND factor16 on the critical path of every panel.  The two triangles of the block are complementary:
+// at step J the Schur complement lives in the columns > J of the rows > J, and the columns <= J of those rows are free -- exactly where
+// the partial sums of the inverse live,
+//     T[i][c] = delta_ic - sum_{k < J} L[i][k] W[k][c]      (rows i >= J, columns c < J),      W[J][c] = T[J][c] / L_JJ,
+// and their update at step J,  T[i][c] -= L[i][J] W[J][c],  is the SAME rank-1 formula  M[i][c] -= l_i (M[J][c] / L_JJ)  the Schur
+// complement gets (row J's entries in my columns, scaled, times my row's multiplier): the step's four fused multiply-adds per lane
+// simply lose their column predicate.  What a step adds: the rows <= J stop (their multiplier is zero), column J starts its life as
+// T[i][J] = -l_i / L_JJ, and the finished column of L moves to a register of its own.  Row r keeps T[r][:] unscaled until the end (nobody
+// reads a finished row again), so the scaling by 1 / L_rr is four multiplications after the last step.
+// Out: L (strict lower) to the mirror position of the image, diagonal to dl, reciprocals to idl, W16 (lower incl. diagonal, ZEROS above:
+// every consumer sums all 16 terms) to w16out[16][WLS].
+template <int J>
+__device__ __forceinline__ void factor16w_step(double (&v)[4], double (&lc)[4], int r, int q, double (&dj)[16], double (&ij)[16], int& bad) {
+    constexpr int QJ = J >> 2, EJ = J & 3;
+    double ajj = readlane_f64(v[EJ], J + 16 * QJ);
+    double arj = lane_fetch(v[EJ], 4 * (r + 16 * QJ));
+    arj = (r > J) ? arj : 0.0;                       // rows <= J are final: their multiplier is zero
+    double ajk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ajk[e] = row_bcast16_dpp<J>(v[e]);
+    const bool ok = ajj > 0.0;
+    bad = (!ok && bad == 0) ? J + 1 : bad;
+    ajj = ok ? ajj : 1.0;
+    const double inv = fast_rsqrt(ajj);
+    const double lr = arj * inv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const double lk = ajk[e] * inv;              // columns > J: L[c][J];  columns < J: W[J][c]
+        v[e] -= lr * lk;
+    }
+    if (q == QJ) {
+        lc[EJ] = lr;                                 // column J of L (rows > J; zero above)
+        v[EJ] = (r > J) ? -(lr * inv) : v[EJ];       // T[r][J] = -L[r][J] W[J][J]
+    }
+    dj[J] = ajj * inv;
+    ij[J] = inv;
+}
+template <int... Js>
+__device__ __forceinline__ void factor16w_steps(double (&v)[4], double (&lc)[4], int r, int q, double (&dj)[16], double (&ij)[16], int& bad,
+                                                std::integer_sequence<int, Js...>) {
+    (factor16w_step<Js>(v, lc, r, q, dj, ij, bad), ...);
+}
+template <int LD, int WLS>   // LD: row stride of the image;  WLS: row stride of w16out
+__device__ __forceinline__ void factor16w(double* a, double* dl, double* idl, double* w16out, int P, int lane, int* info, int row0) {
+    const int r = lane & 15, q = lane >> 4;
+    double v[4], lc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int k = 4 * q + e;
+        v[e] = (k <= r) ? a[(P + r) * LD + P + k] : a[(P + k) * LD + P + r];   // lower triangle, mirrored into the upper
+    }
+    double dj[16], ij[16];
+    int bad = 0;
+    factor16w_steps(v, lc, r, q, dj, ij, bad, std::make_integer_sequence<int, 16>{});
+    double dmine = 0.0, imine = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        dmine = r == j ? dj[j] : dmine;
+        imine = r == j ? ij[j] : imine;
+    }
+    if (lane < 16) { dl[P + lane] = dmine; idl[P + lane] = imine; }
+    if (bad != 0 && lane == 0) atomicCAS(info, 0, row0 + P + bad);
+    d2 w01, w23;
+    {
+        double w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 4 * q + e;
+            if (k < r) a[(P + k) * LD + P + r] = lc[e];   // mirror
+            w[e] = k < r ? v[e] * imine : (k == r ? imine : 0.0);
+        }
+        w01.x = w[0]; w01.y = w[1]; w23.x = w[2]; w23.y = w[3];
+    }
+    *reinterpret_cast<d2*>(w16out + r * WLS + 4 * q) = w01;
+    *reinterpret_cast<d2*>(w16out + r * WLS + 4 * q + 2) = w23;
 }
 
 // B0 + B1 of the header above on an image whose strict upper triangle (mirror) holds L and whose idl[] holds 1 / L_ii:
@@ -685,7 +764,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTParams& p, const int bi
                 if (ok) break;
                 if (p.abort_flag && __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
                 __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t0 > (p.spin_ticks ? p.spin_ticks : CH_SPIN_TICKS_DEFAULT)) { if (p.abort_flag) atomicExch(p.abort_flag, 1u); break; }   // see flag_wait_ge
+                if (wall_clock64() - t0 > (p.spin_ticks ? p.spin_ticks : CH_SPIN_TICKS_DEFAULT)) { if (p.abort_flag) atomicCAS(p.abort_flag, 0u, 1u); break; }   // see flag_wait_ge (the FIRST waiter to give up names the cause)
             }
         }
         __syncthreads();   // what the flag guards was written with agent-scope stores (kernels_chol.hip): no cache maintenance here
