@@ -63,7 +63,8 @@ constexpr int WK_LDS_DOUBLES = 2 * TILE * WK_S + 16 * WK_S + 2;   // Lp[128][20]
 #else
 constexpr int WK_LDS_DOUBLES = 16 * (TILE + 2) + 2 * TILE * WK_XS + 256 + 2;   // LPt[16][130] | XB[128][18] | XS[128][18] | W16[16][16] | next-panel-ready word
 #endif
-constexpr int INV_LDS_DOUBLES = (TILE - 16) * TILE + 16 * (TILE - 16) + 16 * TILE + 256;   // the inverter workgroup's image (inverter_role)
+constexpr int INV_LS = TILE - 16 + 4;           // row stride of the inverter's rows of L (116 = 20 mod 32: see WK_S)
+constexpr int INV_LDS_DOUBLES = (TILE - 16) * TILE + 16 * TILE + 16 * INV_LS + 16 * WK_S;   // the inverter workgroup's image (inverter_role): Wimg | Tl | Lrow | W16
 constexpr int CH_LDS_BYTES = (INV_LDS_DOUBLES > TILE * CH_LD + 2 * TILE + 2 * 16 * CH_WLS ? INV_LDS_DOUBLES : TILE * CH_LD + 2 * TILE + 2 * 16 * CH_WLS) * 8;   // the potf2 image + dl + idl + W16 scratch (the worker arrays alias its start), or the inverter's
 static_assert(WK_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "worker arrays must fit inside the diagonal-block image");
 
@@ -182,6 +183,8 @@ constexpr int WK_LS = TILE + 2;   // row stride of LPt (even: 16-B aligned rows;
 // and the solve.  LDS arrays, row stride WK_S = 20:  Lp[c][m] = L_kk[c][16p + m] (staged as it arrives: rows, not transposed), W16[c][m], and
 // X[r][m] = the panel's 16 columns -- handed over by the wave that holds them while the staging loads are in flight (one phase and one
 // barrier less per panel), then solved IN PLACE: every wave reads the 16 rows it solves and writes -x over them.
+// workgroup barrier that orders LDS accesses only (s_waitcnt lgkmcnt(0) + s_barrier): global loads and stores stay in flight across it
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ double lane_swap1(double v) {   // the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2])
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, true);
@@ -213,13 +216,20 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
             XB[(8 * rb + dr) * WK_S + 8 + dc] = a[2 * rb + 1];
         }
     };
+    // Per panel, a follower that is BEHIND the pivot (its tile arrived late; every solve follower and far row is, at the start of a block)
+    // must not pay a memory round trip it does not need: the look at the NEXT panel's flag is issued behind the first barrier and read
+    // behind the solve (it used to sit in front of the barrier: ~1 us per panel), the prefetch of that panel rides under the update, and
+    // the flag of panel p's columns of S is raised one panel later (p <= 5), when their stores have long landed, instead of behind a drain.
+    // The barriers are LDS barriers (barrier_lds): __syncthreads() also waits for every outstanding GLOBAL access -- this panel's stores to S,
+    // the prefetch of the next one -- which is exactly the latency the schedule keeps off the panel.
+    const bool trc = BOHIP_CHOL_TRACE && t == 0 && k_blk == 5 && i_tile - k_blk == 4;   // (trace build: solve follower 1 of block 5, [5920 + 5 p + phase])
+    unsigned fnext = 0u;   // thread 0: the flag of panel p + 1 as seen during the update of panel p - 1 (looked at again behind the solve if it was not up then)
     for (int p = 0; p < CH_PANELS; ++p) {
-        if (t == 0) {
-            if (!have) flag_wait_ge(fl.panel + k_blk * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
-            *nready = (p + 1 < CH_PANELS && __hip_atomic_load(fl.panel + k_blk * CH_PANELS + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= fl.panel_want) ? 1 : 0;
+        if (!have) {   // (uniform: read from LDS by everybody)
+            if (t == 0) flag_wait_ge(fl.panel + k_blk * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
+            barrier_lds();
         }
-        __syncthreads();
-        const bool nxt = *nready != 0;
+        if (trc) CH_MARK(5920 + 5 * p);
         {   // stage the published panel: rows 16p..127 of L_kk, columns 16p..16p+15 (4 threads per 128-B row segment), and W16;
             // the wave that holds the panel's columns hands them over under the loads
             const int i = t >> 2, mq = t & 3;
@@ -244,16 +254,9 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
                 *reinterpret_cast<d2*>(W16s + (t >> 3) * WK_S + 2 * (t & 7)) = uw;
             }
         }
-        if (nxt) {   // the next panel's staging loads: in flight during this panel's solve and update (a follower that is behind catches up)
-            const int i = t >> 2, mq = t & 3;
-            if (i >= 16 * (p + 1)) {
-                const double* src = Lkk + (int64_t)i * ld + 16 * (p + 1) + 4 * mq;
-                pv0 = ld_agent(src); pv1 = ld_agent(src + 1); pv2 = ld_agent(src + 2); pv3 = ld_agent(src + 3);
-            }
-            if (t < 256) pw = ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p + 1) * 256 + t);
-        }
-        have = nxt;
-        __syncthreads();
+        if (trc) CH_MARK(5920 + 5 * p + 1);
+        barrier_lds();
+        if (trc) CH_MARK(5920 + 5 * p + 2);
         {   // solve: rows 16w .. 16w+15, X = R W16'
             double x[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
 #pragma unroll
@@ -266,6 +269,14 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
                 x[1][1] = mfma444(a1, b1, x[1][1]);
             }
             const bool odd = (lane & 1) != 0;
+            if (trc) { asm volatile("" :: "v"(x[0][0]), "v"(x[1][1])); CH_MARK(5960 + 3 * p); }
+            if (xf) release_wg();   // the stores of the panel BEFORE (issued a whole panel ago) have landed: its flag goes up behind the barrier
+            // (BEFORE this panel's stores are issued: they are inline asm the compiler does not count, so its wait for the flag word below
+            // would be a wait for them too -- 0.8 us per panel in the trace)
+            if (t == 0) {
+                if (p + 1 < CH_PANELS && fnext < fl.panel_want) fnext = __hip_atomic_load(fl.panel + k_blk * CH_PANELS + p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *nready = (p + 1 < CH_PANELS && fnext >= fl.panel_want) ? 1 : 0;
+            }
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int row = 16 * w + 8 * rb + dr;
@@ -277,25 +288,72 @@ __device__ __forceinline__ void follow_block(const double* __restrict__ Lmat, in
                 double* Srow = S + ((int64_t)i_tile * TILE + row) * ld + (int64_t)k_blk * TILE + 16 * p + (odd ? 8 + dc - 1 : dc);
                 st_agent2(Srow, odd ? got : x[rb][0], odd ? x[rb][1] : got);
             }
+            if (trc) CH_MARK(5960 + 3 * p + 1);
         }
-        __syncthreads();
+        barrier_lds();
+        if (trc) CH_MARK(5920 + 5 * p + 3);
+        const bool nxt = *nready != 0;
+        if (t == 0) fnext = p + 2 < CH_PANELS ? __hip_atomic_load(fl.panel + k_blk * CH_PANELS + p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // (lands under the update)
+        if (xf && t == 0 && p >= 1 && p <= CH_PANELS - 2) flag_set(xf + p - 1, 1u);
+        if (nxt) {   // the next panel's staging loads: in flight during this panel's update
+            const int i = t >> 2, mq = t & 3;
+            if (i >= 16 * (p + 1)) {
+                const double* src = Lkk + (int64_t)i * ld + 16 * (p + 1) + 4 * mq;
+                pv0 = ld_agent(src); pv1 = ld_agent(src + 1); pv2 = ld_agent(src + 2); pv3 = ld_agent(src + 3);
+            }
+            if (t < 256) pw = ld_agent(fl.w16_g + ((size_t)k_blk * CH_PANELS + p + 1) * 256 + t);
+        }
+        have = nxt;
         if (w > p) {   // wave-uniform: this wave's columns lie beyond the panel
+            // eight chunks (contraction step ks, row half): the operands of chunk c + 1 are fetched while the 16 MFMAs of chunk c run
+            // (fetched per contraction step in front of its 32 MFMAs, every step waited for its own LDS round trip: 1.3 us for a wave
+            // that has its SIMD to itself, against 0.93 us of matrix-pipe time)
+            double axA[8], axB[8], bA0, bA1, bB0, bB1;
+            const double* lp0 = Lp + (16 * w + bc) * WK_S + kq;
+            const double* xs0 = XS + ar * WK_S + kq;
+            bA0 = lp0[0]; bA1 = lp0[8 * WK_S];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const double b0 = Lp[(16 * w + bc) * WK_S + 4 * ks + kq], b1 = Lp[(16 * w + 8 + bc) * WK_S + 4 * ks + kq];
-                double ax[16];
+            for (int i = 0; i < 8; ++i) axA[i] = xs0[8 * i * WK_S];
 #pragma unroll
-                for (int rb = 0; rb < 16; ++rb) ax[rb] = XS[(8 * rb + ar) * WK_S + 4 * ks + kq];
+            for (int c = 0; c < 8; ++c) {
+                const int ks = c >> 1, hf = c & 1;
+                if (c + 1 < 8) {
+                    const int ks1 = (c + 1) >> 1, hf1 = (c + 1) & 1;
+                    if (hf == 0) {
+                        bB0 = bA0; bB1 = bA1;
 #pragma unroll
-                for (int rb = 0; rb < 16; ++rb) {
-                    a[2 * rb] = mfma444(ax[rb], b0, a[2 * rb]);
-                    a[2 * rb + 1] = mfma444(ax[rb], b1, a[2 * rb + 1]);
+                        for (int i = 0; i < 8; ++i) axB[i] = xs0[(8 * (8 * hf1 + i)) * WK_S + 4 * ks1];
+                    } else {
+                        bA0 = lp0[4 * ks1]; bA1 = lp0[8 * WK_S + 4 * ks1];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) axA[i] = xs0[(8 * (8 * hf1 + i)) * WK_S + 4 * ks1];
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (hf == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        a[2 * i] = mfma444(axA[i], bA0, a[2 * i]);
+                        a[2 * i + 1] = mfma444(axA[i], bA1, a[2 * i + 1]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        a[2 * (8 + i)] = mfma444(axB[i], bB0, a[2 * (8 + i)]);
+                        a[2 * (8 + i) + 1] = mfma444(axB[i], bB1, a[2 * (8 + i) + 1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                (void)ks;
             }
         }
-        if (xf) release_wg();   // the S stores of this panel were issued a phase ago: they have landed by now
-        __syncthreads();   // Lp / XS are rewritten by the next panel
-        if (xf && t == 0) { flag_set(xf + p, 1u); if (k_blk < 24 && i_tile - k_blk <= 2) CH_MARK(3648 + (k_blk * 2 + (i_tile - k_blk - 1)) * 9 + p); }
+        if (xf && p >= CH_PANELS - 2) release_wg();   // the last two panels: what the next pivot block waits for -- drained and flagged at once
+        if (trc) CH_MARK(5920 + 5 * p + 4);
+        barrier_lds();   // Lp / XS are rewritten by the next panel
+        if (xf && t == 0) {
+            if (p >= CH_PANELS - 2) flag_set(xf + p, 1u);
+            if (k_blk < 24 && i_tile - k_blk <= 2) CH_MARK(3648 + (k_blk * 2 + (i_tile - k_blk - 1)) * 9 + p);
+        }
     }
 }
 
@@ -1062,13 +1120,25 @@ static_assert(INV_LDS_DOUBLES * 8 <= CH_LDS_BYTES, "inverter image must fit the 
 // so what is left behind the block's LAST event is one round trip, a 16 x 16 product and the stores.  (First incremental
 // version: T(p) was computed after its own loads, 256 threads, one LDS read per FMA: it fell ~2 us behind per panel over the
 // last panels and published the inverse 18-25 us after the pivot block -- no better than the recursive-doubling inverse.)
+// Round 6: both products on the matrix pipe.  The round-4 form above (thread (column, row group), operands as LDS reads per multiply-add)
+// needed ~49 us per 128-block: fine beside a pivot chain of 58 us per block, the new bound of everything once the chain took 41 -- the
+// inverse fell 8 us further behind with every block until the row solves that wait for it stalled the chain (N = 3000: 26, 32, 40, 48, 56,
+// 64 us behind the pivot over the first six blocks).  Now
+//     W[p, 0:p] = -W16_p T(p)                     2 p column blocks of 8, 8 MFMA each
+//     T(p+1)    =  L[p+1, 0:p+1] W[0:p+1, 0:p+1]  2 (p + 1) column blocks, contraction from the block's own rows on (W is lower triangular)
+// with the column blocks dealt to the eight waves in pairs (cb, 15 - cb) of equal total contraction length.  Wimg and Tl are read as B
+// operands (lane = (contraction index k, column)): their row stride is 128 and the column index is XOR-swizzled with 8 (k & 3), which puts
+// the four contraction indices of an operand fetch on different bank groups.
+#define INV_WIX(m, c) ((m) * TILE + ((c) ^ (((m) & 3) << 3)))
 __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, int64_t ld, double* __restrict__ W,
                                               double* __restrict__ WT, int64_t ldw, int T, const CholFlags& fl, double* sm) {
-    double* Wimg = sm;                         // [112][128]  W_kk rows 0..111 (zero above the diagonal)
-    double* Lrow = sm + INV_WROWS * TILE;      // [16][112]   rows of L_kk behind the next pivot block
-    double* Tl = Lrow + 16 * INV_WROWS;        // [16][128]   T(p), exchanged between the four row groups
-    double* W16s = Tl + 16 * TILE;             // [16][16]
-    const int tid = threadIdx.x, c = tid & 127, rq = tid >> 7;
+    double* Wimg = sm;                         // [112][128]  W_kk rows 0..111 (zero above the diagonal), swizzled
+    double* Tl = Wimg + INV_WROWS * TILE;      // [16][128]   T(p), swizzled
+    double* Lrow = Tl + 16 * TILE;             // [16][116]   rows of L_kk behind the next pivot block; at p = 7: the last row panel of W
+    double* W16s = Lrow + 16 * INV_LS;         // [16][20]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, bb = (lane >> 2) & 3, t4 = lane & 3;
+    const int ar = 4 * (bb >> 1) + t4, bc = 4 * (bb & 1) + t4, dr = 4 * (bb >> 1) + kq, dc = bc;
     for (int e = tid; e < INV_WROWS * TILE; e += CH_THREADS) Wimg[e] = 0.0;   // the strict upper triangle is never written again
     __syncthreads();
     for (int k = 0; k < T; ++k) {
@@ -1076,126 +1146,91 @@ __device__ __forceinline__ void inverter_role(const double* __restrict__ Lmat, i
         const double* Lblk = Lmat + off * (ld + 1);
         double* Wb = W + off * (ldw + 1);
         double* WTb = WT + off * (ldw + 1);
-        double t[4] = {0.0, 0.0, 0.0, 0.0};   // T(p): rows 4 rq .. 4 rq + 3, column c (c < 16 p)
         for (int p = 0; p < CH_PANELS; ++p) {
             const int R0 = 16 * p, R1 = R0 + 16;
+            const bool last = p + 1 == CH_PANELS;
             if (tid == 0) flag_wait_ge(fl.panel + k * CH_PANELS + p, fl.panel_want, fl.abort, fl.spin_ticks);
-            __syncthreads();
-            {   // ONE round trip of 16-byte agent-scope loads (as 8-byte atomic loads: up to 4 + 1 fabric reads per thread and panel)
+            __syncthreads();   // (also: everybody is done with the previous round's W16s / Lrow / row panel)
+            {   // ONE round trip of 16-byte agent-scope loads: W16_p and the rows of L behind the NEXT pivot block, columns < 16 (p + 1)
                 d2 uw, ul[2];
                 uw.x = uw.y = 0.0; ul[0] = uw; ul[1] = uw;
-                const int r = tid >> 5, mm = tid & 31;   // rows 16(p+1) .. of L_kk, columns < 16(p+1): 16-byte pieces 2 mm + 64 i
+                const int r = tid >> 5, mm = tid & 31;
                 const double* src = Lblk + (int64_t)(R1 + r) * ld;
                 if (tid < 128) ld_agent_x2_issue(fl.w16_g + ((size_t)k * CH_PANELS + p) * 256 + 2 * tid, uw);
-                if (p + 1 < CH_PANELS) {
+                if (!last) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
                         if (2 * mm + 64 * i < R1) ld_agent_x2_issue(src + 2 * mm + 64 * i, ul[i]);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(uw), "+v"(ul[0]), "+v"(ul[1]) : : "memory");
-                if (tid < 128) *reinterpret_cast<d2*>(W16s + 2 * tid) = uw;
-                if (p + 1 < CH_PANELS) {
+                if (tid < 128) *reinterpret_cast<d2*>(W16s + (tid >> 3) * WK_S + 2 * (tid & 7)) = uw;
+                if (!last) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        if (2 * mm + 64 * i < R1) *reinterpret_cast<d2*>(Lrow + r * INV_WROWS + 2 * mm + 64 * i) = ul[i];
+                        if (2 * mm + 64 * i < R1) *reinterpret_cast<d2*>(Lrow + r * INV_LS + 2 * mm + 64 * i) = ul[i];
                 }
-            }
-            if (p > 0 && c < R0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) Tl[(4 * rq + j) * TILE + c] = t[j];
             }
             __syncthreads();
-            double wn[4] = {0.0, 0.0, 0.0, 0.0};
-            if (p > 0 && c < R0) {   // the new rows 16p + 4 rq .. + 3 of W, column c: -W16 T
+            // the new rows 16p .. 16p+15 of W, columns < 16p: -W16 T(p)
+            for (int cbi = 0; cbi < 2; ++cbi) {
+                const int cb = cbi == 0 ? wave : 15 - wave;
+                if (cb >= 2 * p) continue;
+                double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int r = 4 * rq + j;
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int m = 0; m < 16; ++m)
-                        if (m <= r) sacc += W16s[r * 16 + m] * Tl[m * TILE + c];
-                    wn[j] = -sacc;
-                    if (p + 1 < CH_PANELS) Wimg[(R0 + r) * TILE + c] = wn[j];
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int kk = 4 * ks + kq;
+                    const double b = Tl[INV_WIX(kk, 8 * cb + bc)];
+                    a0 = mfma444(W16s[ar * WK_S + kk], b, a0);
+                    a1 = mfma444(W16s[(8 + ar) * WK_S + kk], b, a1);
+                }
+                if (!last) {
+                    Wimg[INV_WIX(R0 + dr, 8 * cb + dc)] = -a0;
+                    Wimg[INV_WIX(R0 + 8 + dr, 8 * cb + dc)] = -a1;
+                } else {
+                    Lrow[dr * INV_LS + 8 * cb + dc] = -a0;
+                    Lrow[(8 + dr) * INV_LS + 8 * cb + dc] = -a1;
                 }
             }
-            if (p + 1 < CH_PANELS && tid < 256) Wimg[(R0 + (tid >> 4)) * TILE + R0 + (tid & 15)] = W16s[tid];   // the diagonal block is W16 itself
+            if (!last && tid < 256) Wimg[INV_WIX(R0 + (tid >> 4), R0 + (tid & 15))] = W16s[(tid >> 4) * WK_S + (tid & 15)];   // the diagonal block is W16 itself
             __syncthreads();
-            if (p + 1 < CH_PANELS) {
-                // T(p+1), column c < 16(p+1): 8 contraction indices per round -- 8 + 16 LDS reads (the L rows as 16-byte pieces) for 32 FMAs
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = 0.0;
-                if (c < R1) {
-                    const double* lr = Lrow + 4 * rq * INV_WROWS;
-                    for (int m0 = 0; m0 < R1; m0 += 8) {
-                        double w[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) w[q] = Wimg[(m0 + q) * TILE + c];
-                        d2 l[4][4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) l[j][q] = *reinterpret_cast<const d2*>(lr + j * INV_WROWS + m0 + 2 * q);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                t[j] += l[j][q].x * w[2 * q];
-                                t[j] += l[j][q].y * w[2 * q + 1];
-                            }
+            if (!last) {
+                // T(p+1), columns < 16 (p + 1): column block cb contracts over the rows m >= 8 cb
+                for (int cbi = 0; cbi < 2; ++cbi) {
+                    const int cb = cbi == 0 ? wave : 15 - wave;
+                    if (cb >= 2 * p + 2) continue;
+                    double a0 = 0.0, a1 = 0.0;
+                    for (int ks = 2 * cb; ks < R1 / 4; ++ks) {
+                        const int kk = 4 * ks + kq;
+                        const double b = Wimg[INV_WIX(kk, 8 * cb + bc)];
+                        a0 = mfma444(Lrow[ar * INV_LS + kk], b, a0);
+                        a1 = mfma444(Lrow[(8 + ar) * INV_LS + kk], b, a1);
                     }
+                    Tl[INV_WIX(dr, 8 * cb + dc)] = a0;
+                    Tl[INV_WIX(8 + dr, 8 * cb + dc)] = a1;
                 }
-                // row panel p out, from the image: W rows (16-byte pieces along the row) and the same entries as columns of W'
-                {
-                    const int r = (tid & 255) >> 4, q = tid & 15, hh = tid >> 8;
-                    for (int u = (q >> 3) + 2 * hh; u <= p; u += 4) {
-                        const int col = 16 * u + 2 * (q & 7);
-                        const d2 v = *reinterpret_cast<const d2*>(Wimg + (R0 + r) * TILE + col);
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(Wb + (int64_t)(R0 + r) * ldw + col), "v"(v) : "memory");
-                    }
-                    if (c < R1) {
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const int rr = 2 * (2 * rq + e);
-                            d2 v;
-                            v.x = Wimg[(R0 + rr) * TILE + c];
-                            v.y = Wimg[(R0 + rr + 1) * TILE + c];
-                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTb + (int64_t)c * ldw + R0 + rr), "v"(v) : "memory");
-                        }
-                    }
+            }
+            // row panel p out: W rows (16-byte pieces along the row) and the same entries as columns of W'
+            {
+                auto wval = [&](int rr, int c) -> double {   // W[16p + rr][c], c < 16 (p + 1)
+                    if (!last) return Wimg[INV_WIX(R0 + rr, c)];
+                    return c < R0 ? Lrow[rr * INV_LS + c] : W16s[rr * WK_S + (c - R0)];
+                };
+                for (int e = tid; e < 16 * (R1 / 2); e += CH_THREADS) {   // rows of W
+                    const int rr = e / (R1 / 2), col = 2 * (e % (R1 / 2));
+                    d2 v;
+                    v.x = wval(rr, col); v.y = wval(rr, col + 1);
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(Wb + (int64_t)(R0 + rr) * ldw + col), "v"(v) : "memory");
                 }
-            } else {
-                // the last row panel goes out straight from the registers (rows 112 + 4 rq .. + 3, column c) and from W16
-                {   // rows of W: the even lane of a pair stores rows j = 0, 1 of both lanes' columns, the odd lane rows 2, 3 (16 bytes each)
-                    const bool odd = (c & 1) != 0;
-                    const double g0 = __shfl_xor(odd ? wn[0] : wn[2], 1), g1 = __shfl_xor(odd ? wn[1] : wn[3], 1);
-                    if (c < R0) {   // (R0 = 112 is even: both lanes of a pair are inside or outside)
-                        const int j0 = odd ? 2 : 0, cc = c & ~1;
-                        const double x0 = odd ? g0 : wn[0], y0 = odd ? wn[2] : g0;   // row j0:     columns cc, cc + 1
-                        const double x1 = odd ? g1 : wn[1], y1 = odd ? wn[3] : g1;   // row j0 + 1
-                        st_agent2(Wb + (int64_t)(R0 + 4 * rq + j0) * ldw + cc, x0, y0);
-                        st_agent2(Wb + (int64_t)(R0 + 4 * rq + j0 + 1) * ldw + cc, x1, y1);
-                    }
-                }
-                if (c < R0) {
-                    d2 v0, v1;
-                    v0.x = wn[0]; v0.y = wn[1]; v1.x = wn[2]; v1.y = wn[3];
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq), "v"(v0) : "memory");
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTb + (int64_t)c * ldw + R0 + 4 * rq + 2), "v"(v1) : "memory");
-                }
-                if (tid < 256) {
-                    const int r = tid >> 4, j = tid & 15;
-                    if (j <= r) {
-                        st_agent(Wb + (int64_t)(R0 + r) * ldw + R0 + j, W16s[tid]);
-                        st_agent(WTb + (int64_t)(R0 + j) * ldw + R0 + r, W16s[tid]);
-                    }
+                for (int e = tid; e < 8 * R1; e += CH_THREADS) {   // columns of W': row c of W', entries 16p + 2 j, 16p + 2 j + 1
+                    const int c = e % R1, j = e / R1;
+                    d2 v;
+                    v.x = wval(2 * j, c); v.y = wval(2 * j + 1, c);
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(WTb + (int64_t)c * ldw + R0 + 2 * j), "v"(v) : "memory");
                 }
             }
         }
         release_wg();
         __syncthreads();
-#ifdef BOHIP_INV_DELAY_TICKS   // (sensitivity experiment: publish the inverse this many 10 ns ticks late)
-        if (tid == 0) { const unsigned long long t0_ = wall_clock64(); while (wall_clock64() - t0_ < BOHIP_INV_DELAY_TICKS) __builtin_amdgcn_s_sleep(1); }
-#endif
         if (tid == 0) { flag_set(fl.solved + k, 1u); CH_MARK(4096 + k); }
     }
 }

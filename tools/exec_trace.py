@@ -196,3 +196,9 @@ if qb[4] > qb[3] and not GRP:
         if i < 8 or i % 4 == 0 or i >= T - 3:
             print(f"  row {i:3d}: {e - pe:8.1f} | {'' if prev is None else f'{e - prev:7.1f}'}")
         prev = e
+
+# round 6: solve follower 1 of block 5, phase marks inside follow_block (thread 0 = wave 0): panel start | staged (before the barrier) | barrier passed | solved + barrier | updated (before the barrier)
+if ct[5920] > 0:
+    print("solve follower 1, block 5, per panel (us since its first panel started): start | staged | +barrier | solved+barrier | updated")
+    for p_ in range(8):
+        print("  panel", p_, [round((ct[5920 + 5 * p_ + j] - ct[5920]) / 100.0, 2) for j in range(5)], "| inside the solve (wave 0): products done, stores issued", [round((ct[5960 + 3 * p_ + j] - ct[5920]) / 100.0, 2) for j in range(2)])
