@@ -152,6 +152,9 @@ def defaultoptions(model_type, acq_type):                    # :4-9
     return dict(method="LD_LBFGS", restarts=10, maxeval=2000)
 
 
+ASC_GTOL_ABS = 1e-10   # kernels_ascent.hip: the gradient method's own tolerance (SciPy gtol / PLIS TOLG), absolute
+
+
 def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-10, history=8, ftol_abs=0.0, xtol_rel=0.0,
                           stopval=math.inf):
     """Lock-step projected L-BFGS ascent of R independent d-dimensional problems (role of NLopt :LD_LBFGS
@@ -163,7 +166,11 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
     f, G = fg(X)
     evals = 1
     S, Y = [], []
-    active = np.isfinite(f)
+    def grad_live(X_, G_):   # kernels_ascent.hip asc_grad_live: some free coordinate has |g| above the absolute gradient tolerance
+        held = ((X_ <= lbc) & (G_ < 0)) | ((X_ >= ubc) & (G_ > 0))
+        return ((~held) & (np.abs(G_) > ASC_GTOL_ABS)).any(axis=0)
+
+    active = np.isfinite(f) & grad_live(X, G)
     best_f, best_X = f.copy(), X.copy()
     while evals < maxeval and active.any():
         # two-loop recursion, vectorised over columns, in the FREE SUBSPACE of every column: a coordinate on a bound with the gradient
@@ -220,6 +227,7 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
         active = active & (df > ftol_abs) & ~(fn >= stopval)
         if xtol_rel > 0.0:
             active = active & (np.abs(s_) > xtol_rel * np.abs(Xn)).any(axis=0)
+        active = active & grad_live(Xn, Gn)
         good = np.einsum("dr,dr->r", s_, y_) > 1e-14
         S.append(np.where(good, s_, 0.0)); Y.append(np.where(good, y_, 0.0))
         if len(S) > history:

@@ -153,6 +153,7 @@ struct bohip_gp {
     // one-process-per-device exchange (multigpu.hip): communicator attached by bohip_gp_comm_init
     void* comm = nullptr;
     int comm_rank = 0, comm_n = 0;
+    int64_t comm_exchanges = 0;        // BOHIP_INFO_COMM_EXCHANGES: all-gathers this handle has issued on its communicator
     Best *csend = nullptr, *crecv = nullptr, *cfinal = nullptr;
     int64_t crec_cap = 0;
     // bookkeeping
@@ -2952,10 +2953,10 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     if (free_run) {
         // no synchronisation here: how many start points are active at all is counted by the adopt kernel into the ring slot the host reads
         // once the first pass is queued (below)
-        hipLaunchKernelGGL(k_asc_adopt_count, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, ASC_RING - 1);
+        hipLaunchKernelGGL(k_asc_adopt_count, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, ASC_RING - 1, dlb, dub);
         HIPCHK(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d);
+        hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d, dlb, dub);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(g->stream));
         any_active = any_of(st.h_active, 1);
@@ -3025,7 +3026,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
             if (!any_of(st.h_accepted, 0) || evals >= maxeval || !any_active) break;
         }
         if (!any_active) { --evals; break; }   // the speculative evaluation of an already converged set is not counted
-        hipLaunchKernelGGL(k_asc_update, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, it % ASC_M, ftol_rel, xtol_abs);
+        hipLaunchKernelGGL(k_asc_update, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, it % ASC_M, ftol_rel, xtol_abs, dlb, dub);
         nh = std::min(nh + 1, ASC_M);
         ++it;
     }
@@ -3111,6 +3112,8 @@ int bohip_gp_get_alpha(bohip_gp* g, double* alpha) {
     HIPCHK(hipStreamSynchronize(g->stream));
     return 0;
 }
+static int comm_nranks(const bohip_gp* g, int64_t* value);
+static int comm_rccl_version(int64_t* value);
 int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
     if (!g || !value) return fail(BOHIP_E_ARG, "null argument");
     switch (what) {
@@ -3134,6 +3137,9 @@ int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
             if (c[1] > 0) *value = (int64_t)((double)c[0] / (double)c[1] * 100.0 + 0.5);   // wall_clock64 ticks at 100 MHz
             return 0;
         }
+        case BOHIP_INFO_COMM_NRANKS: return comm_nranks(g, value);   // read back from the communicator (multigpu.hip)
+        case BOHIP_INFO_COMM_EXCHANGES: *value = g->comm_exchanges; return 0;
+        case BOHIP_INFO_COMM_RCCL_VERSION: return comm_rccl_version(value);
         default: return fail(BOHIP_E_ARG, "unknown info id");
     }
 }

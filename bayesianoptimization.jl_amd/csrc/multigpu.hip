@@ -37,6 +37,7 @@ struct RcclApi {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -59,7 +60,7 @@ static RcclApi* rccl_api() {
         bool ok = true;
 #define BIND(field, sym) ok = ((api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, #sym))) != nullptr) && ok
         BIND(GetVersion, ncclGetVersion); BIND(GetUniqueId, ncclGetUniqueId); BIND(CommInitRank, ncclCommInitRank);
-        BIND(CommInitAll, ncclCommInitAll); BIND(CommDestroy, ncclCommDestroy); BIND(AllGather, ncclAllGather);
+        BIND(CommInitAll, ncclCommInitAll); BIND(CommDestroy, ncclCommDestroy); BIND(AllGather, ncclAllGather); BIND(CommCount, ncclCommCount);
         BIND(GroupStart, ncclGroupStart); BIND(GroupEnd, ncclGroupEnd); BIND(GetErrorString, ncclGetErrorString);
 #undef BIND
         if (!ok) { api.error = "librccl lacks a required symbol"; api.lib = nullptr; }
@@ -561,6 +562,23 @@ int bohip_mgp_set_jitter(bohip_mgp* m, double rel, int max_tries) {
 }
 bohip_gp* bohip_mgp_handle(bohip_mgp* m, int i) { return (m && i >= 0 && i < m->nd) ? m->h[i] : nullptr; }
 
+// BOHIP_INFO_COMM_NRANKS of a handle: what the communicator itself says (ncclCommCount), not what the caller passed to comm_init
+static int comm_nranks(const bohip_gp* g, int64_t* value) {
+    *value = 0;
+    if (!g->comm) return 0;
+    int n = 0;
+    RCCL_OR_FAIL(R);
+    NCCLCHK(R->CommCount((ncclComm_t)g->comm, &n));
+    *value = n;
+    return 0;
+}
+static int comm_rccl_version(int64_t* value) {
+    int v = 0;
+    RCCL_OR_FAIL(R);
+    NCCLCHK(R->GetVersion(&v));
+    *value = v;
+    return 0;
+}
 int bohip_mgp_info(const bohip_mgp* m, int what, int64_t* value) {
     if (!m || !value) return fail(BOHIP_E_ARG, "null argument");
     switch (what) {
@@ -572,6 +590,15 @@ int bohip_mgp_info(const bohip_mgp* m, int what, int64_t* value) {
             RCCL_OR_FAIL(R);
             NCCLCHK(R->GetVersion(&v));
             *value = v;
+            return 0;
+        }
+        case BOHIP_MGP_INFO_COMM_NRANKS: {   // ncclCommCount of the communicator the records travel over (0: one device, no communicator)
+            *value = 0;
+            if (m->comm.empty() || !m->comm[0]) return 0;
+            int n = 0;
+            RCCL_OR_FAIL(R);
+            NCCLCHK(R->CommCount(m->comm[0], &n));
+            *value = n;
             return 0;
         }
         default: return fail(BOHIP_E_ARG, "unknown info id");
@@ -651,6 +678,7 @@ int bohip_gp_score_sharded_dev(bohip_gp* g, int acq_id, const double* acq_params
     t_begin(g, "exchange");
     RCCL_OR_FAIL(R);
     NCCLCHK(R->AllGather(g->csend, g->crecv, 2, ncclInt64, (ncclComm_t)g->comm, g->stream));
+    g->comm_exchanges++;
     hipLaunchKernelGGL(k_reduce_records, dim3(1), dim3(256), 0, g->stream, g->crecv, g->comm_n, 1, reinterpret_cast<Best*>(best));
     HIPCHK(hipGetLastError());
     t_end(g);
@@ -680,6 +708,7 @@ int bohip_gp_thompson_sharded(bohip_gp* g, const double* Xs, int64_t R_local, in
     HIPCHK(hipGetLastError());
     RCCL_OR_FAIL(R);
     NCCLCHK(R->AllGather(g->csend, g->crecv, (size_t)(2 * S), ncclInt64, (ncclComm_t)g->comm, g->stream));
+    g->comm_exchanges++;
     hipLaunchKernelGGL(k_reduce_records, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, g->stream, g->crecv, g->comm_n, (int)S,
                        g->cfinal);
     HIPCHK(hipGetLastError());

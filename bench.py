@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_OBS, DIM, R_PER_GPU = 3000, 8, 4096
+SPIN_S = float(os.environ.get("BOHIP_BENCH_SPIN_S", "4"))   # untimed repetition of the step for an outside activity sampler (reported as untimed_spin_s)
 STRONG_R_TOTAL = 32768   # --strong: BASELINE configs[2] (R = 32768 restarts in total) at every --gpus
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix = vector peak (256 CU x 4 SIMD x 2.4 GHz x 32 FLOP/clk); the
 #                          MICROARCH guide lists no FP64 row; tools/ubench_fp64b.hip measures 73 TF/s sustained.
@@ -104,6 +105,7 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
     t0 = time.perf_counter()
     orc.score_grad(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], gsample)   # cpu-ref-grad-1t: value + analytic gradient
     tg = time.perf_counter() - t0
+    search = default_search_on_oracle(orc, X, y, ll, L, alpha, tau)
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -120,9 +122,45 @@ def cpu_baseline(X, y, Xs, tau, budget_candidates=1536):
         "allcores": {"value": len(big) / tn, "cores": ncores, "sample": f"{len(big)} candidates, {tn:.1f} s"},
         "with_gradient": {"value": len(gsample) / tg, "cores": 1, "sample": f"{len(gsample)} candidates, {tg:.1f} s "
                           "(the reference's default :LD_LBFGS path evaluates value and gradient)"},
+        "default_search": search,
         "cholesky": {"gflops": (N_OBS ** 3 / 3.0) / t_chol / 1e9, "cores": 1, "sample": f"N={N_OBS}, {t_chol:.1f} s (row-by-row scalar port)", **lapack},
         "cpu_model": cpu_model, "host_cores": os.cpu_count(),
     }
+
+
+BETA_T = 10.152008469453344   # BrochuBetaScaling(0.1) at N=3000, d=8 (src/acquisitionfunctions.jl:91-95)
+
+
+def default_search_on_oracle(orc, X, y, ll, L, alpha, tau):
+    """cpu_baseline leg: what the reference's DEFAULT search (src/acquisition.jl:4-6: :LD_LBFGS, 10 restarts, maxeval 2000) costs on the CPU
+    restatement -- SciPy's L-BFGS-B (bounds, ftol = gtol = 1e-10) maximising the oracle's value + analytic gradient from the same ten
+    Latin-hypercube starts `default_usage` / `default_usage_ei` use on the device: evaluations per start, the best end value, seconds."""
+    try:
+        from scipy.optimize import minimize
+    except Exception as e:      # noqa: BLE001
+        return {"note": f"SciPy unavailable: {e}"}
+    starts = lhs(10, seed=7)
+    out = {}
+    for acq, prm in (("UCB", [BETA_T]), ("EI", [tau])):
+        nf, fs = [], []
+        t0 = time.perf_counter()
+        for r in range(len(starts)):
+            cnt = [0]
+
+            def negfg(x):
+                cnt[0] += 1
+                sc, g = orc.score_grad(X, ll, 0.0, 0.0, L, alpha, acq, prm, x[None, :].copy())
+                return -float(sc[0]), -g[0]
+
+            res = minimize(negfg, starts[r], jac=True, method="L-BFGS-B", bounds=[(0.0, 1.0)] * DIM,
+                           options=dict(maxiter=2000, maxfun=2000, ftol=1e-10, gtol=1e-10))
+            nf.append(cnt[0])
+            fs.append(-float(res.fun))
+        out[acq] = {"evaluations_per_start": nf, "max_evaluations_per_start": int(max(nf)), "evaluations": int(sum(nf)),
+                    "best_value": float(max(fs)), "seconds": time.perf_counter() - t0, "cores": 1}
+    out["note"] = ("SciPy L-BFGS-B on oracle/gp_oracle.c, one start after the other (as the reference's loop does); the device runs all ten "
+                   "starts in lock-free passes: compare max_evaluations_per_start with default_usage*.evaluations")
+    return out
 
 
 def traffic_child():
@@ -412,12 +450,12 @@ def main_single_process(args):
         for name, ms in model.timing(4096):
             stage_sum[name] = stage_sum.get(name, 0.0) + ms
         clock_mhz = model.info(_lib.INFO_KERNEL_CLOCK_MHZ)   # core clock under k_trigemm_sq over the timed region (sampled workgroups)
-        # UNTIMED: eleven more seconds of the same step, so that a coarse GPU-activity sampler around this process (one sample every 5 s)
-        # sees the device busy at least twice (the timed region is ~20 ms of a run whose remainder is the CPU baseline; one second was
-        # not enough: `gpu_busy` read 0 in three rounds running)
+        # UNTIMED: a few more seconds of the same step, so that a coarse GPU-activity sampler around this process (one sample every 5 s)
+        # sees the device busy (the timed region is ~20 ms of a run whose remainder is side figures and the CPU baseline); the JSON says
+        # so (untimed_spin_s).  BOHIP_BENCH_SPIN_S overrides.
         model.enable_timing(0)
         t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < float(os.environ.get("BOHIP_BENCH_SPIN_S", "11")):
+        while time.perf_counter() - t_spin < SPIN_S:
             step()
         n_launch = C.c_int64(0)
         _lib.check(lib.bohip_gp_info(model._h, _lib.INFO_SCORE_LAUNCHES, C.byref(n_launch)))
@@ -425,7 +463,12 @@ def main_single_process(args):
                  "host_buffers_note": "same workload through bohip_gp_score: host X* in (pageable, 256 KB H2D inside the "
                                       "call), 16-byte record out; `value` is the HBM-resident rate",
                  "host_buffers_same_winner": bool(hv == val and hi == idx)}
+        extra["untimed_spin_s"] = SPIN_S   # (gpu_busy of an outside sampler reflects this untimed repetition of the step, not the timed region)
         extra["default_usage"] = default_usage(model, tau)
+        extra["default_usage_ei"] = default_usage(model, tau, "EI")
+        extra["thompson_default"] = thompson_default(model)
+        extra["thompson_c5"] = thompson_c5(model)
+        # (last user of `model`: the call changes the hyper-parameters' staleness, nothing after it looks at the model)
         extra["mll_grad_ms"] = {"N=3000": mll_grad_ms(model)}      # value + gradient of the marginal likelihood (optimizemodel!)
         if not args.no_c4:
             extra["cholesky_c4"] = cholesky_c4(bohip)
@@ -470,45 +513,126 @@ def main_single_process(args):
     lib.bohip_gp_enable_timing(g0, 3)
     step()
     timing0()
+    ex0 = model.info(_lib.MGP_INFO_EXCHANGES)
     elapsed, (val, idx) = timed(args, step, torch.cuda.synchronize)
     stage_sum = {}
     for name, ms in timing0():
         stage_sum[name] = stage_sum.get(name, 0.0) + ms / spd   # per shard launch
+    ex1 = model.info(_lib.MGP_INFO_EXCHANGES)
     mode = f"one process, {len(devices)} device(s) x {spd} shard(s), in-library RCCL {model.info(_lib.MGP_INFO_RCCL_VERSION)}"
     n_launch = C.c_int64(0)
     lib.bohip_gp_info(g0, _lib.INFO_SCORE_LAUNCHES, C.byref(n_launch))
-    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode,
-           {"_launches": int(n_launch.value), "_shards_per_device": spd}, n_devices=len(devices))
+    # the collective, read back from the communicator itself: a line that claims N GPUs must have exchanged over N ranks
+    nranks = model.info(_lib.MGP_INFO_COMM_NRANKS)
+    if len(devices) > 1 and nranks != len(devices):
+        raise SystemExit(f"bench.py --gpus {G}: the in-library communicator has {nranks} ranks, expected {len(devices)}")
+    extra = {"_launches": int(n_launch.value), "_shards_per_device": spd,
+             "rccl": {"nranks": int(nranks), "version": int(model.info(_lib.MGP_INFO_RCCL_VERSION)),
+                      "allgathers_per_step": (ex1 - ex0) / float(args.steps), "read_from": "ncclCommCount / ncclGetVersion / the library's exchange counter"}}
+    if not args.strong and STRONG_R_TOTAL % G == 0:
+        # BASELINE configs[2] beside the weak-scaling line: R = 32768 in total over the same devices
+        Xs_s = lhs(STRONG_R_TOTAL, seed=1)
+        model.set_candidates(Xs_s.T)
+        for _ in range(3):
+            step()
+        el_s, (v_s, i_s) = timed(args, step, torch.cuda.synchronize)
+        extra["configs2_strong"] = {"workload": f"BASELINE configs[2]: R = {STRONG_R_TOTAL} restarts in total over {len(devices)} device(s)",
+                                    "R_total": STRONG_R_TOTAL, "ms_per_step": el_s / args.steps * 1e3, "value": STRONG_R_TOTAL * args.steps / el_s,
+                                    "unit": "candidates/s", "best": {"value": v_s, "index": i_s}}
+    report(args, G, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, extra, n_devices=len(devices))
 
 
-def default_usage(model, tau):
+def default_usage(model, tau, acq="UCB"):
     """What the reference does BY DEFAULT (src/acquisition.jl:4-6: method :LD_LBFGS, restarts 10, maxeval 2000) on the headline
     model: acquire_max = 10 Latin-hypercube starts, each refined by a gradient-based local search.  On the device all starts
     advance on their own schedule (bohip_gp_acquire_max, free-running driver): one value + gradient pass of the model per evaluation.  Reported beside the
-    headline metric; the CPU figure to hold against it is cpu_baseline.with_gradient (one candidate's value + gradient at a time)."""
+    headline metric; the CPU figures to hold against it are cpu_baseline.with_gradient (one candidate's value + gradient at a time) and
+    cpu_baseline.default_search (SciPy's L-BFGS-B on the oracle from the same starts).
+    acq = "UCB": the README's acquisition at BrochuBetaScaling's beta_t;  acq = "EI": the DEFAULT acquisition of `BOpt`
+    (src/BayesianOptimization.jl:265) at tau = max y -- BASELINE configs[1]'s acquisition through the default search."""
     R = 10
     starts = np.asfortranarray(lhs(R, seed=7).T)
     lb, ub = np.zeros(DIM), np.ones(DIM)
-    beta_t = 10.152008469453344   # BrochuBetaScaling(0.1) at N=3000, d=8 (src/acquisitionfunctions.jl:91-95; SURVEY.md 8 A6)
-    model.ascend("UCB", [beta_t], lb, ub, starts, 2000)
+    prm = [BETA_T] if acq == "UCB" else [tau]
+    model.ascend(acq, prm, lb, ub, starts, 2000)
     runs = []
     for _ in range(5):
         t0 = time.perf_counter()
-        f, Xb, bf, bi, bx, ev = model.ascend("UCB", [beta_t], lb, ub, starts, 2000)
+        f, Xb, bf, bi, bx, ev = model.ascend(acq, prm, lb, ub, starts, 2000)
         runs.append((time.perf_counter() - t0, ev))
     t, ev = sorted(runs)[len(runs) // 2]
     sg = []
     for _ in range(20):
         t0 = time.perf_counter()
-        model.score_grad("UCB", [beta_t], starts)
+        model.score_grad(acq, prm, starts)
         sg.append(time.perf_counter() - t0)
-    return {"workload": f"acquire_max, N={N_OBS}, d={DIM}, UpperConfidenceBound (BrochuBetaScaling, the README's acquisition), 10 restarts, "
-                        ":LD_LBFGS (the reference's defaultoptions)",
-            "acquire_max_ms": t * 1e3, "evaluations": int(ev), "us_per_evaluation": t / max(ev, 1) * 1e6,
-            "score_grad_call_us": float(np.median(sg)) * 1e6, "best": {"value": float(bf), "index": int(bi)},
-            "note": "an evaluation = value + gradient of all 10 starts in one pass (round 5: two kernels, K*' + V' + posterior and U' + gradient, kernels_small.hip); "
-                    "compare with 10 / cpu_baseline.with_gradient.value seconds per such pass on one CPU core",
-            "small_model": default_usage_small()}
+    name = ("UpperConfidenceBound (BrochuBetaScaling, the README's acquisition)" if acq == "UCB" else
+            "ExpectedImprovement at tau = max y (the default acquisition of BOpt, src/BayesianOptimization.jl:265)")
+    out = {"workload": f"acquire_max, N={N_OBS}, d={DIM}, {name}, 10 restarts, :LD_LBFGS, maxeval 2000 (the reference's defaultoptions)",
+           "acquire_max_ms": t * 1e3, "evaluations": int(ev), "us_per_evaluation": t / max(ev, 1) * 1e6,
+           "score_grad_call_us": float(np.median(sg)) * 1e6, "best": {"value": float(bf), "index": int(bi)},
+           "end_values": [float(v) for v in f],
+           "note": "an evaluation = value + gradient of all 10 starts in one pass (two kernels, K*' + V' + posterior and U' + gradient, kernels_small.hip); "
+                   "compare with 10 / cpu_baseline.with_gradient.value seconds per such pass on one CPU core"}
+    if acq == "UCB":
+        out["small_model"] = default_usage_small()
+    else:
+        out["note_ei"] = ("EI at a Latin-hypercube start of this model is 1e-20 .. 1e-70 with a gradient to match: a gradient method's own tolerance "
+                          "(SciPy gtol, PLIS TOLG behind NLopt; here ASC_GTOL_ABS = 1e-10 on the projected gradient, kernels_ascent.hip) ends such a "
+                          "start at its first evaluation -- cpu_baseline.default_search.EI shows SciPy on the oracle doing the same")
+    return out
+
+
+def thompson_default(model):
+    """The reference's default for ThompsonSamplingSimple (src/acquisition.jl:7-9: :GN_DIRECT_L, restarts 1, maxeval 2000, one posterior draw
+    per point, src/acquisitionfunctions.jl:107-108) on the headline model: the batched dividing-rectangles search of the host mirror
+    (acquisition._batched_direct_l: every iteration's new points in ONE predict_f call)."""
+    from bohip.acquisition import ThompsonSamplingSimple, acquire_max, defaultoptions
+    calls = {"n": 0, "pts": 0}
+    pf = model.predict_f
+
+    def counted(xs):
+        calls["n"] += 1
+        calls["pts"] += int(np.shape(xs)[1]) if np.ndim(xs) == 2 else 1
+        return pf(xs)
+
+    model.predict_f = counted
+    try:
+        opts = defaultoptions(type(model), ThompsonSamplingSimple)
+        lb, ub = np.zeros(DIM), np.ones(DIM)
+        acquire_max(ThompsonSamplingSimple(), model, lb, ub, opts, rng=np.random.default_rng(5), setparams=False)
+        runs = []
+        for i in range(3):
+            calls["n"] = calls["pts"] = 0
+            t0 = time.perf_counter()
+            acquire_max(ThompsonSamplingSimple(), model, lb, ub, opts, rng=np.random.default_rng(6 + i), setparams=False)
+            runs.append((time.perf_counter() - t0, calls["n"], calls["pts"]))
+    finally:
+        del model.predict_f
+    t, n, pts = sorted(runs)[1]
+    return {"workload": f"acquire_max, N={N_OBS}, d={DIM}, ThompsonSamplingSimple, :GN_DIRECT_L, restarts 1, maxeval 2000 (the reference's defaultoptions)",
+            "acquire_max_ms": t * 1e3, "device_calls": int(n), "direct_iterations": int(n) - 1, "evaluations": int(pts),
+            "us_per_device_call": t / max(n, 1) * 1e6,
+            "note": "one predict_f call per DIRECT iteration (all of its new rectangle centres); the draws are taken on the host from the call's mu / sigma^2"}
+
+
+def thompson_c5(model):
+    """BASELINE configs[4] on ONE GPU: 1024 posterior draws x 65536 candidates (d = 8, N = 3000): bohip_gp_thompson = mu / sigma^2 of all
+    candidates (k_kstar + k_trigemm_sq, 16 chunks) + k_thompson (counter-based normals, arg-max per draw, S x R never materialised)."""
+    R, S = 65536, 1024
+    Xs = np.asfortranarray(np.random.default_rng(2).random((DIM, R)))
+    model.enable_timing(True)
+    model.thompson(Xs, S, seed=7)
+    runs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        model.thompson(Xs, S, seed=7)
+        runs.append((time.perf_counter() - t0, dict(model.timing())))
+    model.enable_timing(0)
+    t, st = sorted(runs, key=lambda r: r[0])[1]
+    return {"workload": f"N={N_OBS}, d={DIM}, {S} draws x {R} candidates, one GPU (host X* in)", "host_call_ms": t * 1e3, "draws_per_s": S * R / t,
+            "kernel_ms": st.get("thompson"), "kernel_draws_per_s": S * R / (st["thompson"] * 1e-3) if st.get("thompson") else None,
+            "stage_ms": st}
 
 
 def default_usage_small():
@@ -703,17 +827,59 @@ def main():
         step()
         model.timing(4096)          # (drop the barrier step's event records)
 
+    ex0 = model.info(_lib.INFO_COMM_EXCHANGES)
     elapsed, (val, idx) = timed(args, step, torch.cuda.synchronize, step_barrier, barrier_after=False)
+    ex1 = model.info(_lib.INFO_COMM_EXCHANGES)
     stage_sum = {}
     for name, ms in model.timing(4096):
         stage_sum[name] = stage_sum.get(name, 0.0) + ms
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    extra = {"_launches": model.info(_lib.INFO_SCORE_LAUNCHES)}
+    if in_library:
+        # the collective, read back from the communicator itself: a line that claims N GPUs must have exchanged over N ranks
+        nranks = model.info(_lib.INFO_COMM_NRANKS)
+        if nranks != world:
+            raise SystemExit(f"[rank {rank}] bench.py --gpus {world}: the communicator has {nranks} ranks")
+        extra["rccl"] = {"nranks": int(nranks), "version": int(model.info(_lib.INFO_COMM_RCCL_VERSION)),
+                         "allgathers_per_step": (ex1 - ex0 - 1) / float(args.steps),   # (- 1: the collective step that serves as the opening barrier)
+                         "read_from": "ncclCommCount / the handle's exchange counter"}
+    if not args.strong and STRONG_R_TOTAL % world == 0:
+        # BASELINE configs[2] beside the weak-scaling line: R = 32768 in total, this rank's contiguous shard
+        R_s = STRONG_R_TOTAL // world
+        Xs_s = lhs(STRONG_R_TOTAL, seed=1)
+        lo_s = rank * R_s
+        dXs_s = torch.from_numpy(np.ascontiguousarray(Xs_s[lo_s:lo_s + R_s])).to(dev)
+        d_best_s = torch.tensor([0, -1, lo_s], dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        if not in_library:
+            model.set_batch_hint(STRONG_R_TOTAL)
+
+        def step_s():
+            if in_library:
+                model.score_sharded_dev("EI", [tau], dXs_s.data_ptr(), R_s, lo_s, STRONG_R_TOTAL, h_best.data_ptr())
+                _lib.check(lib.bohip_gp_synchronize(model._h))
+                i = int(h_best_np[1])
+                return (float(h_best_np[:1].view(np.float64)[0]), i) if i >= 0 else (-np.inf, -1)
+            _lib.check(lib.bohip_gp_score_dev(model._h, _lib.ACQ["EI"], params, C.c_void_p(dXs_s.data_ptr()), R_s, None, C.c_void_p(d_best_s.data_ptr())))
+            _lib.check(lib.bohip_gp_synchronize(model._h))
+            return allgather_best(d_best_s, lo_s, world, force_collective=True)
+
+        model.enable_timing(0)
+        for _ in range(5):
+            step_s()
+        el_s, (v_s, i_s) = timed(args, step_s, torch.cuda.synchronize, step_s, barrier_after=False)
+        t = torch.tensor([el_s], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el_s = float(t.item())
+        extra["configs2_strong"] = {"workload": f"BASELINE configs[2]: R = {STRONG_R_TOTAL} restarts in total, sharded over {world} rank(s)",
+                                    "R_total": STRONG_R_TOTAL, "ms_per_step": el_s / args.steps * 1e3, "value": STRONG_R_TOTAL * args.steps / el_s,
+                                    "unit": "candidates/s", "best": {"value": v_s, "index": i_s}}
     if rank == 0:
         mode = ("one process per GPU, in-library RCCL (bohip_gp_score_sharded_dev)" if in_library
                 else f"one process per GPU, TEST exchange through torch.distributed/{backend}")
-        report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, {"_launches": model.info(_lib.INFO_SCORE_LAUNCHES)})
+        report(args, world, elapsed, stage_sum, info_ms, fit_ms, val, idx, X, y, Xs_all, tau, mode, extra)
     if in_library:
         model.comm_destroy()
     dist.destroy_process_group()

@@ -179,6 +179,9 @@ int bohip_gp_get_alpha(bohip_gp *gp, double *alpha);
 #define BOHIP_INFO_SCORE_CHUNK 9  /* candidates per K*' chunk of the last scoring call (equal-sized multiples of 512) */
 #define BOHIP_INFO_KERNEL_CLOCK_MHZ 10 /* core clock the chip sustained under k_trigemm_sq since the previous read (timing enabled:
                                         * a sample of its workgroups counts core-clock cycles against the 100 MHz wall clock), else 0 */
+#define BOHIP_INFO_COMM_NRANKS 11 /* ranks of the communicator attached by bohip_gp_comm_init, read back from it (ncclCommCount); 0: none */
+#define BOHIP_INFO_COMM_RCCL_VERSION 13 /* ncclGetVersion of the RCCL the library bound (loads it if no multi-GPU call has yet) */
+#define BOHIP_INFO_COMM_EXCHANGES 12 /* RCCL all-gathers this handle has issued so far (bohip_gp_score_sharded_dev / _thompson_sharded) */
 int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
 /* Benchmarks only (bench.py, tools/): the executor form of the factorisation grows W = L^-1 behind the pivot chain in
  * pieces of `blocks` 128-blocks (default 8).  0 switches those queues off -- the factorisation then runs alone and can
@@ -244,6 +247,7 @@ bohip_gp *bohip_mgp_handle(bohip_mgp *mgp, int i); /* replica on the i-th listed
 #define BOHIP_MGP_INFO_SHARDS 1
 #define BOHIP_MGP_INFO_EXCHANGES 2    /* RCCL all-gathers performed so far */
 #define BOHIP_MGP_INFO_RCCL_VERSION 3
+#define BOHIP_MGP_INFO_COMM_NRANKS 4   /* ranks of the in-library communicator, read back from it (ncclCommCount); 0: one device */
 int bohip_mgp_info(const bohip_mgp *mgp, int what, int64_t *value);
 
 /* ---- one process per device (torch.distributed.run, Distributed.jl, MPI) ----------------------------------
