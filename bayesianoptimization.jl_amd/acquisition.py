@@ -152,7 +152,7 @@ def defaultoptions(model_type, acq_type):                    # :4-9
     return dict(method="LD_LBFGS", restarts=10, maxeval=2000)
 
 
-ASC_GTOL_ABS = 1e-10   # kernels_ascent.hip: the gradient method's own tolerance (SciPy gtol / PLIS TOLG), absolute
+ASC_MAX_BT = 30   # kernels_ascent.hip: trial points per line search
 
 
 def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-10, history=8, ftol_abs=0.0, xtol_rel=0.0,
@@ -166,11 +166,7 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
     f, G = fg(X)
     evals = 1
     S, Y = [], []
-    def grad_live(X_, G_):   # kernels_ascent.hip asc_grad_live: some free coordinate has |g| above the absolute gradient tolerance
-        held = ((X_ <= lbc) & (G_ < 0)) | ((X_ >= ubc) & (G_ > 0))
-        return ((~held) & (np.abs(G_) > ASC_GTOL_ABS)).any(axis=0)
-
-    active = np.isfinite(f) & grad_live(X, G)
+    active = np.isfinite(f)
     best_f, best_X = f.copy(), X.copy()
     while evals < maxeval and active.any():
         # two-loop recursion, vectorised over columns, in the FREE SUBSPACE of every column: a coordinate on a bound with the gradient
@@ -204,11 +200,14 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
         bad = ~(slope > 0)
         D[:, bad] = Gp[:, bad]
         slope = np.einsum("dr,dr->r", Gp, D)
-        step = np.ones(R) if S else 1.0 / np.maximum(np.sqrt(np.einsum("dr,dr->r", D, D)), 1e-12) * 0.1 * np.min(ub - lb + 1e-300)
+        if S:
+            step = np.ones(R)
+        else:                                                     # the FIRST step (kernels_ascent.hip asc_direction_one): L-BFGS-B's unit step to P(x + g),
+            step = np.maximum(1.0, 0.1 * np.min(ub - lb + 1e-300) / np.maximum(np.sqrt(np.einsum("dr,dr->r", D, D)), 1e-12))   # but never shorter than a tenth of the box
         step = np.where(active & (slope > 0), step, 0.0)
         accepted = ~active | ~(slope > 0)
         Xn, fn, Gn = X.copy(), f.copy(), G.copy()
-        for _ in range(12):                                       # backtracking Armijo, all columns per device call
+        for _ in range(ASC_MAX_BT):                               # backtracking Armijo, all columns per device call
             Xt = np.clip(X + step * D, lbc, ubc)
             ft, Gt = fg(Xt)
             evals += 1
@@ -227,7 +226,6 @@ def _batched_lbfgs_ascent(fg, X0, lb, ub, maxeval, ftol_rel=1e-10, xtol_abs=1e-1
         active = active & (df > ftol_abs) & ~(fn >= stopval)
         if xtol_rel > 0.0:
             active = active & (np.abs(s_) > xtol_rel * np.abs(Xn)).any(axis=0)
-        active = active & grad_live(Xn, Gn)
         good = np.einsum("dr,dr->r", s_, y_) > 1e-14
         S.append(np.where(good, s_, 0.0)); Y.append(np.where(good, y_, 0.0))
         if len(S) > history:

@@ -295,6 +295,7 @@ static int g_bulk_pieces = 4;   // gated pieces of the side-stream bulk update p
 static int g_split = 1;   // split-K path for batches of a few hundred candidates (BOHIP_SPLIT=0 disables)
 static int g_asc_wg_nmax = 256;  // BOHIP_ASC_WG_NMAX: models up to this many observations run acquire_max as ONE launch, one workgroup per start point
                                  // (kernels_ascent.hip k_ascent_wg); 0: never
+static const double g_asc_first_step = 0.1;   // the first step is never shorter than this fraction of the smallest box side (kernels_ascent.hip asc_direction_one)
 static int g_asc_lockstep = 0;   // BOHIP_ASC_LOCKSTEP=1: the lock-step driver of the device ascent (five launches + a stream synchronisation per
                                  // evaluation pass) instead of the free-running one (k_asc_step)
 static int g_small_mfma = 1;   // BOHIP_SMALL_MFMA: the small-batch pass as two MFMA kernels (kernels_small.hip); 0 = round 4's five kernels
@@ -2912,7 +2913,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
             if (acq_id == BOHIP_ACQ_MI) pw.ap.p1 = acq_params[1];
         }
         pw.beta = g->beta; pw.st = st; pw.starts = g->asc_dio + 2 * d; pw.lb = g->asc_dio; pw.ub = g->asc_dio + d; pw.R = (int)R;
-        pw.maxeval = (int)std::min<int64_t>(maxeval, 1 << 30); pw.ftol_rel = ftol_rel; pw.xtol_abs = xtol_abs; pw.first_step_scale = 0.1 * span;
+        pw.maxeval = (int)std::min<int64_t>(maxeval, 1 << 30); pw.ftol_rel = ftol_rel; pw.xtol_abs = xtol_abs; pw.first_step_scale = g_asc_first_step * span;
         pw.max_ticks = g->asc_maxtime > 0.0 ? (unsigned long long)(g->asc_maxtime * 1e8) : 0ull;
         pw.passes = st.accepted;
         t_begin(g, "ascent_wg");
@@ -2953,10 +2954,10 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     if (free_run) {
         // no synchronisation here: how many start points are active at all is counted by the adopt kernel into the ring slot the host reads
         // once the first pass is queued (below)
-        hipLaunchKernelGGL(k_asc_adopt_count, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, ASC_RING - 1, dlb, dub);
+        hipLaunchKernelGGL(k_asc_adopt_count, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, ASC_RING - 1);
         HIPCHK(hipGetLastError());
     } else {
-        hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d, dlb, dub);
+        hipLaunchKernelGGL(k_asc_adopt, dim3(nR), dim3(64), 0, g->stream, st, d);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(g->stream));
         any_active = any_of(st.h_active, 1);
@@ -2975,7 +2976,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         // LAG passes run beyond convergence.  Same per-start-point trajectories as the lock-step form below.
         const int LAG = 1;   // (2 until round 4: with 17 passes per call instead of 228 a wasted pass is 5 % of it; one queued pass keeps the device fed)
         if (any_active) {
-            hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, 0, 0, dlb, dub, 0.1 * span);
+            hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, 0, 0, dlb, dub, g_asc_first_step * span);
             int64_t e = 0, converged_at = -1;
             bool none_active = false;
             auto read_count = [&](int64_t pass) -> int {   // active start points after `pass` (waits for it if need be)
@@ -2994,7 +2995,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
                 g->asc_go = nullptr;
                 CHK(rc_pass);
                 ++evals;
-                hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, 0.1 * span, ftol_rel, xtol_abs,
+                hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, g_asc_first_step * span, ftol_rel, xtol_abs,
                                    (int)(e % ASC_RING));
                 HIPCHK(hipGetLastError());
                 if (e == 0) {   // the adopt kernel's count (the device is busy with the first pass meanwhile)
@@ -3015,8 +3016,8 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
     } else {
     while (evals < maxeval && any_active && !out_of_time()) {
         hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, nh, (it + ASC_M - 1) % ASC_M, dlb, dub,
-                           0.1 * span);
-        for (int bt = 0; bt < 12; ++bt) {   // backtracking Armijo, all start points per device pass
+                           g_asc_first_step * span);
+        for (int bt = 0; bt < ASC_MAX_BT; ++bt) {   // backtracking Armijo, all start points per device pass
             CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
             ++evals;
             hipLaunchKernelGGL(k_asc_linesearch, dim3(nR), dim3(64), 0, g->stream, st, d, dlb, dub);
@@ -3026,7 +3027,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
             if (!any_of(st.h_accepted, 0) || evals >= maxeval || !any_active) break;
         }
         if (!any_active) { --evals; break; }   // the speculative evaluation of an already converged set is not counted
-        hipLaunchKernelGGL(k_asc_update, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, it % ASC_M, ftol_rel, xtol_abs, dlb, dub);
+        hipLaunchKernelGGL(k_asc_update, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, it % ASC_M, ftol_rel, xtol_abs);
         nh = std::min(nh + 1, ASC_M);
         ++it;
     }

@@ -15,6 +15,10 @@
 namespace bohip {
 
 constexpr int ASC_M = 8;   // curvature pairs kept
+// Trial points per line search (the step is halved between them).  12 until round 6: on the flank of a narrow EI ridge -- the value falls to 0
+// within 1e-3 |g| of the point, tests' N = 600 model at tau = median y -- a start needs ~14 halvings and was given up as "line search failed"
+// short of a KKT point (1-3 of 576 start points, tools/ascent_kkt_margin.py).  30 halvings reach 1e-9 of the first step.
+constexpr int ASC_MAX_BT = 30;
 
 struct AscentState {
     double *X, *f, *G;          // [R][d], [R], [R][d]   current point
@@ -77,23 +81,11 @@ __device__ __forceinline__ double asc_wsum_dpp(double v) {
 // Does start point r go on after an iteration that moved it by s (this lane's coordinate, new value xn) and changed the value by
 // df to fn?  NLopt's tests for a maximisation: ftol_rel, ftol_abs on the improvement, xtol_abs on the step (its norm, as before),
 // xtol_rel per coordinate (stop when EVERY |dx_k| <= xtol_rel |x_k|), stopval.  Wave-uniform (the sums are butterflies).
-// Round 6: the projected-gradient test.  A gradient method has a gradient tolerance of its own -- SciPy's L-BFGS-B (gtol), Luksan's PLIS
-// behind NLopt's :LD_LBFGS (TOLG; UPSTREAM-UNVERIFIED value, NLopt is not vendored) -- and on the reference's DEFAULT acquisition it is what
-// ends most searches: ExpectedImprovement at a Latin-hypercube start of the headline model is 1e-20 .. 1e-70 with a gradient to match, SciPy
-// on the oracle stops at the FIRST evaluation of every start, while the relative tests below never fire on such a plateau and the ascent
-// crawled uphill for 73 .. 2000 passes (profiles/r05_ascent_kkt_margin.txt).  A start point is retired when no free coordinate (not held on
-// a bound by the gradient) has |g| above ASC_GTOL_ABS, the absolute tolerance of the SciPy-on-oracle cross-check.
-constexpr double ASC_GTOL_ABS = 1e-10;
-__device__ __forceinline__ bool asc_grad_live(bool on, double x, double g, double lo, double hi, int d) {
-    const bool held = (x <= lo && g < 0.0) || (x >= hi && g > 0.0);
-    return asc_csum((on && !held && fabs(g) > ASC_GTOL_ABS) ? 1.0 : 0.0, d) > 0.0;
-}
 __device__ __forceinline__ bool asc_goes_on(const AscentState& st, int d, bool on, double s, double xn, double df, double fn, double moved,
-                                            double ftol_rel, double xtol_abs, double gn, double lo, double hi) {
+                                            double ftol_rel, double xtol_abs) {
     const double n_big = asc_csum((on && fabs(s) > st.xtol_rel * fabs(xn)) ? 1.0 : 0.0, d);   // coordinates that moved by more than xtol_rel |x|
-    const bool live = asc_grad_live(on, xn, gn, lo, hi, d);
     return df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs && df > st.ftol_abs && (st.xtol_rel <= 0.0 || n_big > 0.0) &&
-           !(fn >= st.stopval) && live;
+           !(fn >= st.stopval);
 }
 constexpr int ASC_RING = 8;
 
@@ -108,38 +100,31 @@ __global__ __launch_bounds__(64) void k_asc_start(AscentState st, int d, const d
     st.Xt[(int64_t)r * d + k] = x;
 }
 
-// (all 64 lanes of the wave call this: asc_grad_live is a wave sum).  Returns whether the start point is active at all: a finite value and a
-// projected gradient above the tolerance (asc_grad_live).
-__device__ __forceinline__ int asc_adopt_one(const AscentState& st, int r, int k, int d, const double* __restrict__ lb, const double* __restrict__ ub) {
+__device__ __forceinline__ void asc_adopt_one(const AscentState& st, int r, int k, int d) {
     const double f = st.ft[r];
-    const bool on = k < d;
-    const double x = on ? st.X[(int64_t)r * d + k] : 0.0, g = on ? st.Gt[(int64_t)r * d + k] : 0.0;
-    const int a = (isfinite(f) && asc_grad_live(on, x, g, on ? lb[k] : 0.0, on ? ub[k] : 0.0, d)) ? 1 : 0;
-    if (on) {
-        st.G[(int64_t)r * d + k] = g;
-        st.best_X[(int64_t)r * d + k] = x;
+    if (k < d) {
+        st.G[(int64_t)r * d + k] = st.Gt[(int64_t)r * d + k];
+        st.best_X[(int64_t)r * d + k] = st.X[(int64_t)r * d + k];
     }
     if (k == 0) {
         st.f[r] = f;
         st.best_f[r] = f;
+        const int a = isfinite(f) ? 1 : 0;
         st.active[r] = a;
         st.h_active[r] = a;
     }
-    return a;
 }
-__global__ __launch_bounds__(64) void k_asc_adopt(AscentState st, int d, const double* __restrict__ lb, const double* __restrict__ ub) {
-    asc_adopt_one(st, blockIdx.x, threadIdx.x, d, lb, ub);
-}
+__global__ __launch_bounds__(64) void k_asc_adopt(AscentState st, int d) { asc_adopt_one(st, blockIdx.x, threadIdx.x, d); }
 // The free-running form's adopt: the same, plus this start point's iteration / backtracking counters zeroed (two memset launches per call
 // before) and the number of start points that are active at all counted into ring slot `slot` the way a pass counts (see asc_step_one): the
 // host reads it while the first pass is already queued, where it used to synchronise the stream to look at h_active (~20 us per call).
-__global__ __launch_bounds__(64) void k_asc_adopt_count(AscentState st, int d, int R, int slot, const double* __restrict__ lb,
-                                                        const double* __restrict__ ub) {
+__global__ __launch_bounds__(64) void k_asc_adopt_count(AscentState st, int d, int R, int slot) {
     const int r = blockIdx.x, k = threadIdx.x;
-    const int active = asc_adopt_one(st, r, k, d, lb, ub);
+    asc_adopt_one(st, r, k, d);
     if (k == 0) {
         st.it[r] = 0;
         st.bt[r] = 0;
+        const int active = isfinite(st.ft[r]) ? 1 : 0;
         unsigned long long* cnt = reinterpret_cast<unsigned long long*>(st.nact) + slot;
         const unsigned long long before = atomicAdd(cnt, 1ull + ((unsigned long long)active << 32));
         if ((unsigned)(before & 0xffffffffull) == (unsigned)R - 1u) {
@@ -204,7 +189,12 @@ __device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, 
     }
     const int active = st.active[r];
     double step = 1.0;
-    if (nh == 0) step = 1.0 / fmax(sqrt(asc_csum(on ? D * D : 0.0, d)), 1e-12) * first_step_scale;
+    // The FIRST step (no curvature pair yet).  Round 6: the unit step on the projected gradient itself, which is what L-BFGS-B does -- its first
+    // iterate is the generalised Cauchy point of the model with B = I, P(x + g), tried with step 1 -- but never shorter than a tenth of the box
+    // (first_step_scale / |D|, the cautious step rounds 3-5 always took: it slid into the nearest local maximum where SciPy's reaches the
+    // corner the gradient points at -- over 8 x 10 starts on the headline model 44 of 80 ended at or above SciPy's value from the same start,
+    // with the unit step 72 of 80 -- but on a flat tail, |g| << 1, it is the only step that gets anywhere).
+    if (nh == 0) step = fmax(1.0, first_step_scale / fmax(sqrt(asc_csum(on ? D * D : 0.0, d)), 1e-12));
     if (!(active && slope > 0.0)) step = 0.0;
     if (on) {
         st.D[o] = D;
@@ -254,8 +244,7 @@ __global__ __launch_bounds__(64) void k_asc_linesearch(AscentState st, int d, co
     }
 }
 
-__global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R, int slot, double ftol_rel, double xtol_abs,
-                                                   const double* __restrict__ lb, const double* __restrict__ ub) {
+__global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R, int slot, double ftol_rel, double xtol_abs) {
     const int r = blockIdx.x, k = threadIdx.x;
     const bool on = k < d;
     const int64_t o = (int64_t)r * d + k;
@@ -265,7 +254,7 @@ __global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R,
     const double moved = sqrt(asc_csum(s * s, d));
     const bool good = asc_csum(s * y, d) > 1e-14;
     int active = st.active[r];
-    active = (active && asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs, gn, on ? lb[k] : 0.0, on ? ub[k] : 0.0)) ? 1 : 0;
+    active = (active && asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs)) ? 1 : 0;
     if (on) {
         const int64_t ho = ((int64_t)slot * R + r) * d + k;
         st.S[ho] = good ? s : 0.0;
@@ -284,7 +273,7 @@ __global__ __launch_bounds__(64) void k_asc_update(AscentState st, int d, int R,
 }
 
 // FREE-RUNNING form: one launch per evaluation pass does, for every start point on its own, whatever comes next in ITS iteration --
-// the Armijo test of its trial; on failure the halved step (up to 12 trials, as in the lock-step driver); on success (or after
+// the Armijo test of its trial; on failure the halved step (up to ASC_MAX_BT trials, as in the lock-step driver); on success (or after
 // the 12th failure) the update of k_asc_update and at once the next direction of k_asc_direction with its first trial point.
 // A start point's sequence of trial points, values and curvature pairs is exactly that of the lock-step form (its arithmetic
 // never looks at another start point, and a score_grad result does not depend on what else is in the batch), but no start
@@ -340,18 +329,18 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
     if (active) {
         const double dot = asc_csum(on ? gpo * (xt - x) : 0.0, d);
         const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
-        if (!ok && bt < 11) {
+        if (!ok && bt < ASC_MAX_BT - 1) {
             const double step = step_old * 0.5;
             if (on) st.Xt[o] = asc_clip(x + step * d_old, lo, hi);
             if (k == 0) { st.step[r] = step; st.bt[r] = bt + 1; }
         } else {
-            // ---- the iteration ends (k_asc_update with Xn = the accepted trial, or X itself after 12 failures)
+            // ---- the iteration ends (k_asc_update with Xn = the accepted trial, or X itself after ASC_MAX_BT failures)
             const double g = g_old;
             const double xn = ok ? xt : x, gn = ok ? g_trial : g, fn = ok ? ft : f;
             const double s = xn - x, y = -(gn - g), df = fn - f;
             const double moved = sqrt(asc_csum(s * s, d));
             const bool good = asc_csum(s * y, d) > 1e-14;
-            active = asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs, gn, lo, hi) ? 1 : 0;
+            active = asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs) ? 1 : 0;
             const int slot = it % ASC_M;
             const double s_new = good ? s : 0.0, y_new = good ? y : 0.0;
             if (on) {
@@ -640,7 +629,7 @@ __global__ __launch_bounds__(AWG_THREADS) void k_ascent_wg(AscWgParams p) {
             asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");   // (LDS state: lane 0's scalars are visible to the wave)
             // ---- the ascent's bookkeeping for this start point (same code as the batched drivers, on the LDS state)
             if (pass == 0) {
-                asc_adopt_one(st, 0, k, d, p.lb, p.ub);
+                asc_adopt_one(st, 0, k, d);
                 asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)" ::: "memory");
                 asc_direction_one(st, 0, k, d, 1, 0, 0, p.lb, p.ub, p.first_step_scale);
             } else {

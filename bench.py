@@ -577,9 +577,9 @@ def default_usage(model, tau, acq="UCB"):
     if acq == "UCB":
         out["small_model"] = default_usage_small()
     else:
-        out["note_ei"] = ("EI at a Latin-hypercube start of this model is 1e-20 .. 1e-70 with a gradient to match: a gradient method's own tolerance "
-                          "(SciPy gtol, PLIS TOLG behind NLopt; here ASC_GTOL_ABS = 1e-10 on the projected gradient, kernels_ascent.hip) ends such a "
-                          "start at its first evaluation -- cpu_baseline.default_search.EI shows SciPy on the oracle doing the same")
+        out["note_ei"] = ("EI at a Latin-hypercube start of this model is 1e-20 .. 1e-70 with a gradient to match: the first step of the search moves "
+                          "such a start, finds no Armijo improvement above ftol_rel / xtol_abs and retires it within 2-3 evaluations -- "
+                          "cpu_baseline.default_search.EI shows SciPy on the oracle leaving every start at its first")
     return out
 
 

@@ -195,7 +195,7 @@ def test_default_usage_acquire_max_vs_scipy_on_the_oracle(bohip, orc, headline):
     starts = np.asfortranarray(lhs(10, seed=7).T)
     lb, ub = np.zeros(8), np.ones(8)
     fd, Xd, bf, bi, bx, ev = m.ascend("UCB", [bt], lb, ub, starts, 2000)
-    assert 2 <= ev <= 60, ev                                               # round 3 needed 228 passes here
+    assert 2 <= ev <= 60, ev                                               # round 3 needed 228 passes here (tightened against SciPy below)
     sc_o, g_o = orc.score_grad(X, ll, 0.0, 0.0, L, alpha, "UCB", [bt], np.ascontiguousarray(Xd.T))
     np.testing.assert_allclose(fd, sc_o, rtol=1e-6, atol=1e-9)
     pg = np.where(((Xd.T <= 0) & (g_o < 0)) | ((Xd.T >= 1) & (g_o > 0)), 0.0, g_o)
@@ -216,10 +216,13 @@ def test_default_usage_acquire_max_vs_scipy_on_the_oracle(bohip, orc, headline):
         nf.append(cnt[0]); fs.append(-res.fun)
     fs = np.array(fs)
     print(f"default_usage: device {ev} passes, best {bf:.6f}; SciPy evaluations per start {nf}, best {fs.max():.6f}")
-    # both are stationary points of the same objective from the same starts; the corners SciPy's full first step reaches can be
-    # higher -- bound the difference, and require at least as many starts to end at SciPy's value or above as below it
-    assert bf >= fs.max() - 0.08 * abs(fs.max())
-    assert np.sum(fd >= fs - 1e-6 * np.abs(fs)) >= 4, (fd, fs)
+    # both are stationary points of the same objective from the same starts.  Round 6: the search takes L-BFGS-B's unit first step (to the
+    # corner the gradient points at) where the gradient is not small: per start the device ends at SciPy's value or above for >= 8 of the 10
+    # starts (rounds 3-5: 4 required, 5 reached; six seeds x 10 starts on the device: 54 of 60, none below 8), the best of the starts is within
+    # 1 % of SciPy's (8 % allowed until now), and the passes needed stay within twice SciPy's evaluations for its slowest start
+    assert np.sum(fd >= fs - 1e-6 * np.abs(fs)) >= 8, (fd, fs)
+    assert bf >= fs.max() - 1e-2 * abs(fs.max()), (bf, fs.max())
+    assert ev <= 2 * max(nf), (ev, nf)
     # the host restatement of the same search on the ORACLE's objective ends where the device ends
     from bohip.acquisition import _batched_lbfgs_ascent
 
@@ -229,6 +232,50 @@ def test_default_usage_acquire_max_vs_scipy_on_the_oracle(bohip, orc, headline):
 
     fh, Xh = _batched_lbfgs_ascent(fg, starts, lb, ub, 2000)
     np.testing.assert_allclose(fd, fh, rtol=1e-9, atol=1e-9)
+
+
+def test_default_usage_ei_acquire_max_vs_scipy_on_the_oracle(bohip, orc, headline):
+    """bench.py's `default_usage_ei`: the reference's DEFAULT acquisition (ExpectedImprovement, src/BayesianOptimization.jl:265) through its
+    default search (:LD_LBFGS, 10 restarts, maxeval 2000, src/acquisition.jl:4-6) on the headline model, at two incumbents.
+    tau = max y (what `boptimize!` uses): EI at a Latin-hypercube start is 1e-20 .. 1e-100 with a gradient to match; SciPy's L-BFGS-B on the
+    oracle stops at the first evaluation of every start (its gtol / ftol are absolute at this scale).  The device must do no worse per start
+    and may climb (NLopt, called with no tolerance, would): it gets a pass budget, not SciPy's count.
+    tau = median y: EI of order 1e-2 .. 1, something to climb from every start: per start no worse than SciPy from the same start (one
+    exception), same best of the starts.  No pass bound: a start on the exponential flank of EI (value 1e-8, no curvature pair is ever
+    accepted) improves by a constant FACTOR per pass up to maxeval, as NLopt without tolerances would; SciPy's ftol gives it up."""
+    from scipy.optimize import minimize
+
+    from bench import lhs
+
+    m, X, y, ll, L, alpha = headline
+    lb, ub = np.zeros(8), np.ones(8)
+    for seed in (7, 8):
+        starts = np.asfortranarray(lhs(10, seed=seed).T)
+        for tau, flat in ((float(y.max()), True), (float(np.median(y)), False)):
+            fd, Xd, bf, bi, bx, ev = m.ascend("EI", [tau], lb, ub, starts, 2000)
+            f0, g0 = orc.score_grad(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], np.ascontiguousarray(starts.T))
+            nf, fs = [], []
+            for r in range(10):
+                cnt = [0]
+
+                def negfg(x):
+                    cnt[0] += 1
+                    s, g = orc.score_grad(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], x[None, :].copy())
+                    return -float(s[0]), -g[0]
+
+                res = minimize(negfg, starts[:, r], jac=True, method="L-BFGS-B", bounds=[(0, 1)] * 8, options=dict(maxiter=2000, ftol=1e-10, gtol=1e-10))
+                nf.append(cnt[0]); fs.append(-res.fun)
+            fs = np.array(fs)
+            print(f"default_usage_ei seed {seed} tau {'max y' if flat else 'median y'}: device {ev} passes, best {bf:.3e}; SciPy evaluations per start {nf}, best {fs.max():.3e}")
+            assert np.all(fd >= f0 * (1 - 1e-9)) and bf == fd.max() and bi == int(np.argmax(fd))
+            sc_o = orc.score(X, ll, 0.0, 0.0, L, alpha, "EI", [tau], np.ascontiguousarray(Xd.T))[0]
+            np.testing.assert_allclose(fd, sc_o, rtol=1e-6, atol=1e-300)
+            if flat:
+                assert max(nf) == 1 and ev <= 400, (ev, nf)
+                assert np.all(fd >= fs * (1 - 1e-6)) and bf >= fs.max() * (1 - 1e-6), (fd, fs)
+            else:
+                assert np.sum(fd >= fs - 1e-6 * np.abs(fs).max()) >= 9, (fd, fs)
+                assert bf >= fs.max() * (1 - 1e-6), (bf, fs.max())
 
 
 def test_stress_variant_all_4096_candidates(bohip, orc):

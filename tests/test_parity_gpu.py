@@ -746,8 +746,11 @@ def test_device_ascent_on_the_split_k_and_whole_k_schedules(bohip):
     for R in (300, 1500):
         starts = np.asfortranarray(rng.random((3, R)))
         f0, _ = m.score_grad("UCB", [2.0], starts)
-        f, Xb, bf, bi, bx, ev = m.ascend("UCB", [2.0], lb, ub, starts, maxeval=60)
-        fh, Xh = _batched_lbfgs_ascent(lambda Z: m.score_grad("UCB", [2.0], Z), starts, lb, ub, 60)
+        # (maxeval: enough for BOTH drivers to converge -- under a cap they differ by construction: the free-running device form spends a pass
+        # per start and trial, the lock-step host form a pass per trial of the slowest line search)
+        f, Xb, bf, bi, bx, ev = m.ascend("UCB", [2.0], lb, ub, starts, maxeval=400)
+        fh, Xh = _batched_lbfgs_ascent(lambda Z: m.score_grad("UCB", [2.0], Z), starts, lb, ub, 400)
+        assert ev < 400
         assert np.all(f >= f0 - 1e-12) and np.all(Xb >= 0) and np.all(Xb <= 1)
         fchk, _ = m.score_grad("UCB", [2.0], Xb)
         np.testing.assert_allclose(fchk, f, rtol=1e-9, atol=1e-12)
@@ -796,29 +799,38 @@ def test_device_ascent_against_scipy_lbfgsb_on_the_oracle(bohip, orc, N):
     for acq, p in [("EI", [tau]), ("UCB", [2.0]), ("MaxMean", [])]:
         f, Xd, bf, bi, bx, ev = m.ascend(acq, p, lb, ub, starts, maxeval=2000, ftol_rel=1e-13, xtol_abs=1e-13)
         assert 2 <= ev <= 2000 and np.all(Xd >= 0) and np.all(Xd <= 1)
+        cnt = [0]
 
         def negfg(x):
+            cnt[0] += 1
             sc, g = orc.score_grad(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], x[None, :].copy())
             return -float(sc[0]), -g[0]
 
-        fs, xs = np.empty(R), np.empty((3, R))
+        fs, xs, nf = np.empty(R), np.empty((3, R)), []
         for r in range(R):
+            cnt[0] = 0
             res = minimize(negfg, starts[:, r], jac=True, method="L-BFGS-B", bounds=[(0.0, 1.0)] * 3,
                            options=dict(maxiter=2000, maxfun=4000, ftol=1e-15, gtol=1e-12))
             fs[r], xs[:, r] = -res.fun, res.x
+            nf.append(cnt[0])
+        # evaluation passes (all starts advance in every pass: the slowest start decides) against SciPy's evaluations for its slowest start:
+        # UCB / MaxMean need fewer.  (EI has no bound: a start on the exponential flank of EI -- no curvature pair is ever accepted there --
+        # improves by a constant FACTOR per pass for as long as maxeval lets it, as NLopt's search without tolerances would; SciPy's ftol,
+        # absolute below 1, leaves it.  DESIGN 6c.)
+        if acq != "EI":
+            assert ev <= max(nf) + 10, (acq, ev, max(nf))
         sc_o, g_o = orc.score_grad(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], np.ascontiguousarray(Xd.T))
         scale = max(np.abs(fs).max(), 1e-300)
         np.testing.assert_allclose(f, sc_o, rtol=1e-6, atol=1e-9 * scale)           # the device reports the oracle's value there
         pg = np.where(((Xd.T <= 0) & (g_o < 0)) | ((Xd.T >= 1) & (g_o > 0)), 0.0, g_o)   # projected gradient (maximisation)
         g0 = orc.score_grad(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], np.ascontiguousarray(starts.T))[1]
-        # per start a KKT point.  ONE start point of the 16 may have been given up short of it: the search stops a start whose line search
-        # fails twelve halvings in a row, which happens to ~0.2-0.5 % of EI start points whatever kernels evaluate the objective (round 5,
-        # tools/ascent_kkt_margin.py over 12 start seeds, profiles/r05_ascent_kkt_margin.txt: 3 of 576 with round 4's kernels, 1 of 576 with
-        # round 5's -- this seed's).  Such a start must still sit within 1e-4 (relative) of SciPy's value from the same start.
+        # per start a KKT point -- every one of them (until round 6 a start whose line search failed twelve halvings in a row was given up
+        # short of it, 0.2-0.5 % of EI starts: the line search now has 30 trial points, tools/ascent_kkt_margin.py reads 0 of 576)
         kkt = np.abs(pg).max(1) <= 2e-4 * np.abs(g0).max()
-        assert kkt.sum() >= R - 1, (acq, np.abs(pg).max(1), np.abs(g0).max())
+        assert kkt.all(), (acq, np.abs(pg).max(1), np.abs(g0).max())
         assert np.all(f >= orc.score(X, ll, lsig, beta, L, alpha, acq, p if p else [0.0], np.ascontiguousarray(starts.T))[0] - 1e-12 * scale)
-        assert np.all(f[~kkt] >= fs[~kkt] - 1e-4 * scale), (acq, f[~kkt], fs[~kkt])
+        # and per start no worse than SciPy from the same start (one exception allowed: two searches may fall into neighbouring maxima)
+        assert np.sum(f >= fs - 1e-6 * scale) >= R - 1, (acq, f, fs)
         same = np.abs(f - fs) <= 1e-6 * scale                                        # same local maximum as SciPy from that start
         assert same.mean() >= 0.75, (acq, same.mean())
         sharp = same & (fs >= 0.5 * fs.max()) if fs.max() > 0 else same                # plateaus (EI ~ 0) have no unique maximiser
