@@ -325,6 +325,20 @@ def _batched_direct_l(f_batch, lb, ub, maxeval, stopval=math.inf, maxtime=0.0):
 # NLopt.Opt properties the reference forwards with setproperty! (src/acquisition.jl:24-27).  The device ascent
 # implements the first group; the second is accepted by NLopt but has no counterpart here (a warning says so);
 # anything else raises, as setproperty! on an NLopt.Opt does.
+_WARNED_METHODS = set()
+
+
+def _warn_not_a_local_search(method):
+    """:LN_* and the non-DIRECT :GN_* methods have no device counterpart: NLopt would run that algorithm (COBYLA, BOBYQA, Nelder-Mead,
+    CRS, ISRES ...) from each start, here `maxeval` Latin-hypercube candidates per restart are scored in one batch and the best one is
+    returned.  Said once per process and method, since the result is a candidate-set maximum, not that algorithm's."""
+    if method in _WARNED_METHODS:
+        return
+    _WARNED_METHODS.add(method)
+    warnings.warn(f"acquire_max: method :{method} is not implemented as such; maxeval Latin-hypercube candidates per restart are "
+                  "scored in one device batch instead (use :LD_LBFGS or :GN_DIRECT_L for a search)", stacklevel=3)
+
+
 _OPTS_USED = {"method", "restarts", "maxeval", "maxtime", "ftol_rel", "xtol_abs", "ftol_abs", "xtol_rel", "stopval"}
 _OPTS_NLOPT_ONLY = {"initial_step", "population", "vector_storage", "seed", "local_optimizer", "default_initial_step"}
 
@@ -384,6 +398,7 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None, setparams
             warnings.warn("acquisition returned no finite value; keeping the lower bounds as maximiser")
         return maxf, maxx
     if isinstance(a, ThompsonSamplingSimple):
+        _warn_not_a_local_search(method)
         # one joint draw of the posterior at `maxeval` candidates per restart, arg-max on the device
         n = max(maxeval, 1)
         for _ in range(restarts):
@@ -420,6 +435,7 @@ def acquire_max(a, model, lowerbounds, upperbounds, options, rng=None, setparams
         f, X = _batched_lbfgs_ascent(fg, starts, lb, ub, iters, ftol_rel=ftol, xtol_abs=xtol, ftol_abs=fabs_, xtol_rel=xrel,
                                      stopval=sval)
     else:
+        _warn_not_a_local_search(method)
         n = max(restarts, min(maxeval * restarts, 1 << 20))
         X = latin_hypercube_sampling(lb, ub, n, rng)
         f, _, _ = model.score(acq, p, X)

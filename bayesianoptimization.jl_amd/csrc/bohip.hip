@@ -19,8 +19,8 @@
 #include "kernels_chol.hip"
 #include "kernels_exec.hip"
 #include "kernels_score.hip"
-#include "kernels_small.hip"
 #include "kernels_ascent.hip"
+#include "kernels_small.hip"   // (after the ascent: k_small_u's last workgroup runs its step, asc_step_one<true>)
 
 #include <algorithm>
 #include <atomic>
@@ -314,6 +314,8 @@ static int g_chol_df2_min = 47;  // cholesky_dataflow2 (large-T form) from this 
 static int g_chol_df = 1;  // dataflow factorisation (kernels_chol.hip) for 3 <= T <= g_chol_df_tmax row tiles: N=3000 1.66 vs 2.71 ms, N=1000 0.57
                             // vs 0.82 ms.  Far beyond that its one-tier K=128 bulk updates lose to the two-tier launch chain, below 3 there is
                             // nothing to pipeline.  BOHIP_CHOL_DATAFLOW=0 disables, =2 forces it for every 2 <= T <= CHOL_DF_TCAP.
+static bool g_chol_df_strict = false;   // BOHIP_CHOL_DF_STRICT: a timed-out dependency is an error instead of a fall-back (tests, tools)
+static bool g_chol_df_dump = false;     // measurement builds: the flags of a timed-out factorisation on stderr
 static int g_chol_df_tmax = 96;   // = CHOL_DF_TCAP, N <= ~12200 (N=12000: 16.5 vs 18.5 ms for the launch chain)
 // A dataflow factorisation that timed out on a dependency (another process holds the CUs, two streams share a hardware queue, ...)
 // switches the PROCESS to the launch chain -- for the next `skip` refits, not for good: the cause is usually transient, a
@@ -357,6 +359,32 @@ static int launch_gemm_nt(bohip_gp* g, const GemmNTParams& p, int batch = 1, hip
 }
 
 static int device_cus();
+// Measurement builds only (make abl/libbohip_dev.so, -DBOHIP_DEV_KNOBS=1): the constants the sweeps under tools/ vary, by
+// name.  The shipped library does not read them -- each has a measured default recorded beside its declaration above.
+static void read_dev_knobs() {
+#if BOHIP_DEV_KNOBS
+    struct Knob { const char* name; int* v; int lo, hi; };
+    static int chunk_rows = 0, dump = 0;
+    const Knob knobs[] = {
+        {"BOHIP_CHOL_DF2_HI", &g_chol_df2_hi, 0, 1}, {"BOHIP_CHOL_DF2_COAL", &g_chol_df2_coal, 0, 1}, {"BOHIP_CHOL_DF2_WIN", &g_chol_df2_win, 6, 10},
+        {"BOHIP_CHOL_DF_TMAX", &g_chol_df_tmax, 0, CHOL_DF_TCAP}, {"BOHIP_INV_HI_H", &g_inv_hi_h, 0, 1 << 20}, {"BOHIP_INV_OVERLAP", &g_inv_overlap, 0, 1},
+        {"BOHIP_CHOL_EXEC_PAIRS", &g_chol_exec_pairs, -1, 64}, {"BOHIP_CHOL_EXEC_FILL", &g_chol_exec_fill, 0, 2}, {"BOHIP_CHOL_COPY_EARLY", &g_chol_copy_early, 0, 1},
+        {"BOHIP_CHOL_EXEC_URGENT", &g_chol_exec_urgent, 1, 1 << 20}, {"BOHIP_CHOL_NSF", &g_chol_nsf, 1, CH_NSF_MAX},
+        {"BOHIP_CHOL_EXEC_PATIENCE_US", &g_chol_exec_patience_us, 0, 1 << 30}, {"BOHIP_CHOL_EXEC_FILL_INV", &g_chol_exec_fill_inv, 0, 1},
+        {"BOHIP_CHOL_EXEC_INV_PAIRS", &g_chol_exec_inv_pairs, 0, 1}, {"BOHIP_CHOL_EXEC_WGS", &g_chol_exec_wgs, 1, 1 << 20}, {"BOHIP_KS8", &g_ks8, 0, 1},
+        {"BOHIP_CHOL_EXEC_BULK_EDF", &g_chol_exec_bulk_edf, 0, 1}, {"BOHIP_CHOL_EXEC_FAST", &g_chol_exec_fast, -1, 1 << 20},
+        {"BOHIP_CHOL_EXEC_SECOND", &g_chol_exec_second, 0, 1}, {"BOHIP_CHOL_EXEC_NBU", &g_chol_exec_nbu, 0, 16}, {"BOHIP_CHUNK_ROWS", &chunk_rows, 0, 1 << 30},
+        {"BOHIP_TRIGEMM_HALVE_LO", &g_halve_lo, 0, 1 << 20}, {"BOHIP_TRIGEMM_HALVE_HI", &g_halve_hi, 0, 1 << 20}, {"BOHIP_FUSE_FINISH", &g_fuse_finish, 0, 1},
+        {"BOHIP_APPEND_ALPHA_INC", &g_append_alpha_inc, 0, 1}, {"BOHIP_BULK_PIECES", &g_bulk_pieces, 0, 8}, {"BOHIP_SPLIT", &g_split, 0, 1},
+        {"BOHIP_SMALL_R", &g_small_r, 0, SMALL_MAX}, {"BOHIP_SMALL_M", &g_small_m, 0, 1 << 20}, {"BOHIP_CHOL_DF_DUMP", &dump, 0, 1},
+    };
+    for (const Knob& k : knobs)
+        if (const char* e = getenv(k.name)) *k.v = std::min(k.hi, std::max(k.lo, atoi(e)));
+    g_chunk_rows_forced = chunk_rows;
+    g_chol_df_dump = dump != 0;
+#endif
+}
+
 static int one_time_kernel_setup() {
     // the >64 KB dynamic-LDS opt-in is a per-device function attribute
     static bool done_dev[64] = {false};
@@ -375,48 +403,22 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_quad, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_chol_exec, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_trimv_stream<TRIMV_D>, hipFuncAttributeMaxDynamicSharedMemorySize, trimv_lds_bytes(TRIMV_D)));
+    // The library's switches (README "Environment"): the forms of the factorisation the tests select, the bound of its
+    // waits, the ascent drivers, the small-batch pass.  Everything else that used to be read here is a constant now; the
+    // sweeps under tools/ that vary those constants run against csrc/abl/libbohip_dev.so (read_dev_knobs below).
     if (const char* e = getenv("BOHIP_CHOL_DATAFLOW")) g_chol_df = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_MIN")) g_chol_df2_min = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_DF2_HI")) g_chol_df2_hi = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_DF2_COAL")) g_chol_df2_coal = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_DF2_LL")) g_chol_df2_ll = atoi(e);
-    if (const char* e = getenv("BOHIP_INV_HI_H")) g_inv_hi_h = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_DF2_WIN")) g_chol_df2_win = std::min(10, std::max(6, atoi(e)));
-    if (const char* e = getenv("BOHIP_CHOL_DF_TMAX")) g_chol_df_tmax = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_SPIN_US")) g_chol_spin_ticks = 100ull * (unsigned long long)std::max(1, atoi(e));
     if (const char* e = getenv("BOHIP_CHOL_EXEC")) g_chol_exec = atoi(e);
     if (const char* e = getenv("BOHIP_CHOL_EXEC_MIN")) g_chol_exec_min = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_PAIRS")) g_chol_exec_pairs = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL")) g_chol_exec_fill = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_COPY_EARLY")) g_chol_copy_early = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_URGENT")) g_chol_exec_urgent = std::max(1, atoi(e));
-    if (const char* e = getenv("BOHIP_CHOL_NSF")) g_chol_nsf = std::min(CH_NSF_MAX, std::max(1, atoi(e)));
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_PATIENCE_US")) g_chol_exec_patience_us = std::max(0, atoi(e));
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_FILL_INV")) g_chol_exec_fill_inv = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_INV_PAIRS")) g_chol_exec_inv_pairs = atoi(e) != 0;
     if (const char* e = getenv("BOHIP_CHOL_INV_G")) g_chol_inv_g = std::min(64, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_INV_GRP_MIN")) g_chol_inv_grp_min = std::max(0, atoi(e));
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_WGS")) g_chol_exec_wgs = std::max(1, atoi(e));
-    if (const char* e = getenv("BOHIP_KS8")) g_ks8 = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_BULK_EDF")) g_chol_exec_bulk_edf = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_FAST")) g_chol_exec_fast = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_SECOND")) g_chol_exec_second = atoi(e);
-    if (const char* e = getenv("BOHIP_CHOL_EXEC_NBU")) g_chol_exec_nbu = std::max(0, std::min(16, atoi(e)));
-    if (const char* e = getenv("BOHIP_CHUNK_ROWS")) g_chunk_rows_forced = atoll(e);
-    if (const char* e = getenv("BOHIP_TRIGEMM_HALVE")) {   // "lo,hi": row tiles lo <= rt < hi go as two 64-row halves ("0,0": none)
-        int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= a) { g_halve_lo = a; g_halve_hi = b; }
-    }
-    if (const char* e = getenv("BOHIP_FUSE_FINISH")) g_fuse_finish = atoi(e);
-    if (const char* e = getenv("BOHIP_APPEND_ALPHA_INC")) g_append_alpha_inc = atoi(e);
-    if (const char* e = getenv("BOHIP_BULK_PIECES")) g_bulk_pieces = std::min(8, std::max(0, atoi(e)));
-    if (const char* e = getenv("BOHIP_SPLIT")) g_split = atoi(e);
-    if (const char* e = getenv("BOHIP_INV_OVERLAP")) g_inv_overlap = atoi(e);
     if (const char* e = getenv("BOHIP_ASC_WG_NMAX")) g_asc_wg_nmax = std::max(0, atoi(e));
     if (const char* e = getenv("BOHIP_ASC_LOCKSTEP")) g_asc_lockstep = atoi(e) != 0;
-    if (const char* e = getenv("BOHIP_SMALL_R")) g_small_r = std::min(SMALL_MAX, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_SMALL_MFMA")) g_small_mfma = atoi(e);
-    if (const char* e = getenv("BOHIP_SMALL_M")) g_small_m = std::max(0, atoi(e));
+    g_chol_df_strict = getenv("BOHIP_CHOL_DF_STRICT") != nullptr;
+    read_dev_knobs();
     done = true;
     return 0;
 }
@@ -1300,8 +1302,9 @@ struct DfFileLock {
         return open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
     }
     explicit DfFileLock(int device) {
-        static int enabled = [] { const char* e = getenv("BOHIP_DF_FILE_LOCK"); return e ? atoi(e) : 1; }();
-        static int wait_ms = [] { const char* e = getenv("BOHIP_DF_FILE_LOCK_MS"); return e ? std::max(0, atoi(e)) : 300; }();
+        // BOHIP_DF_FILE_LOCK: 0 = off, 1 = on with the default wait (300 ms), n > 1 = on, waiting up to n ms for the other process
+        static int setting = [] { const char* e = getenv("BOHIP_DF_FILE_LOCK"); return e ? std::max(0, atoi(e)) : 1; }();
+        const int enabled = setting != 0, wait_ms = setting > 1 ? setting : 300;
         if (!enabled) return;
         static int fds[64];
         static pid_t owner[64];
@@ -1528,7 +1531,7 @@ static int refit_once(bohip_gp* g, double jitter) {
                 fprintf(stderr, "libbohip: dataflow factorisation (form %d, %d row tiles) timed out on a dependency (%s); using the launch-chained form for a while\n",
                         g->chol_form_last, T, which);
             }
-            if (getenv("BOHIP_CHOL_DF_DUMP")) {   // diagnosis: which flags of the dataflow form never arrived
+            if (g_chol_df_dump) {   // diagnosis: which flags of the dataflow form never arrived
                 std::vector<unsigned> hf(chol_flag_words(T));
                 hipMemcpy(hf.data(), g->dchol_flags, hf.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
                 const CholFlags fl = chol_flags_layout(g, T);
@@ -1549,7 +1552,7 @@ static int refit_once(bohip_gp* g, double jitter) {
                     fprintf(stderr, "\n");
                 }
             }
-            if (getenv("BOHIP_CHOL_DF_STRICT")) return fail(BOHIP_E_HIP, "dataflow factorisation timed out on a dependency (BOHIP_CHOL_DF_STRICT)");
+            if (g_chol_df_strict) return fail(BOHIP_E_HIP, "dataflow factorisation timed out on a dependency (BOHIP_CHOL_DF_STRICT)");
             {
                 const int bo = std::min(1024, 2 * g_chol_df_backoff.load(std::memory_order_relaxed) + 8);
                 g_chol_df_backoff.store(bo, std::memory_order_relaxed);
@@ -3213,8 +3216,7 @@ int64_t bohip_debug_exec_tasks(int T, int64_t ld, uint64_t base_L, uint64_t base
     unsigned* fb = reinterpret_cast<unsigned*>(uintptr_t(1) << 40);
     // the follower count the records are built for = the one reported in layout[10]: the env knob is read HERE (the library's
     // one-time setup may not have run yet), and the process-wide setting is left alone
-    int nsf = g_chol_nsf;
-    if (const char* e = getenv("BOHIP_CHOL_NSF")) nsf = std::min(bohip::CH_NSF_MAX, std::max(1, atoi(e)));
+    const int nsf = g_chol_nsf;
     int grp_min = g_chol_inv_grp_min;
     if (const char* e = getenv("BOHIP_CHOL_INV_GRP_MIN")) grp_min = std::max(0, atoi(e));
     exec_task_list(reinterpret_cast<double*>(base_L), reinterpret_cast<double*>(base_S), reinterpret_cast<double*>(base_W),

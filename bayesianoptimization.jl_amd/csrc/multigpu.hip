@@ -238,7 +238,7 @@ static int mgp_exchange(bohip_mgp* m, int64_t S, Best* out) {
     }));
     // every device reduced the same gathered records with the same kernel: its copy can only differ if the collective delivered
     // different data to different ranks.  Checked on request (BOHIP_MGP_VERIFY=1, and in the tests), not on every step.
-    static const bool verify = getenv("BOHIP_MGP_VERIFY") != nullptr && atoi(getenv("BOHIP_MGP_VERIFY")) != 0;
+    static const bool verify = [] { const char* e = getenv("BOHIP_MGP_VERIFY"); return e != nullptr && atoi(e) != 0; }();
     if (verify)
         for (int i = 1; i < m->nd; ++i)
             if (std::memcmp(m->hfinal, m->hfinal + (int64_t)i * S, (size_t)S * sizeof(Best)) != 0)

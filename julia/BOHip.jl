@@ -340,10 +340,21 @@ function acquire_max_device(a::AbstractAcquisition, m::AbstractBOHipModel, lower
         return isfinite(f) ? (f, x) : (maxf, maxx)
     end
     # other derivative-free methods (:LN_*, non-DIRECT :GN_*): `maxeval` Latin-hypercube candidates per restart, ONE batch on the device
+    _warn_not_a_local_search(options.method)
     n = clamp(options.maxeval * options.restarts, options.restarts, 1 << 20)
     cand = BO.latin_hypercube_sampling(lb, ub, n)
     _, f, j = score(m, a, cand; scores = false)
     j == 0 ? (maxf, maxx) : (f, cand[:, j])
+end
+
+const _WARNED_METHODS = Set{Symbol}()
+# :LN_* and the non-DIRECT :GN_* methods have no device counterpart: said once per process and method, since what comes back is the
+# best of a Latin-hypercube candidate set, not that algorithm's result.
+function _warn_not_a_local_search(method)
+    m = Symbol(method)
+    m in _WARNED_METHODS && return
+    push!(_WARNED_METHODS, m)
+    @warn "acquire_max: method :$m is not implemented as such; maxeval Latin-hypercube candidates per restart are scored in one device batch instead (use :LD_LBFGS or :GN_DIRECT_L for a search)"
 end
 
 """
@@ -453,6 +464,7 @@ function acquire_max_device(::ThompsonSamplingSimple, m::AbstractBOHipModel, low
         return maxf, maxx
     end
     # other derivative-free methods: one posterior draw per Latin-hypercube candidate, arg-max on the device
+    _warn_not_a_local_search(options.method)
     for _ in 1:options.restarts
         cand = BO.latin_hypercube_sampling(lb, ub, max(options.maxeval, 1))
         best = Ref(Best(-Inf, -1))

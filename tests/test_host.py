@@ -3,6 +3,7 @@ test/acquisition.jl option plumbing) plus the pure-host parts of acquisition.py.
 import math
 import time
 
+import warnings
 import numpy as np
 import pytest
 
@@ -190,7 +191,14 @@ def test_acquire_max_gradient_free_and_bounds(orc):
     n_direct = [c[1] for c in m.calls]
     assert all(c[0] == "score" for c in m.calls) and n_direct[0] == 1 and 2 < len(n_direct) < 120 and 400 < sum(n_direct) <= 500
     m.calls.clear()
-    fl, xl = bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="LN_COBYLA", restarts=1, maxeval=500), np.random.default_rng(1))
+    from bohip import acquisition as _acq
+    _acq._WARNED_METHODS.discard("LN_COBYLA")
+    with pytest.warns(UserWarning, match="LN_COBYLA is not implemented as such"):     # said once per process and method
+        fl, xl = bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="LN_COBYLA", restarts=1, maxeval=500), np.random.default_rng(1))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="LN_COBYLA", restarts=1, maxeval=500), np.random.default_rng(1))
+    m.calls.pop()
     assert m.calls[-1] == ("score", 500)                                # other derivative-free methods: maxeval Latin-hypercube candidates in ONE batch
     assert f0 >= fl * 0.999                                             # 500 evaluations placed by DIRECT-L beat 500 scattered ones here
     f1, x1 = bohip.acquire_max(ei, m, [-1, -1], [1, 1], dict(method="LD_LBFGS", restarts=16, maxeval=60), np.random.default_rng(1))

@@ -1,6 +1,8 @@
 #!/bin/bash
 # executor form of the factorisation (csrc/kernels_exec.hip) against the launch chain: factor, repeatability, time by size.
 # usage (GPU box): bash tools/chol_exec_check.sh OUTDIR
+# varies constants of the library: needs the measurement build (make -C bayesianoptimization.jl_amd/csrc abl/libbohip_dev.so)
+export BOHIP_LIB=${BOHIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/bayesianoptimization.jl_amd/csrc/abl/libbohip_dev.so}
 out=${1:-gpurun_out/exec}; mkdir -p $out
 export BOHIP_CHOL_DF_STRICT=1
 for N in 1000 3000 6000 10000; do

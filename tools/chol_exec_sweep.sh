@@ -1,5 +1,7 @@
 #!/bin/bash
 # sweep of the executor form's knobs.  usage (GPU box): bash tools/chol_exec_sweep.sh OUTFILE
+# varies constants of the library: needs the measurement build (make -C bayesianoptimization.jl_amd/csrc abl/libbohip_dev.so)
+export BOHIP_LIB=${BOHIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/bayesianoptimization.jl_amd/csrc/abl/libbohip_dev.so}
 out=${1:-gpurun_out/sweep.txt}; mkdir -p $(dirname $out); : > $out
 export BOHIP_CHOL_DF_STRICT=1
 for nsf in 2 3 4 5; do for pairs in 1 2; do

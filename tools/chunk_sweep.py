@@ -2,6 +2,7 @@
 usage: python tools/chunk_sweep.py N d R rows [rows ...]   (rows = 0: the library's rule)"""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV_LIB = os.path.join(ROOT, "bayesianoptimization.jl_amd", "csrc", "abl", "libbohip_dev.so")   # the knob swept here is a constant of the shipped library: make abl/libbohip_dev.so
 code = r'''
 import sys, time, json
 sys.path.insert(0, %r)
@@ -22,7 +23,7 @@ print(json.dumps(dict(ms=float(np.median(ts)) * 1e3, chunk=m.info(_lib.INFO_SCOR
 ''' % ROOT
 N, d, R = sys.argv[1:4]
 for rows in sys.argv[4:]:
-    env = dict(os.environ)
+    env = dict(os.environ); env.setdefault("BOHIP_LIB", DEV_LIB)
     if rows != "0": env["BOHIP_CHUNK_ROWS"] = rows
     r = subprocess.run([sys.executable, "-c", code, N, d, R], env=env, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,5 +1,7 @@
 #!/bin/bash
 # knob sweep of the executor form with its inverse queues.  usage (GPU box): bash tools/fused_inv_sweep.sh OUTDIR
+# varies constants of the library: needs the measurement build (make -C bayesianoptimization.jl_amd/csrc abl/libbohip_dev.so)
+export BOHIP_LIB=${BOHIP_LIB:-$(cd "$(dirname "$0")/.." && pwd)/bayesianoptimization.jl_amd/csrc/abl/libbohip_dev.so}
 out=${1:-gpurun_out/finvs}; mkdir -p $out
 export BOHIP_CHOL_DF_STRICT=1 BOHIP_CHOL_DATAFLOW=2 BOHIP_CHOL_EXEC_MIN=4
 run() { echo "# $*" >> $out/sweep.txt; env "$@" timeout 600 python tools/refit_bench.py $SIZES 2>&1 | grep -v amdgpu.ids >> $out/sweep.txt; }

@@ -2,6 +2,7 @@
 against the default path choice: where is the break-even now that the triangular products stream?  usage: python tools/small_limit_sweep.py [N]"""
 import os, sys, time, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV_LIB = os.path.join(ROOT, "bayesianoptimization.jl_amd", "csrc", "abl", "libbohip_dev.so")   # the knob swept here is a constant of the shipped library: make abl/libbohip_dev.so
 code = r'''
 import sys, time, json
 sys.path.insert(0, %r)
@@ -25,7 +26,7 @@ print(json.dumps(out))
 N = sys.argv[1] if len(sys.argv) > 1 else "3000"
 res = {}
 for name, env in (("default", {}), ("row-wise forced", {"BOHIP_SMALL_R": "256"}), ("row-wise off", {"BOHIP_SMALL_R": "0"})):
-    r = subprocess.run([sys.executable, "-c", code, N], env=dict(os.environ, **env), capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", code, N], env=dict({"BOHIP_LIB": DEV_LIB}, **os.environ, **env), capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     res[name] = json.loads(line[-1]) if line else {}
 print(f"N={N}: us per call, score / score_grad")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # kernel-trace statistics of the small-batch pass (tools/small_pass_profile.py: 200 score_grad + 200 score calls of 10 candidates) at the given sizes.
 # Usage (GPU box, repo root): bash tools/small_pass_prof.sh "3000 8" "500 2" ...   (always under `timeout`, always --output-format csv)
+# BOHIP_SMALL_M (tile depth override) is read by the measurement build only (abl/libbohip_dev.so through BOHIP_LIB)
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
