@@ -120,6 +120,8 @@ struct bohip_gp {
     int64_t batch_hint = 0;      // bohip_gp_set_batch_hint: choose the scoring path as if the batch had at least this many candidates
     double* dsplit = nullptr;    // split-K partial planes (batches of a few hundred candidates)
     int64_t split_cap = 0;
+    const SmallFold* asc_fold = nullptr;   // set around a pass of the free-running ascent: the step this pass's gradient kernel may run in its last workgroup
+    bool asc_fold_done = false;            // ... and whether it took it (small_pass_mfma: one pass of <= 16 candidates, d <= 16); else k_asc_step follows
     const unsigned* asc_go = nullptr;   // set around the passes of the free-running ascent: the pass's big kernels return at once when the word is 0
     double* dgparts = nullptr;   // [SMALL_MAX][16][2 DMAX] split partial sums of k_grad_finish (small batches)
     unsigned* dgcount = nullptr; // per-candidate arrival counters (left at zero by the kernel)
@@ -296,6 +298,7 @@ static int g_split = 1;   // split-K path for batches of a few hundred candidate
 static int g_asc_wg_nmax = 256;  // BOHIP_ASC_WG_NMAX: models up to this many observations run acquire_max as ONE launch, one workgroup per start point
                                  // (kernels_ascent.hip k_ascent_wg); 0: never
 static const double g_asc_first_step = 0.1;   // the first step is never shorter than this fraction of the smallest box side (kernels_ascent.hip asc_direction_one)
+static int g_asc_fold = 1;       // the free-running form's step inside k_small_u's last workgroup (BOHIP_ASC_LOCKSTEP=2: as a launch of its own, until round 6)
 static int g_asc_lockstep = 0;   // BOHIP_ASC_LOCKSTEP=1: the lock-step driver of the device ascent (five launches + a stream synchronisation per
                                  // evaluation pass) instead of the free-running one (k_asc_step)
 static int g_small_mfma = 1;   // BOHIP_SMALL_MFMA: the small-batch pass as two MFMA kernels (kernels_small.hip); 0 = round 4's five kernels
@@ -415,7 +418,7 @@ static int one_time_kernel_setup() {
     if (const char* e = getenv("BOHIP_CHOL_INV_G")) g_chol_inv_g = std::min(64, std::max(0, atoi(e)));
     if (const char* e = getenv("BOHIP_CHOL_INV_GRP_MIN")) g_chol_inv_grp_min = std::max(0, atoi(e));
     if (const char* e = getenv("BOHIP_ASC_WG_NMAX")) g_asc_wg_nmax = std::max(0, atoi(e));
-    if (const char* e = getenv("BOHIP_ASC_LOCKSTEP")) g_asc_lockstep = atoi(e) != 0;
+    if (const char* e = getenv("BOHIP_ASC_LOCKSTEP")) { g_asc_lockstep = atoi(e) == 1; g_asc_fold = atoi(e) != 2; }
     if (const char* e = getenv("BOHIP_SMALL_MFMA")) g_small_mfma = atoi(e);
     g_chol_df_strict = getenv("BOHIP_CHOL_DF_STRICT") != nullptr;
     read_dev_knobs();
@@ -2053,6 +2056,10 @@ static int small_pass_mfma(bohip_gp* g, const double* dXs, int64_t R, const AcqP
     SmallU su{};
     sv.ks16 = sv.fstash + SMALL_MAX;
     su.v16 = sv.v16; su.sv = sv; su.gpart = sv.ks16 + n_v16; su.gmpart = su.gpart + n_g; su.grad = d_grad;
+    if (g->asc_fold && d_grad && npass == 1 && g->d <= 16 && 16 * ((g->d + 1) / 2) <= SP_THREADS - 128) {
+        su.fold = *g->asc_fold;
+        g->asc_fold_done = true;
+    }
     const SmallU* sup = d_grad ? &su : nullptr;
     SmallCommon scu = sc;       // the U pass: W itself (contraction k >= c), its own partial planes and counters
     scu.A = g->dW; scu.cnt = g->dsm_cnt + cnt_block;
@@ -2952,9 +2959,20 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         for (int i = 0; i < ASC_RING; ++i) st.h_cnt[i] = 0;
     }
     hipLaunchKernelGGL(k_asc_start, dim3(nR), dim3(64), 0, g->stream, st, d, g->asc_dio + 2 * d, dlb, dub);
-    CHK(score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt));
+    bool first_folded = false;   // the start points' adoption and first direction ran in the gradient kernel's last workgroup (SmallFold, on = 2)
+    {
+        SmallFold fold{};
+        fold.on = 2; fold.R = (int)R; fold.ring_slot = ASC_RING - 1; fold.st = st; fold.lb = dlb; fold.ub = dub; fold.first_step_scale = g_asc_first_step * span;
+        g->asc_fold = (free_run && g_asc_fold) ? &fold : nullptr;
+        g->asc_fold_done = false;
+        const int rc_first = score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt);
+        g->asc_fold = nullptr;
+        CHK(rc_first);
+        first_folded = g->asc_fold_done;
+    }
     bool any_active = true;
-    if (free_run) {
+    if (first_folded) {
+    } else if (free_run) {
         // no synchronisation here: how many start points are active at all is counted by the adopt kernel into the ring slot the host reads
         // once the first pass is queued (below)
         hipLaunchKernelGGL(k_asc_adopt_count, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, ASC_RING - 1);
@@ -2979,7 +2997,7 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
         // LAG passes run beyond convergence.  Same per-start-point trajectories as the lock-step form below.
         const int LAG = 1;   // (2 until round 4: with 17 passes per call instead of 228 a wasted pass is 5 % of it; one queued pass keeps the device fed)
         if (any_active) {
-            hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, 0, 0, dlb, dub, g_asc_first_step * span);
+            if (!first_folded) hipLaunchKernelGGL(k_asc_direction, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, 0, 0, dlb, dub, g_asc_first_step * span);
             int64_t e = 0, converged_at = -1;
             bool none_active = false;
             auto read_count = [&](int64_t pass) -> int {   // active start points after `pass` (waits for it if need be)
@@ -2994,12 +3012,18 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
             };
             for (; evals < maxeval && !out_of_time(); ++e) {
                 g->asc_go = st.ticket;   // (written by the adopt kernel and by every pass's step: active start points)
+                SmallFold fold{};
+                fold.on = 1; fold.R = (int)R; fold.ring_slot = (int)(e % ASC_RING); fold.st = st; fold.lb = dlb; fold.ub = dub; fold.ftol_rel = ftol_rel; fold.xtol_abs = xtol_abs;
+                g->asc_fold = g_asc_fold ? &fold : nullptr;
+                g->asc_fold_done = false;
                 const int rc_pass = score_grad_core(g, acq_id, acq_params, st.Xt, R, st.ft, st.Gt);
                 g->asc_go = nullptr;
+                g->asc_fold = nullptr;
                 CHK(rc_pass);
                 ++evals;
-                hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, g_asc_first_step * span, ftol_rel, xtol_abs,
-                                   (int)(e % ASC_RING));
+                if (!g->asc_fold_done)   // (more than 16 start points, d > 16, or the batch took another path: the step as a launch of its own)
+                    hipLaunchKernelGGL(k_asc_step, dim3(nR), dim3(64), 0, g->stream, st, d, (int)R, dlb, dub, g_asc_first_step * span, ftol_rel, xtol_abs,
+                                       (int)(e % ASC_RING));
                 HIPCHK(hipGetLastError());
                 if (e == 0) {   // the adopt kernel's count (the device is busy with the first pass meanwhile)
                     const int n0 = read_count(ASC_RING - 1);

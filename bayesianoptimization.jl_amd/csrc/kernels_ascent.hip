@@ -68,6 +68,22 @@ __device__ __forceinline__ double asc_csum(double v, int d) {
     if (d > 1) v += asc_dpp_pair<(1 | (0 << 2) | (3 << 4) | (2 << 6)), 0xf, 0, 0>(v);   // lane ^ 1: quad_perm [1, 0, 3, 2]
     return readlane_f64(v, 0);
 }
+// Four start points per wave (round 6, the step folded into k_small_u's last workgroup): lane = 16 * (start point in the wave) + coordinate,
+// d <= 16.  asc_csum's levels inside every row of 16 lanes, and no readlane: the rows of a wave are at different places of their searches.
+__device__ __forceinline__ double asc_rsum(double v, int d) {
+    if (d > 8) v += asc_dpp_pair<0x108, 0x3, 0x118, 0xc>(v);
+    if (d > 4) v += asc_dpp_pair<0x104, 0x5, 0x114, 0xa>(v);
+    if (d > 2) v += asc_dpp_pair<(2 | (3 << 2) | (0 << 4) | (1 << 6)), 0xf, 0, 0>(v);
+    if (d > 1) v += asc_dpp_pair<(1 | (0 << 2) | (3 << 4) | (2 << 6)), 0xf, 0, 0>(v);
+    // lane 0 of the row has run asc_csum's own sequence; its total goes to the row's other lanes (row_newbcast:0).  NOT the lanes' own totals:
+    // the compiler may fold the product that feeds a sum into the first level's addition (an fma whose two partners then round differently)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <bool ROWS>
+__device__ __forceinline__ double asc_sum_t(double v, int d) { if constexpr (ROWS) return asc_rsum(v, d); else return asc_csum(v, d); }
 // A sum over all 64 lanes (k_ascent_wg: a row of W against k*, one partial sum per lane), the same way: four DPP levels inside every row
 // of 16 lanes, then the four row totals from lanes 0, 16, 32, 48.  Wave-uniform result.  (The association differs from the butterfly's --
 // rows first --: the one-workgroup form agrees with the batched kernels to rounding, as it always did, not bit for bit.)
@@ -81,9 +97,10 @@ __device__ __forceinline__ double asc_wsum_dpp(double v) {
 // Does start point r go on after an iteration that moved it by s (this lane's coordinate, new value xn) and changed the value by
 // df to fn?  NLopt's tests for a maximisation: ftol_rel, ftol_abs on the improvement, xtol_abs on the step (its norm, as before),
 // xtol_rel per coordinate (stop when EVERY |dx_k| <= xtol_rel |x_k|), stopval.  Wave-uniform (the sums are butterflies).
+template <bool ROWS = false>
 __device__ __forceinline__ bool asc_goes_on(const AscentState& st, int d, bool on, double s, double xn, double df, double fn, double moved,
                                             double ftol_rel, double xtol_abs) {
-    const double n_big = asc_csum((on && fabs(s) > st.xtol_rel * fabs(xn)) ? 1.0 : 0.0, d);   // coordinates that moved by more than xtol_rel |x|
+    const double n_big = asc_sum_t<ROWS>((on && fabs(s) > st.xtol_rel * fabs(xn)) ? 1.0 : 0.0, d);   // coordinates that moved by more than xtol_rel |x|
     return df > ftol_rel * fmax(fabs(fn), 1e-300) && moved > xtol_abs && df > st.ftol_abs && (st.xtol_rel <= 0.0 || n_big > 0.0) &&
            !(fn >= st.stopval);
 }
@@ -137,11 +154,15 @@ __global__ __launch_bounds__(64) void k_asc_adopt_count(AscentState st, int d, i
 }
 
 // nh curvature pairs are valid; the newest sits in slot (newest), older ones in the slots before it (ring of ASC_M)
+// (ROWS: four start points per wave as in asc_step_compute, for the FIRST direction only -- nh = 0 --, with the gradient and the start
+// point's activity handed in by asc_first_rows, which has just adopted them)
+template <bool ROWS = false>
 __device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, int k, int d, int R, int nh, int newest,
-                                                  const double* __restrict__ lb, const double* __restrict__ ub, double first_step_scale) {
-    const bool on = k < d;
+                                                  const double* __restrict__ lb, const double* __restrict__ ub, double first_step_scale,
+                                                  double g_in = 0.0, int active_in = 0, double f_in = 0.0) {
+    const bool on = k < d && r < R;
     const int64_t o = (int64_t)r * d + k;
-    const double x = on ? st.X[o] : 0.0, g = on ? st.G[o] : 0.0;
+    const double x = on ? st.X[o] : 0.0, g = ROWS ? (on ? g_in : 0.0) : (on ? st.G[o] : 0.0);
     const double lo = on ? lb[k] : 0.0, hi = on ? ub[k] : 0.0;
     // FREE SUBSPACE (round 4): a coordinate that sits on a bound with the gradient pushing outward takes no part in the two-loop
     // recursion -- not in the vector it starts from and not in the curvature pairs' inner products.  Rounds 1-3 ran the recursion in the
@@ -158,15 +179,15 @@ __device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, 
         const int slot = (newest - i + ASC_M) % ASC_M;
         const int64_t ho = ((int64_t)slot * R + r) * d + k;
         const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
-        const double sy = asc_csum(y * s, d);
+        const double sy = asc_sum_t<ROWS>(y * s, d);
         rho[i] = sy > 1e-14 ? 1.0 / sy : 0.0;     // (a pair without curvature in the free subspace is skipped)
-        al[i] = rho[i] * asc_csum(s * q, d);
+        al[i] = rho[i] * asc_sum_t<ROWS>(s * q, d);
         q -= al[i] * y;
     }
     if (nh > 0) {
         const int64_t ho = ((int64_t)newest * R + r) * d + k;
         const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
-        const double sy = asc_csum(s * y, d), yy = fmax(asc_csum(y * y, d), 1e-300);
+        const double sy = asc_sum_t<ROWS>(s * y, d), yy = fmax(asc_sum_t<ROWS>(y * y, d), 1e-300);
         q *= sy > 1e-14 ? sy / yy : 1.0;
     }
 #pragma unroll
@@ -175,26 +196,26 @@ __device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, 
         const int slot = (newest - i + ASC_M) % ASC_M;
         const int64_t ho = ((int64_t)slot * R + r) * d + k;
         const double s = fr ? st.S[ho] : 0.0, y = fr ? st.Y[ho] : 0.0;
-        const double b = rho[i] * asc_csum(y * q, d);
+        const double b = rho[i] * asc_sum_t<ROWS>(y * q, d);
         q += (al[i] - b) * s;
     }
     // do not push active constraints outward; fall back to the projected gradient if that is no ascent direction
     double D = q;
     if ((x <= lo && D < 0.0) || (x >= hi && D > 0.0)) D = 0.0;
     const double gp = ((x <= lo && g < 0.0) || (x >= hi && g > 0.0)) ? 0.0 : g;
-    double slope = asc_csum(on ? gp * D : 0.0, d);
+    double slope = asc_sum_t<ROWS>(on ? gp * D : 0.0, d);
     if (!(slope > 0.0)) {
         D = gp;
-        slope = asc_csum(on ? gp * gp : 0.0, d);
+        slope = asc_sum_t<ROWS>(on ? gp * gp : 0.0, d);
     }
-    const int active = st.active[r];
+    const int active = ROWS ? active_in : st.active[r];
     double step = 1.0;
     // The FIRST step (no curvature pair yet).  Round 6: the unit step on the projected gradient itself, which is what L-BFGS-B does -- its first
     // iterate is the generalised Cauchy point of the model with B = I, P(x + g), tried with step 1 -- but never shorter than a tenth of the box
     // (first_step_scale / |D|, the cautious step rounds 3-5 always took: it slid into the nearest local maximum where SciPy's reaches the
     // corner the gradient points at -- over 8 x 10 starts on the headline model 44 of 80 ended at or above SciPy's value from the same start,
     // with the unit step 72 of 80 -- but on a flat tail, |g| << 1, it is the only step that gets anywhere).
-    if (nh == 0) step = fmax(1.0, first_step_scale / fmax(sqrt(asc_csum(on ? D * D : 0.0, d)), 1e-12));
+    if (nh == 0) step = fmax(1.0, first_step_scale / fmax(sqrt(asc_sum_t<ROWS>(on ? D * D : 0.0, d)), 1e-12));
     if (!(active && slope > 0.0)) step = 0.0;
     if (on) {
         st.D[o] = D;
@@ -203,13 +224,34 @@ __device__ __forceinline__ void asc_direction_one(const AscentState& st, int r, 
         st.Gn[o] = g;
         st.Xt[o] = asc_clip(x + step * D, lo, hi);
     }
-    if (k == 0) {
+    if (k == 0 && r < R) {
         st.step[r] = step;
-        st.fn[r] = st.f[r];
+        st.fn[r] = ROWS ? f_in : st.f[r];
         const int acc = (!active || !(slope > 0.0)) ? 1 : 0;
         st.accepted[r] = acc;
         st.h_accepted[r] = acc;
     }
+}
+// The free-running form's first pass in k_small_u's last workgroup (ROWS layout): k_asc_adopt_count's adoption of the start points' values and
+// gradients, then k_asc_direction's first direction and trial point.  Returns (lanes k == 0) whether start point r is active at all.
+__device__ __forceinline__ int asc_first_rows(const AscentState& st, int r, int k, int d, int R, const double* __restrict__ lb,
+                                              const double* __restrict__ ub, double first_step_scale, double ft, double g_trial) {
+    const bool on = k < d && r < R;
+    const int active = (r < R && isfinite(ft)) ? 1 : 0;
+    if (on) {
+        st.G[(int64_t)r * d + k] = g_trial;
+        st.best_X[(int64_t)r * d + k] = st.X[(int64_t)r * d + k];
+    }
+    if (k == 0 && r < R) {
+        st.f[r] = ft;
+        st.best_f[r] = ft;
+        st.active[r] = active;
+        st.h_active[r] = active;
+        st.it[r] = 0;
+        st.bt[r] = 0;
+    }
+    asc_direction_one<true>(st, r, k, d, R, 0, 0, lb, ub, first_step_scale, g_trial, active, ft);
+    return active;
 }
 __global__ __launch_bounds__(64) void k_asc_direction(AscentState st, int d, int R, int nh, int newest,
                                                       const double* __restrict__ lb, const double* __restrict__ ub,
@@ -293,10 +335,11 @@ __device__ __forceinline__ void asc_age_order_t(const double (&sv)[ASC_M], const
         py[i] = yv[(NEWEST - i + ASC_M) % ASC_M];
     }
 }
+template <bool ROWS = false>
 __device__ __forceinline__ void asc_age_order(int newest, const double (&sv)[ASC_M], const double (&yv)[ASC_M], double s_new, double y_new,
                                               double (&ps)[ASC_M], double (&py)[ASC_M]) {
     static_assert(ASC_M == 8, "eight arms");
-    switch (__builtin_amdgcn_readfirstlane(newest)) {     // (one start point per wave: uniform)
+    switch (ROWS ? newest : __builtin_amdgcn_readfirstlane(newest)) {     // (one start point per wave: uniform; four: up to four arms run)
         case 0: asc_age_order_t<0>(sv, yv, s_new, y_new, ps, py); break;
         case 1: asc_age_order_t<1>(sv, yv, s_new, y_new, ps, py); break;
         case 2: asc_age_order_t<2>(sv, yv, s_new, y_new, ps, py); break;
@@ -307,27 +350,47 @@ __device__ __forceinline__ void asc_age_order(int newest, const double (&sv)[ASC
         default: asc_age_order_t<7>(sv, yv, s_new, y_new, ps, py); break;
     }
 }
-__device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k, int d, int R, const double* __restrict__ lb,
-                                             const double* __restrict__ ub, double ftol_rel, double xtol_abs, int ring_slot) {
-    const bool on = k < d;
+struct AscStepRegs {   // everything asc_step_compute may need of start point r's state, coordinate k: ONE round of loads
+    int active, bt, it;
+    double lo, hi, x, xt, gpo, g_old, d_old, f, step_old, best_before;
+    double sv[ASC_M], yv[ASC_M];   // the curvature pairs (slot order)
+};
+template <bool ROWS = false>
+__device__ __forceinline__ void asc_step_load(const AscentState& st, int r, int k, int d, int R, const double* __restrict__ lb,
+                                              const double* __restrict__ ub, AscStepRegs& a) {
+    const bool on = k < d && r < R;
     const int64_t o = (int64_t)r * d + k;
-    // everything the step may need, in ONE round of loads (taken one by one as the branches reach them they were a chain of
-    // five or six dependent memory round trips: 8 us for a few hundred flops)
-    int active = st.active[r];
-    const double lo = on ? lb[k] : 0.0, hi = on ? ub[k] : 0.0;
-    const double x = on ? st.X[o] : 0.0, xt = on ? st.Xt[o] : 0.0, gpo = on ? st.Gp[o] : 0.0;
-    const double g_old = on ? st.G[o] : 0.0, g_trial = on ? st.Gt[o] : 0.0, d_old = on ? st.D[o] : 0.0;
-    const double ft = st.ft[r], f = st.f[r], step_old = st.step[r], best_before = st.best_f[r];
-    const int bt = st.bt[r], it = st.it[r];
-    double sv[ASC_M], yv[ASC_M];   // the curvature pairs (slot order), also in flight now
+    const int rl = r < R ? r : 0;
+    // (taken one by one as the branches reach them these were a chain of five or six dependent memory round trips: 8 us for a few hundred flops)
+    a.active = r < R ? st.active[rl] : 0;
+    a.lo = on ? lb[k] : 0.0; a.hi = on ? ub[k] : 0.0;
+    a.x = on ? st.X[o] : 0.0; a.xt = on ? st.Xt[o] : 0.0; a.gpo = on ? st.Gp[o] : 0.0;
+    a.g_old = on ? st.G[o] : 0.0; a.d_old = on ? st.D[o] : 0.0;
+    a.f = st.f[rl]; a.step_old = st.step[rl]; a.best_before = st.best_f[rl];
+    a.bt = st.bt[rl]; a.it = st.it[rl];
 #pragma unroll
     for (int i = 0; i < ASC_M; ++i) {
         const int64_t ho = ((int64_t)i * R + r) * d + k;
-        sv[i] = on ? st.S[ho] : 0.0;
-        yv[i] = on ? st.Y[ho] : 0.0;
+        a.sv[i] = on ? st.S[ho] : 0.0;
+        a.yv[i] = on ? st.Y[ho] : 0.0;
     }
+}
+// ROWS (four start points per wave, lane = 16 * row + k, d <= 16; rows with r >= R idle): every sum is the row's own (asc_rsum), and the
+// number of the pass's active start points is the caller's to add up -- the return value, valid in the lanes k == 0, says whether r goes on.
+// ft / g_trial: the trial point's value and gradient (k_small_u's last workgroup has just made them; k_asc_step loads them).
+template <bool ROWS = false>
+__device__ __forceinline__ int asc_step_compute(const AscentState& st, const AscStepRegs& a, int r, int k, int d, int R, double ftol_rel, double xtol_abs,
+                                                int ring_slot, double ft, double g_trial) {
+    const bool on = k < d && r < R;
+    const int64_t o = (int64_t)r * d + k;
+    int active = a.active;
+    const double lo = a.lo, hi = a.hi, x = a.x, xt = a.xt, gpo = a.gpo, g_old = a.g_old, d_old = a.d_old, f = a.f, step_old = a.step_old,
+                 best_before = a.best_before;
+    const int bt = a.bt, it = a.it;
+    const double (&sv)[ASC_M] = a.sv;
+    const double (&yv)[ASC_M] = a.yv;
     if (active) {
-        const double dot = asc_csum(on ? gpo * (xt - x) : 0.0, d);
+        const double dot = asc_sum_t<ROWS>(on ? gpo * (xt - x) : 0.0, d);
         const bool ok = isfinite(ft) && ft >= f + 1e-4 * dot;
         if (!ok && bt < ASC_MAX_BT - 1) {
             const double step = step_old * 0.5;
@@ -338,9 +401,9 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
             const double g = g_old;
             const double xn = ok ? xt : x, gn = ok ? g_trial : g, fn = ok ? ft : f;
             const double s = xn - x, y = -(gn - g), df = fn - f;
-            const double moved = sqrt(asc_csum(s * s, d));
-            const bool good = asc_csum(s * y, d) > 1e-14;
-            active = asc_goes_on(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs) ? 1 : 0;
+            const double moved = sqrt(asc_sum_t<ROWS>(s * s, d));
+            const bool good = asc_sum_t<ROWS>(s * y, d) > 1e-14;
+            active = asc_goes_on<ROWS>(st, d, on, s, xn, df, fn, moved, ftol_rel, xtol_abs) ? 1 : 0;
             const int slot = it % ASC_M;
             const double s_new = good ? s : 0.0, y_new = good ? y : 0.0;
             if (on) {
@@ -366,7 +429,7 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
                 // rotation is resolved by ONE wave-uniform switch on `newest` whose eight arms are register renames (28 moves) -- until
                 // round 5 every use selected its pair out of all eight slots (16 v_cndmask per pair and use: the step grew by 0.6 us per pair).
                 double ps_age[ASC_M], py_age[ASC_M];
-                asc_age_order(newest, sv, yv, s_new, y_new, ps_age, py_age);
+                asc_age_order<ROWS>(newest, sv, yv, s_new, y_new, ps_age, py_age);
                 auto pair_s = [&](int i) { return ps_age[i]; };
                 auto pair_y = [&](int i) { return py_age[i]; };
                 // (the free subspace of asc_direction_one: coordinates on a bound with the gradient pushing outward stay out)
@@ -377,30 +440,30 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
                 for (int i = 0; i < ASC_M; ++i) {   // newest -> oldest
                     if (i >= nh) break;
                     const double ps = fr ? pair_s(i) : 0.0, py = fr ? pair_y(i) : 0.0;
-                    const double sy = asc_csum(py * ps, d);
+                    const double sy = asc_sum_t<ROWS>(py * ps, d);
                     rho[i] = sy > 1e-14 ? 1.0 / sy : 0.0;
-                    al[i] = rho[i] * asc_csum(ps * q, d);
+                    al[i] = rho[i] * asc_sum_t<ROWS>(ps * q, d);
                     q -= al[i] * py;
                 }
                 {
                     const double sf = fr ? s_new : 0.0, yf = fr ? y_new : 0.0;
-                    const double sy = asc_csum(sf * yf, d), yy = fmax(asc_csum(yf * yf, d), 1e-300);
+                    const double sy = asc_sum_t<ROWS>(sf * yf, d), yy = fmax(asc_sum_t<ROWS>(yf * yf, d), 1e-300);
                     q *= sy > 1e-14 ? sy / yy : 1.0;
                 }
 #pragma unroll
                 for (int i = ASC_M - 1; i >= 0; --i) {   // oldest -> newest
                     if (i >= nh) continue;
                     const double ps = fr ? pair_s(i) : 0.0, py = fr ? pair_y(i) : 0.0;
-                    const double b = rho[i] * asc_csum(py * q, d);
+                    const double b = rho[i] * asc_sum_t<ROWS>(py * q, d);
                     q += (al[i] - b) * ps;
                 }
                 double D = q;
                 if ((xn <= lo && D < 0.0) || (xn >= hi && D > 0.0)) D = 0.0;
                 const double gp = ((xn <= lo && gn < 0.0) || (xn >= hi && gn > 0.0)) ? 0.0 : gn;
-                double slope = asc_csum(on ? gp * D : 0.0, d);
+                double slope = asc_sum_t<ROWS>(on ? gp * D : 0.0, d);
                 if (!(slope > 0.0)) {
                     D = gp;
-                    slope = asc_csum(on ? gp * gp : 0.0, d);
+                    slope = asc_sum_t<ROWS>(on ? gp * gp : 0.0, d);
                 }
                 if (slope > 0.0) {
                     if (on) {
@@ -417,6 +480,7 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
             if (k == 0) st.active[r] = active;
         }
     }
+    if constexpr (ROWS) return active;
     if (k == 0 && ring_slot >= 0) {
         // ONE 64-bit counter per pass: arrivals in the low word, still-active start points in the high word -- no fence between
         // two counters (a __threadfence() is an L2 write-back here: microseconds per workgroup)
@@ -429,6 +493,14 @@ __device__ __forceinline__ void asc_step_one(const AscentState& st, int r, int k
             __hip_atomic_store(st.h_cnt + ring_slot, (int)n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the host reads nothing else on the strength of it: no release, which would be a cache write-back)
         }
     }
+    return active;
+}
+__device__ __forceinline__ int asc_step_one(const AscentState& st, int r, int k, int d, int R, const double* __restrict__ lb,
+                                            const double* __restrict__ ub, double ftol_rel, double xtol_abs, int ring_slot) {
+    AscStepRegs a;
+    asc_step_load<false>(st, r, k, d, R, lb, ub, a);
+    const double g_trial = k < d ? st.Gt[(int64_t)r * d + k] : 0.0, ft = st.ft[r];
+    return asc_step_compute<false>(st, a, r, k, d, R, ftol_rel, xtol_abs, ring_slot, ft, g_trial);
 }
 __global__ __launch_bounds__(64) void k_asc_step(AscentState st, int d, int R, const double* __restrict__ lb,
                                                  const double* __restrict__ ub, double first_step_scale, double ftol_rel,

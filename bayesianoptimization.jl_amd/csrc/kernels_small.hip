@@ -64,12 +64,23 @@ struct SmallV {
     int finish;             // 1: this kernel also finishes the posterior (value-only call); 0: k_small_u's last workgroup does (one counter level and
                             // one serial tail less in front of the U pass)
 };
+// Round 6: the free-running ascent's step (kernels_ascent.hip asc_step_one) runs in k_small_u's LAST workgroup, right behind the gradient --
+// its own launch was 4.6 us of launch + one round of loads before the first flop, the third kernel of every pass.  One pass of <= 16
+// candidates and d <= 16 only (four start points per wave); everything else keeps k_asc_step.
+struct SmallFold {
+    int on;                 // 0: no step here; 1: asc_step_compute (a pass of the search); 2: asc_first_rows (the start points' own evaluation)
+    int R, ring_slot;
+    AscentState st;
+    const double *lb, *ub;
+    double ftol_rel, xtol_abs, first_step_scale;
+};
 struct SmallU {
     const double* v16;
     SmallV sv;              // the posterior finish rides in this kernel's last workgroup (same device function as the value-only call: same bits)
     double* gpart;          // [pass][ntiles][16][DT]  the tiles' u-weighted gradient sums
     double* gmpart;         // [pass][T][16][DT]       the column blocks' alpha-weighted gradient sums
     double* grad;           // [P][d]
+    SmallFold fold;
 };
 
 __device__ __forceinline__ int small_slot_to_r(int slot) { return 4 * (slot & 3) + (slot >> 2); }
@@ -661,7 +672,14 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, unsigned gow
     const int pcand = min(16, sc.P - pass * 16), dh = (d + 1) / 2;      // candidates of this pass, dimension pairs
     const int npairs = pcand * dh;                                       // <= 16 * 32
     constexpr int FT = SP_THREADS - 128;                                 // fetching threads
-    double* gfin = lbuf;                                                 // [nparts][npairs][4]
+    // (the step's state: requested now, used behind the gradient -- its round trip to memory rides under the posterior and the records' fetch)
+    AscStepRegs fold_regs;
+    if (su.fold.on == 1 && wave < ((su.fold.R + 3) >> 2))
+        asc_step_load<true>(su.fold.st, 4 * wave + (lane >> 4), lane & 15, d, su.fold.R, su.fold.lb, su.fold.ub, fold_regs);
+    double* gfin = lbuf;                                                 // [nparts][npairs][4]  (<= 384 x 4)
+    double* const fold_g = lbuf + 4096;                                  // [16][16] the pass's gradients, [16] its values: the ascent's step below
+    double* const fold_f = lbuf + 4096 + 256;
+    unsigned* const fold_cnt = reinterpret_cast<unsigned*>(lbuf + 4096 + 256 + 16);
     if (tid < 128) {
         const int slot_ = tid & 63;
         if (slot_ < 16 && pass * 16 + small_slot_to_r(slot_) < sc.P) {
@@ -683,7 +701,9 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, unsigned gow
                 const int rr = pass * 16 + small_slot_to_r(slot_);
                 if (su.sv.mu_out) su.sv.mu_out[rr] = mu;
                 if (su.sv.var_out) su.sv.var_out[rr] = s2;
-                if (su.sv.score_out) su.sv.score_out[rr] = acq_eval(su.sv.ap, mu, s2);
+                const double fv = acq_eval(su.sv.ap, mu, s2);
+                if (su.sv.score_out) su.sv.score_out[rr] = fv;
+                fold_f[rr & 15] = fv;
             } else {
                 double dmu, ds2;
                 acq_partials(su.sv.ap, mu, s2, dmu, ds2);
@@ -747,8 +767,34 @@ __device__ __forceinline__ void small_u_body(const SmallCommon& sc, unsigned gow
             const int rr = pass * 16 + ri2;
             const double dmu = post_l[2 * sl2], ds2 = post_l[2 * sl2 + 1], v = post_l[32 + sl2];
             // a clamped variance (sigma^2 == 0 exactly) has zero gradient, like max(., 0) under ForwardDiff
-            su.grad[(int64_t)rr * d + 2 * k22] = dmu * a.x + (v > 0.0 ? ds2 * (-2.0 * b.x) : 0.0);
-            if (2 * k22 + 1 < d) su.grad[(int64_t)rr * d + 2 * k22 + 1] = dmu * a.y + (v > 0.0 ? ds2 * (-2.0 * b.y) : 0.0);
+            const double g0 = dmu * a.x + (v > 0.0 ? ds2 * (-2.0 * b.x) : 0.0), g1 = dmu * a.y + (v > 0.0 ? ds2 * (-2.0 * b.y) : 0.0);
+            su.grad[(int64_t)rr * d + 2 * k22] = g0;
+            if (2 * k22 + 1 < d) su.grad[(int64_t)rr * d + 2 * k22 + 1] = g1;
+            fold_g[ri2 * 16 + ((2 * k22) & 15)] = g0;
+            fold_g[ri2 * 16 + ((2 * k22 + 1) & 15)] = g1;
+        }
+        if (su.fold.on) {
+            // ---- the ascent's step of every start point of the pass (free-running form: what k_asc_step did in a launch of its own)
+            if (tid == 0) *fold_cnt = 0u;
+            __syncthreads();
+            const int nw = (su.fold.R + 3) >> 2;
+            if (wave < nw) {
+                const int row = lane >> 4, k = lane & 15, r = 4 * wave + row;
+                const double ft_ = fold_f[r & 15], gt_ = k < d ? fold_g[(r & 15) * 16 + k] : 0.0;
+                const int act = su.fold.on == 1 ? asc_step_compute<true>(su.fold.st, fold_regs, r, k, d, su.fold.R, su.fold.ftol_rel, su.fold.xtol_abs,
+                                                                         su.fold.ring_slot, ft_, gt_)
+                                                : asc_first_rows(su.fold.st, r, k, d, su.fold.R, su.fold.lb, su.fold.ub, su.fold.first_step_scale, ft_, gt_);
+                const unsigned long long bal = __ballot(act != 0 && k == 0 && r < su.fold.R);
+                if (lane == 0) {
+                    const unsigned mine = (unsigned)__popcll(bal);
+                    const unsigned before = atomicAdd(fold_cnt, (mine << 8) | 1u);
+                    if ((before & 0xffu) == (unsigned)nw - 1u) {      // the last of the step's waves publishes the pass's count (asc_step_one's tail)
+                        const unsigned n = (before >> 8) + mine;
+                        __hip_atomic_store(su.fold.st.ticket, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(su.fold.st.h_cnt + su.fold.ring_slot, (int)n + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
         }
     } else {
         // (more pairs than fetching threads: d > 48 with a full pass -- every thread of the workgroup takes pairs in turn, one record at a time)

@@ -666,7 +666,7 @@ import json, sys
 sys.path.insert(0, %r)
 import numpy as np, bohip
 out = {}
-for N, d, R in ((700, 3, 10), (1100, 2, 37), (900, 4, 300)):
+for N, d, R in ((700, 3, 10), (1100, 2, 37), (900, 4, 300), (800, 9, 13), (600, 16, 16), (650, 5, 1)):
     rng = np.random.default_rng(N)
     X = rng.random((N, d)); y = np.sin(3 * X).sum(1) + 0.1 * rng.standard_normal(N)
     m = bohip.ElasticGPE(d, kernel=bohip.SEArd(np.full(d, -0.9), 0.2), logNoise=-2.0, capacity=N)
@@ -678,7 +678,9 @@ for N, d, R in ((700, 3, 10), (1100, 2, 37), (900, 4, 300)):
 print("RESULT" + json.dumps(out))
 ''' % ROOT
     res = {}
-    for name, env in (("free", {}), ("lockstep", {"BOHIP_ASC_LOCKSTEP": "1"})):
+    # round 6: with <= 16 start points and d <= 16 the step runs in the gradient kernel's last workgroup, four start points per wave
+    # (kernels_small.hip SmallFold); BOHIP_ASC_LOCKSTEP=2 keeps it a launch of its own (k_asc_step) -- the same trajectories again
+    for name, env in (("free", {}), ("own_launch", {"BOHIP_ASC_LOCKSTEP": "2"}), ("lockstep", {"BOHIP_ASC_LOCKSTEP": "1"})):
         o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert o.returncode == 0, (name, o.stderr[-2000:])
         res[name] = json.loads([l for l in o.stdout.splitlines() if l.startswith("RESULT")][-1][6:])
@@ -687,6 +689,7 @@ print("RESULT" + json.dumps(out))
         assert a["f"] == b["f"] and a["X"] == b["X"], key
         assert (a["bf"], a["bi"], a["bx"]) == (b["bf"], b["bi"], b["bx"]), key
         assert 1 <= a["ev"] <= b["ev"], (key, a["ev"], b["ev"])
+        assert a == res["own_launch"][key], key
 
 
 def test_one_workgroup_per_start_ascent_against_the_batched_driver():
