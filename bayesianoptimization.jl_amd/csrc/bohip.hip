@@ -1472,7 +1472,7 @@ static int refit_once(bohip_gp* g, double jitter) {
     const bool want_df = !paused && df_size;
     // (from TWO row tiles on with the inverse queues: at T = 2, 3 the executor has no factorisation task at all -- every tile is inside the
     // chain kernel's window -- but it grows W = L^-1 behind the chain: N = 200 0.15 instead of 0.21 ms, N = 300 0.20 instead of 0.28)
-    const int exec_min = g_chol_exec_min >= 0 ? g_chol_exec_min : (g_chol_inv_g > 0 ? 2 : 32);
+    const int exec_min = g_chol_exec_min >= 0 ? g_chol_exec_min : (g_chol_inv_g > 0 ? 2 : 24);   // (alone: 32 until round 6 -- since the chain's blocks run on the matrix pipe the first form's followers are what lags from 24 row tiles on: N=3000 1.15 against 1.18 ms, N=3500 1.37 / 1.51; N=2500 0.935 / 0.908)
     const bool exec_ok = g_chol_exec && T >= std::max(g_chol_inv_g > 0 ? 2 : 4, exec_min) && cus >= 9 + g_chol_nsf + 6 + 8;
     const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
     const bool form1_ok = T >= 3 && cus >= 8 + 3 * std::max(0, T - 3) + 8;
