@@ -19,7 +19,7 @@ ACQ = {"EI": 0, "PI": 1, "UCB": 2, "MI": 3, "MaxMean": 4}
 INFO_PIVOT, INFO_CAPACITY, INFO_REFITS, INFO_APPENDS = 0, 1, 2, 3
 INFO_CHOL_FORM, INFO_CHOL_FALLBACKS, INFO_CHOL_ABORT_TILES, INFO_JITTER_STEPS = 4, 5, 6, 7
 INFO_SCORE_LAUNCHES, INFO_SCORE_CHUNK, INFO_KERNEL_CLOCK_MHZ = 8, 9, 10
-INFO_COMM_NRANKS, INFO_COMM_EXCHANGES, INFO_COMM_RCCL_VERSION = 11, 12, 13
+INFO_COMM_NRANKS, INFO_COMM_EXCHANGES, INFO_COMM_RCCL_VERSION, INFO_CHOL_LOCK_SKIPS = 11, 12, 13, 14
 MGP_INFO_DEVICES, MGP_INFO_SHARDS, MGP_INFO_EXCHANGES, MGP_INFO_RCCL_VERSION, MGP_INFO_COMM_NRANKS = 0, 1, 2, 3, 4
 UNIQUE_ID_BYTES = 128
 

@@ -160,6 +160,9 @@ struct bohip_gp {
     int64_t crec_cap = 0;
     // bookkeeping
     int64_t pivot = 0, refits = 0, appends = 0;
+    int alpha_inc_run = 0;         // appends since alpha was last computed in full (compute_alpha); the incremental form re-synchronises every 256
+    bool mirror_dirty = false;     // a staged append failed after the host mirrors advanced: the next refit uploads X and y again
+    int64_t chol_lock_skips = 0;   // refits that took the launch-chained form because another process held the refit lock
     int chol_form_last = 0;            // BOHIP_INFO_CHOL_FORM: 0 launch chain, 1 dataflow form 1, 2 form 2, 3 form 2 left-looking, 4 executor
     int64_t chol_fallbacks = 0;        // BOHIP_INFO_CHOL_FALLBACKS: refits of this handle that timed out on a dependency and were redone launch-chained
     int chol_abort_T = 0;              // BOHIP_INFO_CHOL_ABORT_TILES: row tiles of the last factorisation that timed out (0: never)
@@ -432,6 +435,8 @@ static int compute_alpha(bohip_gp* g) {
     // alpha = W'(W (y - beta)): two passes of the row-wise kernel (W, then the resident W' as an upper-triangular
     // K-major matrix) with one right-hand side
     const int64_t N = g->n;
+    g->alpha_inc_run = 0;
+    // (dr = y - beta and dt = W (y - beta) stay behind for the incremental update of the appends: nothing else may write them between refits)
     hipLaunchKernelGGL(k_sub_mean, dim3((N + 255) / 256), dim3(256), 0, g->stream, g->dy, g->beta, N, g->dr);
     HIPCHK(hipGetLastError());
     CHK(launch_rows_trimv(g, g->dW, N, g->dr, 1, g->dt, 0));
@@ -1304,10 +1309,13 @@ struct DfFileLock {
         snprintf(path, sizeof path, "%s/bohip_refit_%s.lock", dir, bus);
         return open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
     }
-    explicit DfFileLock(int device) {
-        // BOHIP_DF_FILE_LOCK: 0 = off, 1 = on with the default wait (300 ms), n > 1 = on, waiting up to n ms for the other process
+    bool contended = false;   // another process held the lock for the whole wait: this refit takes the launch-chained form (nothing in it spins)
+    DfFileLock() = default;
+    // T: row tiles of the refit -- the wait covers a dozen refits of this size by the other process (300 ms up to ~50 row tiles, T^2 / 8 ms beyond)
+    void acquire(int device, int T) {
+        // BOHIP_DF_FILE_LOCK: 0 = off, 1 = on with the default wait, n > 1 = on, waiting up to n ms for the other process
         static int setting = [] { const char* e = getenv("BOHIP_DF_FILE_LOCK"); return e ? std::max(0, atoi(e)) : 1; }();
-        const int enabled = setting != 0, wait_ms = setting > 1 ? setting : 300;
+        const int enabled = setting != 0, wait_ms = setting > 1 ? setting : std::max(300, T * T / 8);
         if (!enabled) return;
         static int fds[64];
         static pid_t owner[64];
@@ -1323,15 +1331,15 @@ struct DfFileLock {
             }
             fd = fds[dv];
         }
-        if (fd < 0) return;
+        if (fd < 0) return;                               // no lock file (directory not ours, ...): unlocked, the time-out fall-back is the safety net
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             if (flock(fd, LOCK_EX | LOCK_NB) == 0) return;
             if (errno != EWOULDBLOCK && errno != EINTR) break;
-            if (std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(wait_ms)) break;
+            if (std::chrono::steady_clock::now() - t0 >= std::chrono::milliseconds(wait_ms)) { contended = true; break; }
             usleep(200);
         }
-        fd = -1;                                          // not ours: go ahead unlocked (the time-out fall-back is the safety net)
+        fd = -1;
     }
     void release() { if (fd >= 0) { flock(fd, LOCK_UN); fd = -1; } }
     ~DfFileLock() { release(); }
@@ -1448,6 +1456,12 @@ static int refit_once(bohip_gp* g, double jitter) {
     const int T = (int)(Npad / TILE);
     const KernelHyper hp = make_hyper(g);
     const double noise = std::exp(2.0 * g->lognoise) + std::numeric_limits<double>::epsilon() + jitter;
+    if (g->mirror_dirty) {   // a staged append failed after the mirrors advanced: the host copies are the truth
+        HIPCHK(hipMemcpyAsync(g->dX, g->hX.data(), (size_t)N * g->d * 8, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipMemcpyAsync(g->dy, g->hy.data(), (size_t)N * 8, hipMemcpyHostToDevice, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        g->mirror_dirty = false;
+    }
     HIPCHK(hipMemsetAsync(g->dinfo, 0, sizeof(int), g->stream));
     t_begin(g, "build_cov");
     {
@@ -1477,14 +1491,27 @@ static int refit_once(bohip_gp* g, double jitter) {
     const bool form2_ok = T >= g_chol_df2_min && cus >= 9 + 32;
     const bool form1_ok = T >= 3 && cus >= 8 + 3 * std::max(0, T - 3) + 8;
     // (stage name: with the executor's inverse queues the factorisation and W = L^-1 are ONE stage)
-    t_begin(g, want_df && exec_ok && g_chol_inv_g > 0 ? "cholesky+inverse" : "cholesky");
-    if (want_df && (exec_ok || form2_ok || form1_ok)) {
+    // One dataflow refit per device at a time (see below): the host lock of this process and the file lock between processes, taken before
+    // the stage begins.  Round 6: when ANOTHER PROCESS keeps the file lock for the whole wait this refit takes the launch-chained form instead
+    // of going ahead unlocked (two processes' persistent kernels on one chip are what the 200 ms time-outs of profiles/r06_soak.txt are made of).
+    std::unique_lock<std::mutex> df_lock;
+    DfFileLock df_file;
+    bool df_go = want_df && (exec_ok || form2_ok || form1_ok);
+    if (df_go) {
+        df_lock = std::unique_lock<std::mutex>(g_df_mutex[g->device & 63]);
+        df_file.acquire(g->device, T);
+        if (df_file.contended) {
+            df_go = false;
+            df_lock.unlock();
+            g->chol_lock_skips++;
+        }
+    }
+    t_begin(g, df_go && exec_ok && g_chol_inv_g > 0 ? "cholesky+inverse" : "cholesky");
+    if (df_go) {
         // One dataflow refit per device at a time: its persistent workgroups must be resident together, and two refits from two host threads
         // (several models on one GPU, the logical shards of bohip_mgp_*) take each other's CUs -- every other one then sat out its 200 ms
         // time-out and fell back (tools/w_stress.py: 6 time-outs in 64 refits on 8 threads).  The refit is synchronous anyway (the abort word is
         // read back below), so a host lock from the first launch to that read costs nothing a contended chip would not have cost.
-        std::unique_lock<std::mutex> df_lock(g_df_mutex[g->device & 63]);
-        DfFileLock df_file(g->device);
         g->w_done = false;
         if (exec_ok) { g->chol_form_last = 4; CHK(cholesky_exec(g, T)); }
         else if (form2_ok && g_chol_df2_ll) { g->chol_form_last = 3; CHK(cholesky_dataflow3(g, T)); }
@@ -1758,7 +1785,9 @@ static int append_incremental(bohip_gp* g, int64_t N0, int64_t p, int* defer_inf
     HIPCHK(hipGetLastError());
     t_end(g);
     t_begin(g, "alpha");
-    if (g_append_alpha_inc) {      // alpha_new = [alpha_old + W21' u2; W22' u2] (kernels_linalg.hip k_alpha_append_*); BOHIP_APPEND_ALPHA_INC=0: the full product
+    if (g_append_alpha_inc && g->alpha_inc_run < 256) {      // (every 256 appends the full product: the increments' rounding does not accumulate without bound)
+        g->alpha_inc_run++;
+        // alpha_new = [alpha_old + W21' u2; W22' u2] (kernels_linalg.hip k_alpha_append_*); BOHIP_APPEND_ALPHA_INC=0: the full product
         hipLaunchKernelGGL(k_alpha_append_u, dim3((unsigned)p), dim3(1024), 0, g->stream, g->dW, ld, N0, (int)p, g->dy, g->beta, g->dr, g->dt);
         hipLaunchKernelGGL(k_alpha_append_apply, dim3((unsigned)((N1 + 255) / 256)), dim3(256), 0, g->stream, g->dW, ld, N0, (int)p, g->dt, g->dalpha);
         HIPCHK(hipGetLastError());
@@ -2529,11 +2558,11 @@ int bohip_gp_append(bohip_gp* g, const double* X, const double* y, int64_t p) {
             g->n = n_new;
             if (!g->stale && g->n_factored == n_old && n_old > 0 && p <= APPEND_PMAX) {
                 rc = append_incremental(g, n_old, p, pinfo);
-                if (rc != 0) g->stale = true;
+                if (rc != 0) { g->stale = true; g->mirror_dirty = staged; }   // (staged: the rows' copies were only queued -- the device may not hold them)
                 done = true;
                 if (rc == 0 && pinfo) {
                     const hipError_t e = hipStreamSynchronize(g->stream);
-                    if (e != hipSuccess) { g->stale = true; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
+                    if (e != hipSuccess) { g->stale = true; g->mirror_dirty = true; return fail(BOHIP_E_HIP, hipGetErrorString(e)); }
                     t_collect(g);
                     if (*pinfo != 0) {
                         g->pivot = *pinfo;
@@ -3168,6 +3197,7 @@ int bohip_gp_info(const bohip_gp* g, int what, int64_t* value) {
         case BOHIP_INFO_COMM_NRANKS: return comm_nranks(g, value);   // read back from the communicator (multigpu.hip)
         case BOHIP_INFO_COMM_EXCHANGES: *value = g->comm_exchanges; return 0;
         case BOHIP_INFO_COMM_RCCL_VERSION: return comm_rccl_version(value);
+        case BOHIP_INFO_CHOL_LOCK_SKIPS: *value = g->chol_lock_skips; return 0;
         default: return fail(BOHIP_E_ARG, "unknown info id");
     }
 }

@@ -181,6 +181,7 @@ int bohip_gp_get_alpha(bohip_gp *gp, double *alpha);
                                         * a sample of its workgroups counts core-clock cycles against the 100 MHz wall clock), else 0 */
 #define BOHIP_INFO_COMM_NRANKS 11 /* ranks of the communicator attached by bohip_gp_comm_init, read back from it (ncclCommCount); 0: none */
 #define BOHIP_INFO_COMM_RCCL_VERSION 13 /* ncclGetVersion of the RCCL the library bound (loads it if no multi-GPU call has yet) */
+#define BOHIP_INFO_CHOL_LOCK_SKIPS 14    /* refits that took the launch-chained form because another process kept the refit lock for the whole wait */
 #define BOHIP_INFO_COMM_EXCHANGES 12 /* RCCL all-gathers this handle has issued so far (bohip_gp_score_sharded_dev / _thompson_sharded) */
 int bohip_gp_info(const bohip_gp *gp, int what, int64_t *value);
 /* Benchmarks only (bench.py, tools/): the executor form of the factorisation grows W = L^-1 behind the pivot chain in

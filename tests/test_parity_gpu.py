@@ -103,7 +103,7 @@ def test_batch_equals_single_bitexact_on_device(bohip, acq, params):
 _ARGMAX_EXEMPT = []   # (N, d, acquisition) cases of test_seeded_vs_oracle that took the near-tie exemption: printed, and bounded below
 @pytest.mark.parametrize("N,d,R,lsig,lnoise,beta", [
     (1, 1, 5, 0.0, -2.0, 0.0), (7, 2, 3, 0.5, -1.0, 0.3), (127, 3, 129, 0.0, -2.0, 0.0), (128, 4, 128, 0.0, -2.0, -1.0),
-    (129, 5, 257, 0.3, -1.5, 0.0), (500, 2, 1000, 5.0, 0.0, 0.0), (1000, 8, 1500, 0.0, -2.0, 0.0), (700, 16, 300, 0.0, -2.0, 0.2)])
+    (129, 5, 257, 0.3, -1.5, 0.0), (500, 2, 1000, 5.0, 0.0, 0.0), (1000, 8, 1500, 0.0, -2.0, 0.0), (700, 16, 300, 0.0, -2.0, 0.2)])   # = _SEEDED_SHAPES below
 def test_seeded_vs_oracle(bohip, orc, N, d, R, lsig, lnoise, beta):
     X, y, Xs = synth(N, d, R, seed=N + d)
     ll = np.linspace(-0.9, -0.3, d)
@@ -134,11 +134,31 @@ def test_seeded_vs_oracle(bohip, orc, N, d, R, lsig, lnoise, beta):
     print(f"test_seeded_vs_oracle: arg-max exemptions so far (oracle's top two closer than the floor): {len(_ARGMAX_EXEMPT)} {_ARGMAX_EXEMPT}")
 
 
-def test_seeded_vs_oracle_argmax_exemptions_are_rare():
-    """Of the 40 (shape, acquisition) cases above, how many skipped the exact arg-max assertion because the ORACLE's own top two scores were
-    closer than the documented floor?  Reported (run with -s) and bounded: the exemption must stay the exception."""
-    print(f"arg-max exemptions: {len(_ARGMAX_EXEMPT)} of 40: {_ARGMAX_EXEMPT}")
-    assert len(_ARGMAX_EXEMPT) <= 4, _ARGMAX_EXEMPT
+_SEEDED_SHAPES = [(1, 1, 5, 0.0, -2.0, 0.0), (7, 2, 3, 0.5, -1.0, 0.3), (127, 3, 129, 0.0, -2.0, 0.0), (128, 4, 128, 0.0, -2.0, -1.0),
+                  (129, 5, 257, 0.3, -1.5, 0.0), (500, 2, 1000, 5.0, 0.0, 0.0), (1000, 8, 1500, 0.0, -2.0, 0.0), (700, 16, 300, 0.0, -2.0, 0.2)]
+
+
+def test_seeded_vs_oracle_argmax_exemptions_are_rare(orc):
+    """Of the 40 (shape, acquisition) cases of test_seeded_vs_oracle, how many skip the exact arg-max assertion because the ORACLE's own top
+    two scores are closer than the documented floor?  The criterion looks at oracle values only, so it is recomputed HERE from the same
+    shapes and seeds (no module-level state: the bound holds under -k and xdist too) and bounded: the exemption must stay the exception."""
+    exempt = []
+    for N, d, R, lsig, lnoise, beta in _SEEDED_SHAPES:
+        X, y, Xs = synth(N, d, R, seed=N + d)
+        ll = np.linspace(-0.9, -0.3, d)
+        L, alpha = orc.fit(X, y, ll, lsig, lnoise, beta)
+        s2f = math.exp(2 * lsig)
+        _, var_o = orc.predict(X, ll, lsig, beta, L, alpha, Xs, nthreads=8)
+        fl = mu_floor(alpha, s2f)
+        for acq, p in [("EI", [float(y.max())]), ("PI", [float(y.max())]), ("UCB", [orc.brochu_beta(d, N)]), ("MI", [1.0, 0.3]), ("MaxMean", [])]:
+            sc_o, _, _ = orc.score(X, ll, lsig, beta, L, alpha, acq, p, Xs, nthreads=8)
+            amp = max(1.0, abs(p[0])) if acq in ("UCB", "MI") else 1.0
+            floor = fl + amp * np.sqrt(var_tol(var_o, N, s2f, rel=0)) if acq in ("UCB", "MI") else fl + var_tol(var_o, N, s2f, rel=0) + 1e-15
+            top2 = np.sort(sc_o)[-2:] if R > 1 else np.array([-np.inf, sc_o[0]])
+            if not top2[1] - top2[0] > 4 * np.max(floor):
+                exempt.append((N, d, acq))
+    print(f"arg-max exemptions: {len(exempt)} of 40: {exempt}")
+    assert len(exempt) <= 4, exempt
 
 
 def test_mat52ard_and_seiso_kernels(bohip, orc):

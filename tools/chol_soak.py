@@ -16,7 +16,7 @@ ts = []
 for _ in range(reps):
     m.set_params_(logNoise=-2.0); m.fit_()
     t = dict(m.timing()); ts.append(t.get("cholesky+inverse", -t.get("cholesky", 0.0)))
-print("RESULT", m.info(5), m.info(4), " ".join("%%.2f" %% v for v in ts))
+print("RESULT", m.info(5), m.info(4), "lock-skips=%%d" %% m.info(14), " ".join("%%.2f" %% v for v in ts))
 ''' % ROOT
 N, procs, reps = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 bad = 0

@@ -1,6 +1,6 @@
 #!/bin/bash
-# everything copied to profiles/r04_* in one GPU call (tag = $1, default r04)
-TAG=${1:-r05}
+# everything copied to profiles/<tag>_* in one GPU call (tag = $1, default r06)
+TAG=${1:-r06}
 out=gpurun_out/$TAG; mkdir -p $out
 bash tools/prof.sh $TAG > $out/prof_stdout.txt 2>&1
 cp gpurun_out/prof_$TAG/summary.txt $out/rocprof_bench_summary.txt 2>/dev/null
@@ -42,3 +42,18 @@ echo "== two processes refitting at once on one device (the non-blocking file lo
 echo "== tools/w_stress.py 3000 8 8"
 timeout 600 python tools/w_stress.py 3000 8 8 2>&1 | grep -v amdgpu
 } > $out/soak.txt 2>&1
+# round 6: the factorisation's timelines (executor form, in-kernel marks), the ascent against SciPy start by start and its KKT margins,
+# the ascent's kernel timeline with the step folded into the gradient kernel (default) and as a launch of its own (BOHIP_ASC_LOCKSTEP=2)
+make -C bayesianoptimization.jl_amd/csrc abl/libbohip_choltrace.so > /dev/null 2>&1
+timeout 200 python tools/exec_trace.py 3000 2>&1 | grep -v amdgpu > $out/exec_trace_N3000.txt
+timeout 300 python tools/exec_trace.py 10000 2>&1 | grep -v amdgpu > $out/exec_trace_N10000.txt
+timeout 900 python tools/ascent_kkt_margin.py 2>&1 | grep -v amdgpu > $out/ascent_kkt_margin.txt
+timeout 900 python tools/ascent_vs_scipy_starts.py 2>&1 | grep -v amdgpu > $out/ascent_vs_scipy_starts.txt
+{
+echo "# step folded into k_small_u's last workgroup (default)"
+bash tools/ascent_timeline.sh
+echo "# step as a launch of its own (BOHIP_ASC_LOCKSTEP=2, rounds 4-5)"
+BOHIP_ASC_LOCKSTEP=2 bash tools/ascent_timeline.sh
+echo "# 40 back-to-back acquire_max, three runs each: folded / own launch"
+for i in 1 2 3; do python tools/ascent_loop_time.py; BOHIP_ASC_LOCKSTEP=2 python tools/ascent_loop_time.py; done 2>&1 | grep ascend
+} > $out/ascent_kernel_timeline.txt 2>&1
