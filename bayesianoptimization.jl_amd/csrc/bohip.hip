@@ -345,6 +345,7 @@ static int g_chol_exec_urgent = -1; // executor workgroups that serve the urgent
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
 static int g_chol_exec_second = 1;   // BOHIP_CHOL_EXEC_SECOND=0: every executor workgroup serves every queue (until round 4).  1: the workgroups beyond one per CU take
                                      // throughput work only (early sums, bulk, waves) and leave when it is exhausted: N = 6000 4.60 -> 4.38 ms, N = 5000 3.27 -> 3.18
+static int g_chol_exec_early_split = 1;   // Early sums in two pieces (BOHIP_CHOL_EXEC_EARLY_SPLIT=0 in the measurement build: one piece, until round 6)
 static int g_chol_exec_nbu = 2;      // BOHIP_CHOL_EXEC_NBU: rows behind the solve followers whose row step (Solve, Late) sits in the urgent queue
 static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: where CUs hold two executor workgroups and the chain paces, 33 ... 48 row tiles: up to 112)
 static int g_chol_exec_bulk_edf = 0;   // BOHIP_CHOL_EXEC_BULK_EDF=1: bulk queue in earliest-deadline order from a host-side simulation (round-4 experiment: same total, see exec_task_list)
@@ -379,7 +380,7 @@ static void read_dev_knobs() {
         {"BOHIP_CHOL_EXEC_PATIENCE_US", &g_chol_exec_patience_us, 0, 1 << 30}, {"BOHIP_CHOL_EXEC_FILL_INV", &g_chol_exec_fill_inv, 0, 1},
         {"BOHIP_CHOL_EXEC_INV_PAIRS", &g_chol_exec_inv_pairs, 0, 1}, {"BOHIP_CHOL_EXEC_WGS", &g_chol_exec_wgs, 1, 1 << 20}, {"BOHIP_KS8", &g_ks8, 0, 1},
         {"BOHIP_CHOL_EXEC_BULK_EDF", &g_chol_exec_bulk_edf, 0, 1}, {"BOHIP_CHOL_EXEC_FAST", &g_chol_exec_fast, -1, 1 << 20},
-        {"BOHIP_CHOL_EXEC_SECOND", &g_chol_exec_second, 0, 1}, {"BOHIP_CHOL_EXEC_NBU", &g_chol_exec_nbu, 0, 16}, {"BOHIP_CHUNK_ROWS", &chunk_rows, 0, 1 << 30},
+        {"BOHIP_CHOL_EXEC_SECOND", &g_chol_exec_second, 0, 1}, {"BOHIP_CHOL_EXEC_EARLY_SPLIT", &g_chol_exec_early_split, 0, 1}, {"BOHIP_CHOL_EXEC_NBU", &g_chol_exec_nbu, 0, 16}, {"BOHIP_CHUNK_ROWS", &chunk_rows, 0, 1 << 30},
         {"BOHIP_TRIGEMM_HALVE_LO", &g_halve_lo, 0, 1 << 20}, {"BOHIP_TRIGEMM_HALVE_HI", &g_halve_hi, 0, 1 << 20}, {"BOHIP_FUSE_FINISH", &g_fuse_finish, 0, 1},
         {"BOHIP_APPEND_ALPHA_INC", &g_append_alpha_inc, 0, 1}, {"BOHIP_BULK_PIECES", &g_bulk_pieces, 0, 8}, {"BOHIP_SPLIT", &g_split, 0, 1},
         {"BOHIP_SMALL_R", &g_small_r, 0, SMALL_MAX}, {"BOHIP_SMALL_M", &g_small_m, 0, 1 << 20}, {"BOHIP_CHOL_DF_DUMP", &dump, 0, 1},
@@ -929,8 +930,22 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
         // Early(kp): P(i, c) = sum_{b = ks(c)}^{kp} S(i, b) S(c, b)'  for the tiles Late(kp + 2) finishes
         auto early = [&](int i, int c) {
             if (i >= T || c >= T || ks(c) > kp) return;
-            add(2, Sp(i, ks(c)), Sp(c, ks(c)), const_cast<double*>(Pp(i, c)), nullptr, (kp - ks(c) + 1) * CPB,
-                (kp - ks(c) + 1) * CPB, i == c, 0, {{sver(i, kp), 16u}, {sver(c, kp), 16u}}, pver(i, c), EX_NONE);
+            const int nbk = kp - ks(c) + 1;   // blocks in the sum: 1 ... 5, growing with c inside a group of four columns
+            if (g_chol_exec_early_split && inv_g == 0 && T <= 56 && nbk >= 2) {
+                // (round 6) TWO PIECES like Late: the blocks before kp need nothing of block kp, so the task starts a block earlier and waits for
+                // S(i, kp) / S(c, kp) inside, one K = 128 piece from its end.  In one piece it started only when the LAST block's rows were solved and
+                // then ran its whole window -- up to 50 us on the path S(i, kp) -> Early -> Late -> follower, growing over every group of four columns:
+                // the drift behind the owner's 30-50 us waits for crit[k-2] at every fourth block (profiles/r06_exec_trace_N3000.txt).
+                // The factorisation ALONE up to 56 row tiles: N=3000 1.14 -> 1.09-1.11 ms, N=3500 1.37 -> 1.31, N=6000 3.03 -> 2.90; N=8000 the same,
+                // N=10^4 9.0 -> 9.2 (a waiting task holds a workgroup the bulk work could use); with the inverse queues the same at N <= 3000 and
+                // worse beyond (N=4000 2.00 -> 2.05, N=10^4 13.65 -> 14.15): one piece there.
+                add(2, Sp(i, ks(c)), Sp(c, ks(c)), const_cast<double*>(Pp(i, c)), nullptr, nbk * CPB, nbk * CPB, i == c, 0,
+                    {{sver(i, kp - 1), 16u}, {sver(c, kp - 1), 16u}}, pver(i, c), EX_NONE, (nbk - 1) * CPB, Dep{sver(i, kp), 16u},
+                    c != i ? Dep{sver(c, kp), 16u} : Dep{EX_NONE, 0});
+                return;
+            }
+            add(2, Sp(i, ks(c)), Sp(c, ks(c)), const_cast<double*>(Pp(i, c)), nullptr, nbk * CPB,
+                nbk * CPB, i == c, 0, {{sver(i, kp), 16u}, {sver(c, kp), 16u}}, pver(i, c), EX_NONE);
         };
         early(kp + 6, kp + 4);   // the three tiles of row kp+6: blocks up to kp (e_of), then Late(kp+2) adds two, the chain the last
         early(kp + 6, kp + 5);

@@ -320,8 +320,14 @@ def test_executor_records_replay_with_the_inverse_in_group_form(T, inv_g, order)
     replay(T, order, inv_g=inv_g, groups=True)
 
 
-def test_executor_records_without_the_inverse_queue():
-    replay(9, "random", inv_g=0)
+@pytest.mark.parametrize("T,order", [(9, "random"), (14, "tasks_first"), (14, "low_priority_first"), (17, "chain_first"), (17, "random")])
+def test_executor_records_without_the_inverse_queue(T, order):
+    """inv_g = 0 (the factorisation alone): up to 56 row tiles the Early sums are TWO-piece tasks since round 6 (their last block is waited
+    for inside the task, exec_task_list) -- the replay checks that the first piece reads only final operands and that nothing dead-locks."""
+    recs, qbeg, lay = get_tasks(T, TILE * T + 16, 0)
+    early = [decode(r) for r in recs[qbeg[2]:qbeg[3]]]
+    assert any(t["kc_split"] > 0 for t in early) and any(t["kc_split"] == 0 for t in early)   # (one-block windows stay one piece)
+    replay(T, order, inv_g=0)
 
 
 def test_every_tile_gets_every_block_once():
