@@ -202,3 +202,22 @@ if ct[5920] > 0:
     print("solve follower 1, block 5, per panel (us since its first panel started): start | staged | +barrier | solved+barrier | updated")
     for p_ in range(8):
         print("  panel", p_, [round((ct[5920 + 5 * p_ + j] - ct[5920]) / 100.0, 2) for j in range(5)], "| inside the solve (wave 0): products done, stores issued", [round((ct[5960 + 3 * p_ + j] - ct[5920]) / 100.0, 2) for j in range(2)])
+# round 6: second-piece durations of the two-piece urgent tasks (stage-2 in -> loop done; K = 128: ~11 us on a quiet chip) -- which are slow, on which
+# workgroup, and how many bulk / wave tasks ran at that moment
+p2 = us(et[qb[0]:qb[1], 5]) - us(et[qb[0]:qb[1], 4])
+two = (et[qb[0]:qb[1], 4] != 0) & (p2 > 0) & (p2 < 200)
+st2 = us(et[qb[0]:qb[1], 4])
+wk = et[qb[0]:qb[1], 3].astype(np.int64)
+bs, be = us(et[qb[4]:qb[5], 1]), us(et[qb[4]:qb[5], 2])
+ws, we = (us(et[qb[5]:qb[6], 1]), us(et[qb[5]:qb[6], 2])) if qb[6] > qb[5] else (np.zeros(0), np.zeros(0))
+rs, re_ = us(et[qb[3]:qb[4], 1]), us(et[qb[3]:qb[4], 2])
+print("two-piece urgent tasks: second piece (us) | at (us) | workgroup | bulk / inverse-wave / inverse-row tasks running at its start")
+slow_w, fast_w = [], []
+for j in np.flatnonzero(two):
+    t_ = st2[j]
+    nb_, nw_, nr_ = int(((bs <= t_) & (be > t_)).sum()), int(((ws <= t_) & (we > t_)).sum()), int(((rs <= t_) & (re_ > t_)).sum())
+    (slow_w if p2[j] > 16 else fast_w).append((nb_, nw_, nr_))
+    if p2[j] > 16: print(f"   {p2[j]:6.1f} | {t_:7.0f} | wg {wk[j]:3d} | {nb_:3d} {nw_:3d} {nr_:3d}")
+for name, arr in (("slow (> 16 us)", slow_w), ("the others", fast_w)):
+    a = np.array(arr) if arr else np.zeros((0, 3))
+    print(f"{name}: {len(arr)} tasks; bulk / wave / row tasks running beside them, mean: " + (" ".join(f"{v:.1f}" for v in a.mean(0)) if len(arr) else "-"))
