@@ -345,6 +345,7 @@ static int g_chol_exec_urgent = -1; // executor workgroups that serve the urgent
 static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that holds a claimed task whose counters are not in takes bulk work meanwhile (1: Early sums only, 2: also row solves / updates).  Measured without effect on the total (N=10^4: 9.6-9.9 ms in every mode): more workgroups are busy, but the factorisation is paced by the per-block row steps, not by throughput -- so the default stays the simple rule
 static int g_chol_exec_second = 1;   // BOHIP_CHOL_EXEC_SECOND=0: every executor workgroup serves every queue (until round 4).  1: the workgroups beyond one per CU take
                                      // throughput work only (early sums, bulk, waves) and leave when it is exhausted: N = 6000 4.60 -> 4.38 ms, N = 5000 3.27 -> 3.18
+static int g_chol_exec_excl = 0;   // measurement build: more than half a CU's LDS per executor workgroup where the rule says one per CU (no effect measured: the dispatcher places them so already)
 static int g_chol_exec_early_split = 1;   // Early sums in two pieces (BOHIP_CHOL_EXEC_EARLY_SPLIT=0 in the measurement build: one piece, until round 6)
 static int g_chol_exec_nbu = 2;      // BOHIP_CHOL_EXEC_NBU: rows behind the solve followers whose row step (Solve, Late) sits in the urgent queue
 static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: where CUs hold two executor workgroups and the chain paces, 33 ... 48 row tiles: up to 112)
@@ -380,7 +381,7 @@ static void read_dev_knobs() {
         {"BOHIP_CHOL_EXEC_PATIENCE_US", &g_chol_exec_patience_us, 0, 1 << 30}, {"BOHIP_CHOL_EXEC_FILL_INV", &g_chol_exec_fill_inv, 0, 1},
         {"BOHIP_CHOL_EXEC_INV_PAIRS", &g_chol_exec_inv_pairs, 0, 1}, {"BOHIP_CHOL_EXEC_WGS", &g_chol_exec_wgs, 1, 1 << 20}, {"BOHIP_KS8", &g_ks8, 0, 1},
         {"BOHIP_CHOL_EXEC_BULK_EDF", &g_chol_exec_bulk_edf, 0, 1}, {"BOHIP_CHOL_EXEC_FAST", &g_chol_exec_fast, -1, 1 << 20},
-        {"BOHIP_CHOL_EXEC_SECOND", &g_chol_exec_second, 0, 1}, {"BOHIP_CHOL_EXEC_EARLY_SPLIT", &g_chol_exec_early_split, 0, 1}, {"BOHIP_CHOL_EXEC_NBU", &g_chol_exec_nbu, 0, 16}, {"BOHIP_CHUNK_ROWS", &chunk_rows, 0, 1 << 30},
+        {"BOHIP_CHOL_EXEC_SECOND", &g_chol_exec_second, 0, 1}, {"BOHIP_CHOL_EXEC_EARLY_SPLIT", &g_chol_exec_early_split, 0, 2}, {"BOHIP_CHOL_EXEC_EXCL", &g_chol_exec_excl, 0, 1}, {"BOHIP_CHOL_EXEC_NBU", &g_chol_exec_nbu, 0, 16}, {"BOHIP_CHUNK_ROWS", &chunk_rows, 0, 1 << 30},
         {"BOHIP_TRIGEMM_HALVE_LO", &g_halve_lo, 0, 1 << 20}, {"BOHIP_TRIGEMM_HALVE_HI", &g_halve_hi, 0, 1 << 20}, {"BOHIP_FUSE_FINISH", &g_fuse_finish, 0, 1},
         {"BOHIP_APPEND_ALPHA_INC", &g_append_alpha_inc, 0, 1}, {"BOHIP_BULK_PIECES", &g_bulk_pieces, 0, 8}, {"BOHIP_SPLIT", &g_split, 0, 1},
         {"BOHIP_SMALL_R", &g_small_r, 0, SMALL_MAX}, {"BOHIP_SMALL_M", &g_small_m, 0, 1 << 20}, {"BOHIP_CHOL_DF_DUMP", &dump, 0, 1},
@@ -408,7 +409,7 @@ static int one_time_kernel_setup() {
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_pair, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_hi, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
     HIPCHK(hipFuncSetAttribute((const void*)k_gemm_nt_quad, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
-    HIPCHK(hipFuncSetAttribute((const void*)k_chol_exec, hipFuncAttributeMaxDynamicSharedMemorySize, glds3_lds_bytes<4>()));
+    HIPCHK(hipFuncSetAttribute((const void*)k_chol_exec, hipFuncAttributeMaxDynamicSharedMemorySize, std::max<size_t>(glds3_lds_bytes<4>(), 84 * 1024)));
     HIPCHK(hipFuncSetAttribute((const void*)k_trimv_stream<TRIMV_D>, hipFuncAttributeMaxDynamicSharedMemorySize, trimv_lds_bytes(TRIMV_D)));
     // The library's switches (README "Environment"): the forms of the factorisation the tests select, the bound of its
     // waits, the ascent drivers, the small-batch pass.  Everything else that used to be read here is a constant now; the
@@ -931,14 +932,15 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
         auto early = [&](int i, int c) {
             if (i >= T || c >= T || ks(c) > kp) return;
             const int nbk = kp - ks(c) + 1;   // blocks in the sum: 1 ... 5, growing with c inside a group of four columns
-            if (g_chol_exec_early_split && inv_g == 0 && T <= 56 && nbk >= 2) {
+            if (((g_chol_exec_early_split == 1 && T <= (inv_g == 0 ? 56 : 23)) || g_chol_exec_early_split == 2) && nbk >= 2) {
                 // (round 6) TWO PIECES like Late: the blocks before kp need nothing of block kp, so the task starts a block earlier and waits for
                 // S(i, kp) / S(c, kp) inside, one K = 128 piece from its end.  In one piece it started only when the LAST block's rows were solved and
                 // then ran its whole window -- up to 50 us on the path S(i, kp) -> Early -> Late -> follower, growing over every group of four columns:
                 // the drift behind the owner's 30-50 us waits for crit[k-2] at every fourth block (profiles/r06_exec_trace_N3000.txt).
                 // The factorisation ALONE up to 56 row tiles: N=3000 1.14 -> 1.09-1.11 ms, N=3500 1.37 -> 1.31, N=6000 3.03 -> 2.90; N=8000 the same,
                 // N=10^4 9.0 -> 9.2 (a waiting task holds a workgroup the bulk work could use); with the inverse queues the same at N <= 3000 and
-                // worse beyond (N=4000 2.00 -> 2.05, N=10^4 13.65 -> 14.15): one piece there.
+                // worse beyond (N=4000 2.00 -> 2.05, N=10^4 13.65 -> 14.15): one piece there; up to 23 row tiles two pieces with them too
+                // (N=1600 0.64 -> 0.615 ms, N=2000 0.78 -> 0.76, N=2300 0.93 -> 0.90, N=2800 1.147 -> 1.114).
                 add(2, Sp(i, ks(c)), Sp(c, ks(c)), const_cast<double*>(Pp(i, c)), nullptr, nbk * CPB, nbk * CPB, i == c, 0,
                     {{sver(i, kp - 1), 16u}, {sver(c, kp - 1), 16u}}, pver(i, c), EX_NONE, (nbk - 1) * CPB, Dep{sver(i, kp), 16u},
                     c != i ? Dep{sver(c, kp), 16u} : Dep{EX_NONE, 0});
@@ -1416,7 +1418,8 @@ static int cholesky_exec(bohip_gp* g, int T) {
         // the kernel then starts ~10 us behind them -- was built against the time-outs of refits that share the device with other host
         // threads' work: it cost 0.1 ms at N = 10^4 and the time-outs stayed.  What causes those is streams of several handles sharing a
         // hardware queue, where a kernel waits for the END of the one before it; the per-device lock in refit_once removed most of them.)
-        hipLaunchKernelGGL(k_chol_exec, dim3(exec_wgs), dim3(GEMM_THREADS_8), glds3_lds_bytes<4>(), g->col_stream, q);
+        const size_t exec_lds = per_cu <= 1.0 && g_chol_exec_excl ? std::max<size_t>(glds3_lds_bytes<4>(), 84 * 1024) : glds3_lds_bytes<4>();
+        hipLaunchKernelGGL(k_chol_exec, dim3(exec_wgs), dim3(GEMM_THREADS_8), exec_lds, g->col_stream, q);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(g->ev_inv, g->col_stream));
         HIPCHK(hipStreamWaitEvent(g->stream, g->ev_inv, 0));
