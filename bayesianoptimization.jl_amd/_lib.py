@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("BOHIP_LIB") or os.path.join(_HERE, "csrc", "libbohip.
 
 OK, E_ARG, E_NOTPD, E_HIP, E_NODEVICE, E_STATE, E_UNSUPPORTED, E_COMM = 0, -1, -2, -3, -4, -5, -6, -7
 KERN = {"SEArd": 0, "SEIso": 1, "Mat52Ard": 2}
-ACQ = {"EI": 0, "PI": 1, "UCB": 2, "MI": 3, "MaxMean": 4}
+ACQ = {"EI": 0, "PI": 1, "UCB": 2, "MI": 3, "MaxMean": 4, "ThompsonDraw": 5}   # (5: bohip_gp_direct_max only)
 INFO_PIVOT, INFO_CAPACITY, INFO_REFITS, INFO_APPENDS = 0, 1, 2, 3
 INFO_CHOL_FORM, INFO_CHOL_FALLBACKS, INFO_CHOL_ABORT_TILES, INFO_JITTER_STEPS = 4, 5, 6, 7
 INFO_SCORE_LAUNCHES, INFO_SCORE_CHUNK, INFO_KERNEL_CLOCK_MHZ = 8, 9, 10
@@ -68,6 +68,13 @@ SIGNATURES = {
     "bohip_gp_score_grad": (C.c_int, [_gp, C.c_int, _dp, _dp, C.c_int64, _dp, _dp]),
     "bohip_gp_thompson": (C.c_int, [_gp, _dp, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, C.POINTER(Best)]),
     "bohip_thompson_normal": (C.c_double, [C.c_uint64, C.c_int64, C.c_int64]),
+    "bohip_direct_create": (C.c_int, [C.c_int64, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.POINTER(C.c_void_p)]),
+    "bohip_direct_destroy": (None, [C.c_void_p]),
+    "bohip_direct_ask": (C.c_int, [C.c_void_p, _dp, C.c_int64, _i64p]),
+    "bohip_direct_tell": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
+    "bohip_direct_best": (C.c_int, [C.c_void_p, _dp, _dp, _i64p, _i64p]),
+    "bohip_gp_direct_max": (C.c_int, [_gp, C.c_int, _dp, _dp, _dp, C.c_int64, C.c_double, C.c_double, C.c_uint64, _dp, _dp,
+                                     _i64p, _i64p]),
     "bohip_gp_score_dev": (C.c_int, [_gp, C.c_int, _dp, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "bohip_gp_predict_dev": (C.c_int, [_gp, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "bohip_gp_set_stream": (C.c_int, [_gp, C.c_void_p]),

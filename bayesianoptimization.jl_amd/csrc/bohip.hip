@@ -21,6 +21,7 @@
 #include "kernels_score.hip"
 #include "kernels_ascent.hip"
 #include "kernels_small.hip"   // (after the ascent: k_small_u's last workgroup runs its step, asc_step_one<true>)
+#include "direct_l.h"          // host bookkeeping of :GN_DIRECT_L (ask / tell)
 
 #include <algorithm>
 #include <atomic>
@@ -3130,6 +3131,82 @@ int bohip_gp_acquire_max(bohip_gp* g, int acq_id, const double* acq_params, cons
 }
 
 double bohip_thompson_normal(uint64_t seed, int64_t s, int64_t j) { return thompson_normal(seed, s, j); }
+
+// ---- :GN_DIRECT_L (reference src/acquisition.jl:7-9, :20-38): the dividing-rectangles search, bookkeeping in direct_l.h ----
+struct bohip_direct { DirectL s; };
+
+int bohip_direct_create(int64_t d, const double* lb, const double* ub, int64_t maxeval, double stopval, double maxtime,
+                        bohip_direct** out) {
+    if (d < 1 || !lb || !ub || !out) return fail(BOHIP_E_ARG, "bad arguments");
+    for (int64_t i = 0; i < d; ++i)
+        if (!(lb[i] <= ub[i])) return fail(BOHIP_E_ARG, "direct: lower bound above upper bound");
+    try {
+        *out = new bohip_direct{DirectL(d, lb, ub, maxeval, stopval, maxtime)};
+    } catch (const std::exception& e) { return fail(BOHIP_E_ARG, e.what()); }
+    return 0;
+}
+void bohip_direct_destroy(bohip_direct* s) { delete s; }
+int bohip_direct_ask(bohip_direct* s, double* X, int64_t cap, int64_t* n) {
+    if (!s || !n || cap < 0 || (cap > 0 && !X)) return fail(BOHIP_E_ARG, "bad arguments");
+    const int64_t m = s->s.ask(X, cap);
+    if (m < 0) return fail(BOHIP_E_ARG, "direct: the buffer is smaller than this iteration's batch (maxeval columns always suffice)");
+    *n = m;
+    return 0;
+}
+int bohip_direct_tell(bohip_direct* s, const double* f, int64_t n) {
+    if (!s || !f || n < 1) return fail(BOHIP_E_ARG, "bad arguments");
+    if (!s->s.tell(f, n)) return fail(BOHIP_E_STATE, "direct: tell without a matching ask");
+    return 0;
+}
+int bohip_direct_best(const bohip_direct* s, double* best_f, double* best_x, int64_t* evaluations, int64_t* iterations) {
+    if (!s) return fail(BOHIP_E_ARG, "bad arguments");
+    const double f = s->s.best(best_x);
+    if (best_f) *best_f = f;
+    if (evaluations) *evaluations = s->s.evals;
+    if (iterations) *iterations = s->s.iterations;
+    return 0;
+}
+
+// The whole search in one call: ask -> ONE scoring call of the iteration's points -> tell, until DIRECT-L stops.
+// acq_id = BOHIP_ACQ_THOMPSON_DRAW: the objective is x -> myrand(model, x) (src/acquisitionfunctions.jl:107-108), one posterior draw
+// per evaluated point, mu + sigma z with z = bohip_thompson_normal(seed, 0, e) for the e-th evaluation of the search.
+int bohip_gp_direct_max(bohip_gp* g, int acq_id, const double* acq_params, const double* lb, const double* ub, int64_t maxeval,
+                        double stopval, double maxtime, uint64_t seed, double* best_f, double* best_x, int64_t* evaluations,
+                        int64_t* device_calls) {
+#pragma clang fp contract(off)
+    if (!g || !lb || !ub) return fail(BOHIP_E_ARG, "bad arguments");
+    if (acq_id < 0 || acq_id > BOHIP_ACQ_THOMPSON_DRAW) return fail(BOHIP_E_ARG, "unknown acq_id");
+    if (g->n == 0) return fail(BOHIP_E_STATE, "model has no observations");
+    const int64_t d = g->d;
+    for (int64_t i = 0; i < d; ++i)
+        if (!(lb[i] <= ub[i])) return fail(BOHIP_E_ARG, "direct: lower bound above upper bound");
+    DirectL s(d, lb, ub, maxeval, stopval, maxtime);
+    const int64_t cap = std::max<int64_t>(1, std::max<int64_t>(maxeval, 2 * d));
+    std::vector<double> X((size_t)cap * d), f(cap), var(acq_id == BOHIP_ACQ_THOMPSON_DRAW ? cap : 0);
+    int64_t calls = 0, e = 0;
+    for (;;) {
+        const int64_t m = s.ask(X.data(), cap);
+        if (m < 0) return fail(BOHIP_E_ARG, "direct: batch larger than maxeval");
+        if (m == 0) break;
+        if (acq_id == BOHIP_ACQ_THOMPSON_DRAW) {
+            CHK(bohip_gp_predict(g, X.data(), m, f.data(), var.data()));
+            for (int64_t c = 0; c < m; ++c, ++e) {
+                const double sd = std::sqrt(std::max(var[c], 0.0));
+                const double t = sd * thompson_normal(seed, 0, e);
+                f[c] = f[c] + t;
+            }
+        } else {
+            CHK(bohip_gp_score(g, acq_id, acq_params, X.data(), m, f.data(), nullptr));
+        }
+        ++calls;
+        s.tell(f.data(), m);
+    }
+    const double bf = s.best(best_x);
+    if (best_f) *best_f = bf;
+    if (evaluations) *evaluations = s.evals;
+    if (device_calls) *device_calls = calls;
+    return 0;
+}
 
 int bohip_gp_thompson(bohip_gp* g, const double* Xs, int64_t R, int64_t S, uint64_t seed, int64_t j0, bohip_best* best) {
     if (!g || R <= 0 || S <= 0 || !Xs || !best) return fail(BOHIP_E_ARG, "bad arguments");

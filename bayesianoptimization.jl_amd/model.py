@@ -279,6 +279,24 @@ class ElasticGPE:
     def synchronize(self):
         check(self._lib.bohip_gp_synchronize(self._h))
 
+    def direct_max(self, acq, params, lowerbounds, upperbounds, maxeval=2000, stopval=float("inf"), maxtime=0.0, seed=0):
+        """:GN_DIRECT_L on the device model in one call (bohip_gp_direct_max; reference src/acquisition.jl:7-9, :20-38): the
+        dividing-rectangles bookkeeping runs in the library, every iteration's points are one scoring call.  acq = "ThompsonDraw":
+        x -> myrand(model, x), one posterior draw per point from the library's counter-based generator keyed by `seed`.
+        Returns (best value, best point, evaluations, device calls)."""
+        lb = np.ascontiguousarray(lowerbounds, dtype=np.float64)
+        ub = np.ascontiguousarray(upperbounds, dtype=np.float64)
+        if lb.size != self.dim or ub.size != self.dim:
+            raise ValueError("bounds must have one entry per input dimension")
+        p = np.zeros(2)
+        if params is not None:
+            q = np.atleast_1d(np.asarray(params, dtype=np.float64))
+            p[:q.size] = q[:2]
+        bf = C.c_double(); bx = np.empty(self.dim); ev = C.c_int64(); dc = C.c_int64()
+        check(self._lib.bohip_gp_direct_max(self._h, _lib.ACQ[acq], _ptr(p), _ptr(lb), _ptr(ub), int(maxeval), float(stopval),
+                                            float(maxtime or 0.0), int(seed), C.byref(bf), _ptr(bx), C.byref(ev), C.byref(dc)))
+        return float(bf.value), bx, int(ev.value), int(dc.value)
+
     def thompson(self, xs, S, seed=0, j0=0):
         xs = _cols(xs, self.dim)
         out = (Best * S)()

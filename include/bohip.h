@@ -152,6 +152,33 @@ int bohip_gp_thompson(bohip_gp *gp, const double *Xs, int64_t R, int64_t S, uint
 /* the generator itself, exposed so tests and other shards can reproduce z (host side) */
 double bohip_thompson_normal(uint64_t seed, int64_t s, int64_t j);
 
+/* ---- :GN_DIRECT_L, the reference's default search for ThompsonSamplingSimple (reference src/acquisition.jl:7-9: restarts 1,
+ * maxeval 2000; nlopt_setup :20-38 hands the acquisition to NLopt) and for any acquisition the caller selects it for.
+ * NLopt is not vendored in the reference; csrc/direct_l.h restates DIRECT-L with the rules of NLopt's cdirect.c for this variant
+ * (MAXIMISATION; a rectangle's size = its longest side, one potentially optimal rectangle per size class, cubes trisected along
+ * every side best value first, other rectangles along their first longest side).  Batched: every iteration's new centres are ONE
+ * scoring call.
+ *   bohip_direct_*  the host bookkeeping as an ask / tell object, for objectives evaluated by the caller (works without a device):
+ *     ask   X = d x cap column-major; *n = points of this iteration (0: the search is over; cap = maxeval always suffices)
+ *     tell  their values in ask's order (NaN counts as -Inf)
+ *     best  first maximum so far, its point, evaluations, iterations
+ *   bohip_gp_direct_max  the whole search against a resident model in one call: acq_id = BOHIP_ACQ_* scores through bohip_gp_score;
+ *     BOHIP_ACQ_THOMPSON_DRAW evaluates x -> myrand(model, x) (src/acquisitionfunctions.jl:107-108, src/models/gp.jl:6-7): one
+ *     posterior draw per evaluated point, mu + sigma z, z = bohip_thompson_normal(seed, 0, e) for the e-th evaluation.
+ *     maxtime: NLopt's wall-clock budget in seconds (0 = none), checked once per iteration; stopval: +Inf = off.
+ *     best_x = the box centre's image when nothing was finite. */
+typedef struct bohip_direct bohip_direct;
+int bohip_direct_create(int64_t d, const double *lb, const double *ub, int64_t maxeval, double stopval, double maxtime,
+                        bohip_direct **out);
+void bohip_direct_destroy(bohip_direct *s);
+int bohip_direct_ask(bohip_direct *s, double *X, int64_t cap, int64_t *n);
+int bohip_direct_tell(bohip_direct *s, const double *f, int64_t n);
+int bohip_direct_best(const bohip_direct *s, double *best_f, double *best_x, int64_t *evaluations, int64_t *iterations);
+#define BOHIP_ACQ_THOMPSON_DRAW 5
+int bohip_gp_direct_max(bohip_gp *gp, int acq_id, const double *acq_params, const double *lb, const double *ub, int64_t maxeval,
+                        double stopval, double maxtime, uint64_t seed, double *best_f, double *best_x, int64_t *evaluations,
+                        int64_t *device_calls);
+
 /* ---- device-resident variants (inputs already in HBM; results stay in HBM) ----------------
  * dXs: device pointer, d x R column-major.  d_score (nullable), d_best: device pointers.
  * Enqueued on the handle's stream; no host synchronisation.                                */

@@ -69,6 +69,22 @@ c_gp_predict_cov(h, Xs, R, mu, cov) = ccall((:bohip_gp_predict_cov, libbohip), C
 c_gp_score(h, acq, p, Xs, R, sc, best) = ccall((:bohip_gp_score, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Best}), h, acq, p, Xs, R, sc, best)
 c_gp_score_grad(h, acq, p, Xs, R, sc, g) = ccall((:bohip_gp_score_grad, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}), h, acq, p, Xs, R, sc, g)
 c_gp_acquire_max(h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev) = ccall((:bohip_gp_acquire_max, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Best}, Ptr{Float64}, Ptr{Int64}), h, acq, p, lb, ub, st, R, maxeval, ftol, xtol, xo, fo, best, bx, ev)
+c_direct_create(d, lb, ub, maxeval, stopval, maxtime, out) = ccall((:bohip_direct_create, libbohip), Cint, (Int64, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Float64, Ptr{Ptr{Cvoid}}), d, lb, ub, maxeval, stopval, maxtime, out)
+c_direct_destroy(s) = ccall((:bohip_direct_destroy, libbohip), Cvoid, (Ptr{Cvoid},), s)
+c_direct_ask(s, X, cap, n) = ccall((:bohip_direct_ask, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Int64}), s, X, cap, n)
+c_direct_tell(s, f, n) = ccall((:bohip_direct_tell, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), s, f, n)
+c_direct_best(s, bf, bx, ev, it) = ccall((:bohip_direct_best, libbohip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}), s, bf, bx, ev, it)
+c_gp_direct_max(h, acq, p, lb, ub, maxeval, stopval, maxtime, seed, bf, bx, ev, calls) = ccall((:bohip_gp_direct_max, libbohip), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Float64, Float64, UInt64, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}), h, acq, p, lb, ub, maxeval, stopval, maxtime, seed, bf, bx, ev, calls)
+const ACQ_THOMPSON_DRAW = Cint(5)   # BOHIP_ACQ_THOMPSON_DRAW: x -> myrand(model, x), bohip_gp_direct_max only
+
+# :GN_DIRECT_L against ONE device handle in one library call (csrc/direct_l.h does the dividing-rectangles bookkeeping, every
+# iteration's points are one scoring call); the multi-device model keeps the Julia loop below.
+function _direct_max_device(m, acq::Cint, p::Vector{Float64}, lb::Vector{Float64}, ub::Vector{Float64}, options; seed::UInt64 = UInt64(0))
+    bf = Ref(-Inf); bx = similar(lb); ev = Ref(Int64(0)); calls = Ref(Int64(0))
+    check(c_gp_direct_max(m.handle, acq, p, lb, ub, max(1, options.maxeval), Float64(get(options, :stopval, Inf)),
+                          Float64(get(options, :maxtime, 0.0)), seed, bf, bx, ev, calls))
+    bf[], bx, ev[]
+end
 c_gp_set_maxtime(h, s) = ccall((:bohip_gp_set_maxtime, libbohip), Cint, (Ptr{Cvoid}, Float64), h, s)
 c_gp_set_ascent_stop(h, fa, xr, sv) = ccall((:bohip_gp_set_ascent_stop, libbohip), Cint, (Ptr{Cvoid}, Float64, Float64, Float64), h, fa, xr, sv)
 c_debug_set_chol_inv_g(blocks) = ccall((:bohip_debug_set_chol_inv_g, libbohip), Cint, (Cint,), blocks)
@@ -334,6 +350,10 @@ function acquire_max_device(a::AbstractAcquisition, m::AbstractBOHipModel, lower
         # :GN_DIRECT* -- dividing rectangles, every iteration's new points in ONE device call (same search as the Python mirror's
         # acquisition._batched_direct_l; tests/test_julia_binding.py keeps the two from drifting).  DIRECT ignores the start point and the
         # acquisition is deterministic: every restart would be the same run, so one run.
+        if !(m isa BOHipMultiGPE)
+            f, x, _ = _direct_max_device(m, Cint(acqid(a)), Float64.(acqparams(a)), lb, ub, options)
+            return isfinite(f) ? (f, x) : (maxf, maxx)
+        end
         f_batch = X -> score(m, a, X)[1]
         f, x, _ = _batched_direct_l(f_batch, lb, ub, max(1, options.maxeval); stopval = Float64(get(options, :stopval, Inf)),
                                     maxtime = Float64(get(options, :maxtime, 0.0)))
@@ -440,6 +460,34 @@ function _batched_direct_l(f_batch, lb::Vector{Float64}, ub::Vector{Float64}, ma
     F[jb], to_x(C[:, jb:jb])[:, 1], evals
 end
 
+"""
+    direct_l_search(f_batch, lb, ub, maxeval; stopval = Inf, maxtime = 0.0)
+
+The same search as `_batched_direct_l` with the bookkeeping in libbohip (`bohip_direct_ask` / `_tell`, csrc/direct_l.h): `f_batch(X)`
+scores the columns of X, one call per DIRECT iteration.  Returns (best value, best point, evaluations).
+"""
+function direct_l_search(f_batch, lb::Vector{Float64}, ub::Vector{Float64}, maxeval::Integer; stopval = Inf, maxtime = 0.0)
+    d = length(lb)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(c_direct_create(d, lb, ub, max(1, maxeval), Float64(stopval), Float64(maxtime), h))
+    cap = max(maxeval, 2d, 1)
+    X = Matrix{Float64}(undef, d, cap)
+    n = Ref(Int64(0))
+    try
+        while true
+            check(c_direct_ask(h[], X, cap, n))
+            n[] == 0 && break
+            F = Float64.(vec(f_batch(X[:, 1:n[]])))
+            check(c_direct_tell(h[], F, n[]))
+        end
+        bf = Ref(-Inf); bx = Vector{Float64}(undef, d); ev = Ref(Int64(0)); it = Ref(Int64(0))
+        check(c_direct_best(h[], bf, bx, ev, it))
+        return bf[], bx, Int(ev[])
+    finally
+        c_direct_destroy(h[])
+    end
+end
+
 function acquire_max_device(::ThompsonSamplingSimple, m::AbstractBOHipModel, lowerbounds, upperbounds, options)
     # acquisitionfunction(::ThompsonSamplingSimple, model) = x -> myrand(model, x) under a global derivative-free search
     # (src/acquisitionfunctions.jl:107-108, defaults :GN_DIRECT_L)
@@ -455,8 +503,10 @@ function acquire_max_device(::ThompsonSamplingSimple, m::AbstractBOHipModel, low
             mu .+ sqrt.(max.(var, 0.0)) .* randn(length(mu))
         end
         for _ in 1:options.restarts
-            f, x, _ = _batched_direct_l(f_batch, lb, ub, max(1, options.maxeval); stopval = Float64(get(options, :stopval, Inf)),
-                                        maxtime = Float64(get(options, :maxtime, 0.0)))
+            f, x, _ = m isa BOHipMultiGPE ?
+                _batched_direct_l(f_batch, lb, ub, max(1, options.maxeval); stopval = Float64(get(options, :stopval, Inf)),
+                                  maxtime = Float64(get(options, :maxtime, 0.0))) :
+                _direct_max_device(m, ACQ_THOMPSON_DRAW, [0.0, 0.0], lb, ub, options; seed = rand(UInt64))   # draws: the library's counter-based generator
             if f > maxf                                          # src/acquisition.jl:62 strict '>'
                 maxf = f; maxx = x
             end

@@ -45,6 +45,7 @@ def canon_c(t):
     table = {"int": "int", "int64_t": "int64", "uint64_t": "uint64", "double": "double", "void": "void",
              "double*": "ptr(double)", "int64_t*": "ptr(int64)", "int*": "ptr(int)", "void*": "ptr(void)",
              "bohip_gp*": "ptr(void)", "bohip_mgp*": "ptr(void)", "bohip_gp**": "ptr(ptr)", "bohip_mgp**": "ptr(ptr)",
+             "bohip_direct*": "ptr(void)", "bohip_direct**": "ptr(ptr)",
              "bohip_best*": "ptr(best)", "char*": "cstr", "char**": "ptr(cstr)"}
     assert t in table, f"unmapped C type {t!r}"
     return table[t]
@@ -157,7 +158,11 @@ def test_both_hosts_take_the_same_route_for_direct_methods():
         assert b in jfun, ("julia", b)
     assert jl.count('occursin("DIRECT", uppercase(string(options.method)))') == 2           # generic + ThompsonSamplingSimple
     assert jl.count("_batched_direct_l(f_batch, lb, ub, max(1, options.maxeval)") == 2
-    assert py.count("_batched_direct_l(f_batch, lb, ub, max(1, maxeval), sval, maxtime)") == 1 and '"DIRECT" in method.upper()' in py
+    assert py.count("direct_l_search(f_batch, lb, ub, max(1, maxeval), sval, maxtime)") == 1 and '"DIRECT" in method.upper()' in py
+    # a single-device model takes the search as ONE library call on both hosts (bohip_gp_direct_max; csrc/direct_l.h is the same
+    # bookkeeping, tests/test_direct_l.py holds it to the NumPy twin bit for bit); acq 5 = one posterior draw per point
+    assert "model.direct_max(" in py and ":bohip_gp_direct_max" in jl and jl.count("_direct_max_device(m, ") == 3   # the definition + two call sites
+    assert "const ACQ_THOMPSON_DRAW = Cint(5)" in jl and "#define BOHIP_ACQ_THOMPSON_DRAW 5" in open(os.path.join(ROOT, "include", "bohip.h")).read()
     # one posterior draw per new point in both (mu + sigma z, src/models/gp.jl:6)
     assert "mu .+ sqrt.(max.(var, 0.0)) .* randn(length(mu))" in jl
     assert "np.sqrt(np.maximum(np.asarray(var), 0.0)) * gen.standard_normal(np.size(mu))" in py

@@ -452,6 +452,57 @@ def test_thompson_draws_match_oracle(bohip, orc):
     np.testing.assert_array_equal(glob, bi)
 
 
+@pytest.mark.parametrize("N,d,maxeval", [(200, 4, 600), (1000, 8, 2000), (60, 1, 90)])
+def test_direct_l_in_one_library_call(bohip, orc, N, d, maxeval):
+    """:GN_DIRECT_L as ONE library call (bohip_gp_direct_max; reference src/acquisition.jl:7-9, :20-38): the search must evaluate exactly
+    the points its NumPy twin asks for when the twin scores through the same device entry points -- same best value, point and
+    evaluation count, for a deterministic acquisition and for x -> myrand(model, x) with the library's generator -- and the value it
+    reports is the ORACLE's score at the point it reports."""
+    from bohip import _lib
+    from bohip.acquisition import _batched_direct_l
+
+    lib = _lib.load()
+    X, y, _ = synth(N, d, 4, seed=3 * N + d)
+    ll = np.linspace(-0.9, -0.3, d)
+    m = make_model(bohip, X, y, ll, 0.0, -2.0, 0.1)
+    lb, ub = np.full(d, -0.2), np.full(d, 1.1)
+    L, alpha = orc.fit(X, y, ll, 0.0, -2.0, 0.1)
+    for acq, p in [("UCB", [2.0]), ("EI", [float(np.median(y))])]:
+        calls = []
+        f1, x1, e1 = _batched_direct_l(lambda Z: (calls.append(Z.shape[1]), m.score(acq, p, Z)[0])[1], lb, ub, maxeval)
+        f2, x2, e2, dc = m.direct_max(acq, p, lb, ub, maxeval)
+        assert (f1, e1, len(calls)) == (f2, e2, dc) and np.array_equal(x1, x2) and e2 <= maxeval
+        sc_o, _, _ = orc.score(X, ll, 0.0, 0.1, L, alpha, acq, p, x2[None, :])
+        assert abs(f2 - sc_o[0]) <= 1e-6 * abs(sc_o[0]) + 1e-9
+        assert np.all(x2 >= lb) and np.all(x2 <= ub)
+    # one posterior draw per evaluated point, z = bohip_thompson_normal(seed, 0, e) for the e-th evaluation
+    seed = 77
+    cnt = [0]
+
+    def f_draw(Z):
+        mu, var = m.predict_f(Z)
+        z = np.array([lib.bohip_thompson_normal(seed, 0, cnt[0] + j) for j in range(Z.shape[1])])
+        cnt[0] += Z.shape[1]
+        return mu + np.sqrt(np.maximum(var, 0.0)) * z
+    f1, x1, e1 = _batched_direct_l(f_draw, lb, ub, maxeval)
+    f2, x2, e2, dc = m.direct_max("ThompsonDraw", None, lb, ub, maxeval, seed=seed)
+    assert (f1, e1) == (f2, e2) and np.array_equal(x1, x2) and cnt[0] == e2
+    f3, x3, _, _ = m.direct_max("ThompsonDraw", None, lb, ub, maxeval, seed=seed + 1)
+    assert f3 != f2                                                     # another seed, another draw
+    # stopval / maxtime / error paths
+    f4, _, e4, _ = m.direct_max("UCB", [2.0], lb, ub, maxeval, stopval=-1e300)
+    assert e4 == 1
+    with pytest.raises(bohip.BohipError):
+        m.direct_max("UCB", [2.0], ub, lb, maxeval)                     # lower bound above upper bound
+    # acquire_max takes this route for a device model
+    from bohip.acquisition import acquire_max, ThompsonSamplingSimple, defaultoptions
+    f5, x5 = acquire_max(ThompsonSamplingSimple(), m, lb, ub, defaultoptions(type(m), ThompsonSamplingSimple), rng=np.random.default_rng(1),
+                         setparams=False)
+    assert np.isfinite(f5) and np.all(x5 >= lb) and np.all(x5 <= ub)
+    mu5, _ = m.predict_f(x5[:, None])
+    assert mu5[0] > np.quantile(y, 0.5)
+
+
 # ---- BASELINE.json full sizes: size-independent properties + a bounded oracle sample ------------------
 def test_full_size_c2_properties(bohip, orc):
     N, d, R = 3000, 8, 4096
