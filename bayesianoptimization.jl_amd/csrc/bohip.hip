@@ -347,6 +347,7 @@ static int g_chol_exec_fill = 0;   // BOHIP_CHOL_EXEC_FILL=1/2: a workgroup that
 static int g_chol_exec_second = 1;   // BOHIP_CHOL_EXEC_SECOND=0: every executor workgroup serves every queue (until round 4).  1: the workgroups beyond one per CU take
                                      // throughput work only (early sums, bulk, waves) and leave when it is exhausted: N = 6000 4.60 -> 4.38 ms, N = 5000 3.27 -> 3.18
 static int g_chol_exec_excl = 0;   // measurement build: more than half a CU's LDS per executor workgroup where the rule says one per CU (no effect measured: the dispatcher places them so already)
+static int g_chol_exec_early_tail = 0;    // the factorisation ALONE beyond 56 row tiles: two-piece Early sums for the last this-many blocks (the chain-bound tail)
 static int g_chol_exec_early_split = 1;   // Early sums in two pieces (BOHIP_CHOL_EXEC_EARLY_SPLIT=0 in the measurement build: one piece, until round 6)
 static int g_chol_exec_nbu = 2;      // BOHIP_CHOL_EXEC_NBU: rows behind the solve followers whose row step (Solve, Late) sits in the urgent queue
 static int g_chol_exec_fast = -1;    // BOHIP_CHOL_EXEC_FAST: executor workgroups that never take bulk / wave tasks (-1: where CUs hold two executor workgroups and the chain paces, 33 ... 48 row tiles: up to 112)
@@ -382,7 +383,7 @@ static void read_dev_knobs() {
         {"BOHIP_CHOL_EXEC_PATIENCE_US", &g_chol_exec_patience_us, 0, 1 << 30}, {"BOHIP_CHOL_EXEC_FILL_INV", &g_chol_exec_fill_inv, 0, 1},
         {"BOHIP_CHOL_EXEC_INV_PAIRS", &g_chol_exec_inv_pairs, 0, 1}, {"BOHIP_CHOL_EXEC_WGS", &g_chol_exec_wgs, 1, 1 << 20}, {"BOHIP_KS8", &g_ks8, 0, 1},
         {"BOHIP_CHOL_EXEC_BULK_EDF", &g_chol_exec_bulk_edf, 0, 1}, {"BOHIP_CHOL_EXEC_FAST", &g_chol_exec_fast, -1, 1 << 20},
-        {"BOHIP_CHOL_EXEC_SECOND", &g_chol_exec_second, 0, 1}, {"BOHIP_CHOL_EXEC_EARLY_SPLIT", &g_chol_exec_early_split, 0, 2}, {"BOHIP_CHOL_EXEC_EXCL", &g_chol_exec_excl, 0, 1}, {"BOHIP_CHOL_EXEC_NBU", &g_chol_exec_nbu, 0, 16}, {"BOHIP_CHUNK_ROWS", &chunk_rows, 0, 1 << 30},
+        {"BOHIP_CHOL_EXEC_SECOND", &g_chol_exec_second, 0, 1}, {"BOHIP_CHOL_EXEC_EARLY_SPLIT", &g_chol_exec_early_split, 0, 2}, {"BOHIP_CHOL_EXEC_EARLY_TAIL", &g_chol_exec_early_tail, 0, 1 << 20}, {"BOHIP_CHOL_EXEC_EXCL", &g_chol_exec_excl, 0, 1}, {"BOHIP_CHOL_EXEC_NBU", &g_chol_exec_nbu, 0, 16}, {"BOHIP_CHUNK_ROWS", &chunk_rows, 0, 1 << 30},
         {"BOHIP_TRIGEMM_HALVE_LO", &g_halve_lo, 0, 1 << 20}, {"BOHIP_TRIGEMM_HALVE_HI", &g_halve_hi, 0, 1 << 20}, {"BOHIP_FUSE_FINISH", &g_fuse_finish, 0, 1},
         {"BOHIP_APPEND_ALPHA_INC", &g_append_alpha_inc, 0, 1}, {"BOHIP_BULK_PIECES", &g_bulk_pieces, 0, 8}, {"BOHIP_SPLIT", &g_split, 0, 1},
         {"BOHIP_SMALL_R", &g_small_r, 0, SMALL_MAX}, {"BOHIP_SMALL_M", &g_small_m, 0, 1 << 20}, {"BOHIP_CHOL_DF_DUMP", &dump, 0, 1},
@@ -933,7 +934,8 @@ static void exec_task_list(double* dL, double* dS, double* dW, double* dWT, unsi
         auto early = [&](int i, int c) {
             if (i >= T || c >= T || ks(c) > kp) return;
             const int nbk = kp - ks(c) + 1;   // blocks in the sum: 1 ... 5, growing with c inside a group of four columns
-            if (((g_chol_exec_early_split == 1 && T <= (inv_g == 0 ? 56 : 23)) || g_chol_exec_early_split == 2) && nbk >= 2) {
+            if (((g_chol_exec_early_split == 1 && (T <= (inv_g == 0 ? 56 : 23) || (inv_g == 0 && T - kp <= g_chol_exec_early_tail))) ||
+                 g_chol_exec_early_split == 2) && nbk >= 2) {
                 // (round 6) TWO PIECES like Late: the blocks before kp need nothing of block kp, so the task starts a block earlier and waits for
                 // S(i, kp) / S(c, kp) inside, one K = 128 piece from its end.  In one piece it started only when the LAST block's rows were solved and
                 // then ran its whole window -- up to 50 us on the path S(i, kp) -> Early -> Late -> follower, growing over every group of four columns:
