@@ -75,6 +75,53 @@ def test_stopval_nan_and_ties():
         assert (r1[0] == r2[0] or (math.isnan(r1[0]) and math.isnan(r2[0]))) and np.array_equal(r1[1], r2[1]) and r1[2] == r2[2]
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_against_the_twin(seed):
+    """Random dimensions, boxes, budgets and objectives built to tie (values rounded to a coarse grid), to be NaN or +-Inf in places and
+    to be very flat or very peaked: the library and the twin must agree on every point of every iteration."""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.integers(1, 7))
+    lb = rng.normal(size=d) * 3
+    ub = lb + rng.uniform(0.1, 5.0, size=d)
+    maxeval = int(rng.integers(1, 900))
+    c = lb + rng.uniform(0, 1, size=d) * (ub - lb)
+    kind = seed % 4
+
+    def f(X):
+        r2 = (((X - c[:, None]) / (ub - lb)[:, None]) ** 2).sum(0)
+        if kind == 0:
+            v = np.round(np.exp(-3 * r2), 2)                     # plateaus: ties everywhere
+        elif kind == 1:
+            v = -r2 * 1e-12                                       # nearly flat
+        elif kind == 2:
+            v = np.exp(-400 * r2) + 0.1 * np.sin(40 * X[0])      # a needle
+        else:
+            v = np.cos(7 * X.sum(0))
+            v[np.sin(13 * X[0]) > 0.8] = np.nan
+            v[np.sin(11 * X[-1]) < -0.9] = -np.inf
+        return v
+    stop = math.inf
+    if seed % 3 == 0 and kind != 3:                               # a stopval most searches reach before their budget ends
+        sample = f(lb[:, None] + rng.uniform(size=(d, 200)) * (ub - lb)[:, None])
+        stop = float(np.quantile(sample, 0.99))
+    g1, log1 = recorded(f)
+    g2, log2 = recorded(f)
+    with np.errstate(invalid="ignore"):
+        r1 = _batched_direct_l(g1, lb, ub, maxeval, stopval=stop)
+        r2 = direct_l_search(g2, lb, ub, maxeval, stopval=stop)
+    assert len(log1) == len(log2)
+    for A, B in zip(log1, log2):
+        assert np.array_equal(A, B)
+    assert r1[2] == r2[2] <= maxeval and np.array_equal(r1[1], r2[1]) and (r1[0] == r2[0])
+
+
+def test_maxtime_stops_the_search():
+    import time
+    t0 = time.monotonic()
+    f, x, ev = direct_l_search(lambda X: (time.sleep(0.01), -np.sum(X ** 2, axis=0))[1], [-1.0, -1.0], [1.0, 1.0], 10 ** 6, maxtime=0.15)
+    assert 0.1 < time.monotonic() - t0 < 2.0 and 1 < ev < 10 ** 5 and f > -0.1
+
+
 def test_direct_invariants_and_convergence():
     """What DIRECT itself promises: no point is sampled twice, every centre is interior, and the search closes in on Branin's maximum (the reference's own acceptance function, test/BayesianOptimization.jl)."""
     g, log = recorded(branin)
