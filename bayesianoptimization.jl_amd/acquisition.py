@@ -337,13 +337,15 @@ def direct_l_search(f_batch, lb, ub, maxeval, stopval=math.inf, maxtime=0.0):
     _lib.check(lib.bohip_direct_create(d, lb.ctypes.data_as(dp), ub.ctypes.data_as(dp), int(max(1, maxeval)), float(stopval),
                                        float(maxtime or 0.0), C.byref(h)))
     try:
-        cap = max(int(maxeval), 2 * d, 1)
-        X = np.empty((cap, d))                                    # rows = points (d x cap column-major for the library)
+        X = np.empty((max(2 * d, 64), d))                         # rows = points (d x cap column-major for the library)
         n = C.c_int64()
         while True:
-            _lib.check(lib.bohip_direct_ask(h, X.ctypes.data_as(dp), cap, C.byref(n)))
+            _lib.check(lib.bohip_direct_ask(h, None, 0, C.byref(n)))         # size of this iteration's batch
             if n.value == 0:
                 break
+            if n.value > X.shape[0]:
+                X = np.empty((2 * n.value, d))
+            _lib.check(lib.bohip_direct_ask(h, X.ctypes.data_as(dp), X.shape[0], C.byref(n)))
             F = np.ascontiguousarray(np.asarray(f_batch(X[:n.value].T), dtype=np.float64).reshape(-1))
             _lib.check(lib.bohip_direct_tell(h, F.ctypes.data_as(dp), n.value))
         bf = C.c_double(); bx = np.empty(d); ev = C.c_int64(); it = C.c_int64()

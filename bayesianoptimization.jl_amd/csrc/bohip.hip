@@ -3165,6 +3165,10 @@ int bohip_direct_create(int64_t d, const double* lb, const double* ub, int64_t m
 void bohip_direct_destroy(bohip_direct* s) { delete s; }
 int bohip_direct_ask(bohip_direct* s, double* X, int64_t cap, int64_t* n) {
     if (!s || !n || cap < 0 || (cap > 0 && !X)) return fail(BOHIP_E_ARG, "bad arguments");
+    if (cap == 0) {   // size query: plans the iteration, hands out nothing yet
+        *n = s->s.plan_next();
+        return 0;
+    }
     const int64_t m = s->s.ask(X, cap);
     if (m < 0) return fail(BOHIP_E_ARG, "direct: the buffer is smaller than this iteration's batch (maxeval columns always suffice)");
     *n = m;
@@ -3198,13 +3202,13 @@ int bohip_gp_direct_max(bohip_gp* g, int acq_id, const double* acq_params, const
     for (int64_t i = 0; i < d; ++i)
         if (!(lb[i] <= ub[i])) return fail(BOHIP_E_ARG, "direct: lower bound above upper bound");
     DirectL s(d, lb, ub, maxeval, stopval, maxtime);
-    const int64_t cap = std::max<int64_t>(1, std::max<int64_t>(maxeval, 2 * d));
-    std::vector<double> X((size_t)cap * d), f(cap), var(acq_id == BOHIP_ACQ_THOMPSON_DRAW ? cap : 0);
+    std::vector<double> X, f, var;
     int64_t calls = 0, e = 0;
     for (;;) {
-        const int64_t m = s.ask(X.data(), cap);
-        if (m < 0) return fail(BOHIP_E_ARG, "direct: batch larger than maxeval");
+        const int64_t m = s.plan_next();       // (an iteration's batch is at most 2 d points per potentially optimal rectangle)
         if (m == 0) break;
+        if ((int64_t)f.size() < m) { X.resize((size_t)m * d); f.resize(m); var.resize(m); }
+        s.ask(X.data(), m);
         if (acq_id == BOHIP_ACQ_THOMPSON_DRAW) {
             CHK(bohip_gp_predict(g, X.data(), m, f.data(), var.data()));
             for (int64_t c = 0; c < m; ++c, ++e) {

@@ -159,7 +159,8 @@ double bohip_thompson_normal(uint64_t seed, int64_t s, int64_t j);
  * every side best value first, other rectangles along their first longest side).  Batched: every iteration's new centres are ONE
  * scoring call.
  *   bohip_direct_*  the host bookkeeping as an ask / tell object, for objectives evaluated by the caller (works without a device):
- *     ask   X = d x cap column-major; *n = points of this iteration (0: the search is over; cap = maxeval always suffices)
+ *     ask   X = d x cap column-major; *n = points of this iteration (0: the search is over).  cap = 0 (X may be NULL) only
+ *           reports *n; asking again hands out the same batch until it is told; cap < *n is BOHIP_E_ARG
  *     tell  their values in ask's order (NaN counts as -Inf)
  *     best  first maximum so far, its point, evaluations, iterations
  *   bohip_gp_direct_max  the whole search against a resident model in one call: acq_id = BOHIP_ACQ_* scores through bohip_gp_score;

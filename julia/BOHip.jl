@@ -470,13 +470,14 @@ function direct_l_search(f_batch, lb::Vector{Float64}, ub::Vector{Float64}, maxe
     d = length(lb)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(c_direct_create(d, lb, ub, max(1, maxeval), Float64(stopval), Float64(maxtime), h))
-    cap = max(maxeval, 2d, 1)
-    X = Matrix{Float64}(undef, d, cap)
+    X = Matrix{Float64}(undef, d, max(2d, 64))
     n = Ref(Int64(0))
     try
         while true
-            check(c_direct_ask(h[], X, cap, n))
+            check(c_direct_ask(h[], C_NULL, 0, n))               # size of this iteration's batch
             n[] == 0 && break
+            n[] > size(X, 2) && (X = Matrix{Float64}(undef, d, 2 * n[]))
+            check(c_direct_ask(h[], X, size(X, 2), n))
             F = Float64.(vec(f_batch(X[:, 1:n[]])))
             check(c_direct_tell(h[], F, n[]))
         end

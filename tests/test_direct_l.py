@@ -143,6 +143,9 @@ def test_direct_invariants_and_convergence():
         _lib.check(lib.bohip_direct_ask(h, X.ctypes.data_as(dp), 600, C.byref(n)))
         if n.value == 0:
             break
+        nq = C.c_int64()
+        _lib.check(lib.bohip_direct_ask(h, None, 0, C.byref(nq)))                                # size query (cap = 0) hands out nothing
+        assert nq.value == n.value
         # asking twice hands out the same batch
         X2 = np.empty((600, 3)); n2 = C.c_int64()
         _lib.check(lib.bohip_direct_ask(h, X2.ctypes.data_as(dp), 600, C.byref(n2)))
