@@ -188,7 +188,10 @@ struct DirectL {
 
     // best value so far (first maximum), its point in box coordinates
     double best(double* x) const {
-        if (F.empty()) return -INFINITY;
+        if (F.empty()) {                       // nothing told yet: the box's centre, as the first ask would hand out
+            if (x) { const std::vector<double> c(d, 0.5); to_x(c.data(), x); }
+            return -INFINITY;
+        }
         const int64_t jb = argmax_first();
         if (x) to_x(&C[jb * d], x);
         return F[jb];

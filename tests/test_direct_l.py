@@ -176,6 +176,9 @@ def test_bad_arguments_never_crash():
     lib.bohip_direct_destroy(None)
     ub = np.array([1.0, 2.0])
     _lib.check(lib.bohip_direct_create(2, lb.ctypes.data_as(dp), ub.ctypes.data_as(dp), 10, math.inf, 0.0, C.byref(h)))
+    bf = C.c_double(1.0); bx = np.zeros(2); ev = C.c_int64(-1)
+    _lib.check(lib.bohip_direct_best(h, C.byref(bf), bx.ctypes.data_as(dp), C.byref(ev), None))   # before anything was told
+    assert bf.value == -math.inf and np.array_equal(bx, [0.5, 1.5]) and ev.value == 0
     X = np.empty((1, 2)); n = C.c_int64()
     _lib.check(lib.bohip_direct_ask(h, X.ctypes.data_as(dp), 1, C.byref(n)))
     assert n.value == 1 and np.array_equal(X[0], [0.5, 1.5])
