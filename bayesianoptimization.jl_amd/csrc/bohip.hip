@@ -336,7 +336,8 @@ static int g_chol_exec_min = -1;  // BOHIP_CHOL_EXEC_MIN, row tiles.  Default: 4
 static int g_chol_exec_patience_us = 1000;   // BOHIP_CHOL_EXEC_PATIENCE_US: how long a workgroup only polls a held record before it takes other work meanwhile
 static int g_chol_exec_fill_inv = 1;    // a workgroup waiting for the counters of a claimed task runs inverse-wave tasks meanwhile (BOHIP_CHOL_EXEC_FILL_INV)
 static int g_chol_exec_inv_pairs = 0;   // inverse queue claimed one record (0) or one tile = two records (1) at a time (BOHIP_CHOL_EXEC_INV_PAIRS)
-static std::atomic<int> g_chol_inv_grp_min{40};   // row tiles from which the inverse queues take the GROUP form (exec_task_list); BOHIP_CHOL_INV_GRP_MIN
+static std::atomic<int> g_chol_inv_grp_min{28};   // row tiles from which the inverse queues take the GROUP form (exec_task_list); BOHIP_CHOL_INV_GRP_MIN.  40 until the end of
+                                                  // round 6: with that round's faster chain the group form wins from 28 row tiles on (28 ... 39 row tiles: -3 ... -7 %, 26: +3 %, 24: +4 %)
 static std::atomic<int> g_chol_inv_g{8};      // executor form: W = L^-1 is grown behind the chain by a fifth task queue, in pieces of this many 128-blocks
                                    // of contraction (BOHIP_CHOL_INV_G; 0 = off: the level-by-level inverse runs after the factorisation)
 static int g_chol_nsf = 3;         // solve-follower workgroups of the chain kernel in the executor form (BOHIP_CHOL_NSF, 1..6)

@@ -14,7 +14,7 @@ A dependency the builder forgot shows up as a wrong factor in the "tasks first" 
 dead-lock.  Three more rules of the device that a sequential replay would not notice by itself are enforced on the way: a location
 read through LDS-DMA is never written afterwards; W / W' tiles that are read through LDS-DMA are written exactly once (the XCDs' L2s
 do not see each other's stores); and the copy S -> L happens when the chain kernel's roles are done, after which nothing touches L.
-Both forms of the inverse queues are replayed (row by row, and the group form the library uses from 40 row tiles on).
+Both forms of the inverse queues are replayed (row by row, and the group form the library uses from 28 row tiles on).
 (No GPU needed: this is host logic.)"""
 import ctypes as C
 

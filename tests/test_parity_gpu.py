@@ -503,6 +503,31 @@ def test_direct_l_in_one_library_call(bohip, orc, N, d, maxeval):
     assert mu5[0] > np.quantile(y, 0.5)
 
 
+@pytest.mark.parametrize("N,d", [(3600, 6), (4900, 8)])
+def test_mid_size_refit_with_the_inverse_in_group_form_vs_oracle(bohip, orc, N, d):
+    """28 ... 39 row tiles: the sizes whose inverse queues take the group form since the end of round 6.  The whole
+    factor, alpha and the posterior at 300 candidates against the oracle; W against L (L W = I); the executor form ran and nothing timed out."""
+    from bohip import _lib
+
+    X, y, Xs = synth(N, d, 300, seed=7 * N)
+    ll = np.linspace(-0.9, -0.4, d)
+    L, alpha = orc.fit(X, y, ll, 0.1, -2.0, 0.2)
+    m = make_model(bohip, X, y, ll, 0.1, -2.0, 0.2)
+    m.fit_()
+    assert m.info(_lib.INFO_CHOL_FORM) == 4 and m.info(_lib.INFO_CHOL_FALLBACKS) == 0
+    s2f = math.exp(0.2)
+    np.testing.assert_allclose(m.factor(), L, rtol=1e-9, atol=1e-11 * math.sqrt(s2f))
+    np.testing.assert_allclose(m.alpha(), alpha, rtol=1e-6, atol=1e-9 * np.abs(alpha).max())
+    mu_o, var_o = orc.predict(X, ll, 0.1, 0.2, L, alpha, Xs, nthreads=8)
+    mu, var = m.predict_f(Xs.T)
+    assert np.all(np.abs(mu - mu_o) <= 1e-6 * np.abs(mu_o) + mu_floor(alpha, s2f))
+    assert np.all(np.abs(var - var_o) <= var_tol(var_o, N, s2f))
+    # sigma^2 = k** - |W k*|^2 uses W = L^-1 from the inverse queues: check it against the factor directly on random vectors
+    Kstar = np.exp(-0.5 * (((Xs[:4, None, :] - X[None, :, :]) / np.exp(ll)) ** 2).sum(-1)) * s2f     # (4, N)
+    v = np.linalg.solve(L, Kstar.T)                                                                 # L^-1 k*
+    np.testing.assert_allclose(s2f - (v ** 2).sum(0), var[:4], rtol=1e-7, atol=1e-9)
+
+
 # ---- BASELINE.json full sizes: size-independent properties + a bounded oracle sample ------------------
 def test_full_size_c2_properties(bohip, orc):
     N, d, R = 3000, 8, 4096
@@ -1005,7 +1030,7 @@ print("RESULT" + json.dumps(out))
         # the same without the inverse queues (W = L^-1 level by level after the factorisation), and with short pieces
         "executor-inverse-after": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_G="0"),
         "executor-inverse-pieces-of-2": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_G="2"),
-        # the inverse queues in their GROUP form (the default from 40 row tiles on) forced at every size, groups of 8 and of 3 blocks
+        # the inverse queues in their GROUP form (the default from 28 row tiles on) forced at every size, groups of 8 and of 3 blocks
         "executor-inverse-groups": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_GRP_MIN="0"),
         "executor-inverse-groups-of-3": dict(BOHIP_CHOL_DATAFLOW="2", BOHIP_CHOL_EXEC="1", BOHIP_CHOL_EXEC_MIN="4", BOHIP_CHOL_INV_GRP_MIN="0",
                                              BOHIP_CHOL_INV_G="3"),
