@@ -3167,17 +3167,20 @@ void bohip_direct_destroy(bohip_direct* s) { delete s; }
 int bohip_direct_ask(bohip_direct* s, double* X, int64_t cap, int64_t* n) {
     if (!s || !n || cap < 0 || (cap > 0 && !X)) return fail(BOHIP_E_ARG, "bad arguments");
     if (cap == 0) {   // size query: plans the iteration, hands out nothing yet
-        *n = s->s.plan_next();
+        try { *n = s->s.plan_next(); } catch (const std::exception& e) { return fail(BOHIP_E_ARG, e.what()); }
         return 0;
     }
-    const int64_t m = s->s.ask(X, cap);
+    int64_t m = 0;
+    try { m = s->s.ask(X, cap); } catch (const std::exception& e) { return fail(BOHIP_E_ARG, e.what()); }
     if (m < 0) return fail(BOHIP_E_ARG, "direct: the buffer is smaller than this iteration's batch (maxeval columns always suffice)");
     *n = m;
     return 0;
 }
 int bohip_direct_tell(bohip_direct* s, const double* f, int64_t n) {
     if (!s || !f || n < 1) return fail(BOHIP_E_ARG, "bad arguments");
-    if (!s->s.tell(f, n)) return fail(BOHIP_E_STATE, "direct: tell without a matching ask");
+    try {
+        if (!s->s.tell(f, n)) return fail(BOHIP_E_STATE, "direct: tell without a matching ask");
+    } catch (const std::exception& e) { return fail(BOHIP_E_ARG, e.what()); }   // (nothing throws across the ABI: allocation failures end here)
     return 0;
 }
 int bohip_direct_best(const bohip_direct* s, double* best_f, double* best_x, int64_t* evaluations, int64_t* iterations) {
@@ -3202,6 +3205,7 @@ int bohip_gp_direct_max(bohip_gp* g, int acq_id, const double* acq_params, const
     const int64_t d = g->d;
     for (int64_t i = 0; i < d; ++i)
         if (!(lb[i] <= ub[i])) return fail(BOHIP_E_ARG, "direct: lower bound above upper bound");
+    try {
     DirectL s(d, lb, ub, maxeval, stopval, maxtime);
     std::vector<double> X, f, var;
     int64_t calls = 0, e = 0;
@@ -3227,6 +3231,7 @@ int bohip_gp_direct_max(bohip_gp* g, int acq_id, const double* acq_params, const
     if (best_f) *best_f = bf;
     if (evaluations) *evaluations = s.evals;
     if (device_calls) *device_calls = calls;
+    } catch (const std::exception& e) { return fail(BOHIP_E_ARG, e.what()); }   // (nothing throws across the ABI)
     return 0;
 }
 
