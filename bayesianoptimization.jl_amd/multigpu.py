@@ -146,6 +146,23 @@ class MultiGPE:
                                               C.byref(ev)))
         return f, X, best.val, best.idx, bx, ev.value
 
+    def direct_max(self, acq, params, lowerbounds, upperbounds, maxeval=2000, stopval=float("inf"), maxtime=0.0, seed=0):
+        """:GN_DIRECT_L in one library call (ElasticGPE.direct_max, bohip_gp_direct_max) on the FIRST replica: an iteration of the search is a
+        handful of points that depend on the iteration before, so there is nothing to shard -- every device holds the whole model."""
+        lb = np.ascontiguousarray(lowerbounds, dtype=np.float64)
+        ub = np.ascontiguousarray(upperbounds, dtype=np.float64)
+        if lb.size != self.dim or ub.size != self.dim:
+            raise ValueError("bounds must have one entry per input dimension")
+        p = np.zeros(2)
+        if params is not None:
+            q = np.atleast_1d(np.asarray(params, dtype=np.float64))
+            p[:q.size] = q[:2]
+        g = self._lib.bohip_mgp_handle(self._h, 0)
+        bf = C.c_double(); bx = np.empty(self.dim); ev = C.c_int64(); dc = C.c_int64()
+        check(self._lib.bohip_gp_direct_max(g, _lib.ACQ[acq], _ptr(p), _ptr(lb), _ptr(ub), int(maxeval), float(stopval),
+                                            float(maxtime or 0.0), int(seed), C.byref(bf), _ptr(bx), C.byref(ev), C.byref(dc)))
+        return float(bf.value), bx, int(ev.value), int(dc.value)
+
     def replica_factor(self, i):
         """Cholesky factor held by the i-th device (tests: every replica is the same model)."""
         g = self._lib.bohip_mgp_handle(self._h, i)

@@ -48,6 +48,28 @@ def test_sharded_score_is_bit_identical_to_one_handle(bohip, N, d, R, spd):
     assert mg.score_resident("EI", [tau]) == one.score("EI", [tau], Xs.T)[1:]
 
 
+def test_direct_l_on_the_replicated_model_equals_one_handle(bohip):
+    """:GN_DIRECT_L on the device-list model runs on its first replica in one call: same search as on a single handle, through acquire_max too"""
+    from bohip.acquisition import acquire_max, UpperConfidenceBound
+
+    X, y, _ = synth(400, 3, 1, seed=77)
+    ll = np.linspace(-0.8, -0.3, 3)
+    one = make_model(bohip, X, y, ll, 0.1, -2.0, 0.05)
+    mg = make_multi(bohip, X, y, ll, 4, 0.1, -2.0, 0.05)
+    lb, ub = np.zeros(3), np.ones(3)
+    for acq, p in [("UCB", [2.0]), ("EI", [float(np.median(y))])]:
+        f1, x1, e1, c1 = one.direct_max(acq, p, lb, ub, 500)
+        f2, x2, e2, c2 = mg.direct_max(acq, p, lb, ub, 500)
+        assert (f1, e1, c1) == (f2, e2, c2) and np.array_equal(x1, x2)
+    d1 = one.direct_max("ThompsonDraw", None, lb, ub, 300, seed=9)
+    d2 = mg.direct_max("ThompsonDraw", None, lb, ub, 300, seed=9)
+    assert d1[0] == d2[0] and np.array_equal(d1[1], d2[1])
+    a = UpperConfidenceBound(beta_t=2.0)
+    fa, xa = acquire_max(a, mg, lb, ub, dict(method="GN_DIRECT_L", restarts=1, maxeval=500), setparams=False)
+    fb, xb = acquire_max(a, one, lb, ub, dict(method="GN_DIRECT_L", restarts=1, maxeval=500), setparams=False)
+    assert fa == fb and np.array_equal(xa, xb)
+
+
 def test_sharded_ties_and_nan_follow_the_reference_rule(bohip):
     """first maximum wins (src/acquisition.jl:62) across shard boundaries; NaN / -Inf records never win"""
     X, y, _ = synth(64, 2, 1, seed=5)
